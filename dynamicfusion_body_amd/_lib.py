@@ -1,0 +1,82 @@
+"""ctypes binding of libdfusion_hip.so (include/dfusion_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, the caller
+gets an exception.  Build with `python -m dynamicfusion_body_amd.build`.
+"""
+import ctypes
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libdfusion_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dfusion_hip.h")
+
+F32, F64 = 0, 1
+ABI_VERSION = 1
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+
+_SIGNATURES = {
+    "dfh_version": (_int, []),
+    "dfh_last_error": (ctypes.c_char_p, []),
+    "dfh_stream_synchronize": (_int, [_vp]),
+    "dfh_integrate_depth": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _int, _vp, _int, _int, _int,
+                                   _c_double_p, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp]),
+}
+
+_lib = None
+
+
+class DfhError(RuntimeError):
+    pass
+
+
+def declared_symbols(header=HEADER_PATH):
+    """Every function the public header declares (used by the symbol-export test)."""
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DfhError("%s not found: the HIP library is the only implementation of this path "
+                       "(no CPU fallback). Build it with `python -m dynamicfusion_body_amd.build`." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.dfh_version()
+    if v != ABI_VERSION:
+        raise DfhError("libdfusion_hip.so ABI version %d != expected %d (rebuild)" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dfh_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError("%s: %s" % (what, msg))
+        raise DfhError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def darr(values, n):
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))
+    if a.size != n:
+        raise ValueError("expected %d values, got %d" % (n, a.size))
+    return (ctypes.c_double * n)(*a.tolist())
+
+
+def iarr(values):
+    vals = [int(v) for v in values]
+    return (ctypes.c_int * len(vals))(*vals)

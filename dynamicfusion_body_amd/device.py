@@ -1,0 +1,49 @@
+"""Device-memory plumbing on PyTorch-ROCm tensors (torch is the allocator / stream
+provider here, not the compute path)."""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.DfhError("no HIP device visible: this path only runs on the GPU (no CPU fallback)")
+
+
+def current_stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return _lib.F32
+    if t.dtype == torch.float64:
+        return _lib.F64
+    raise ValueError("only float32 / float64 device tensors are supported, got %s" % t.dtype)
+
+
+def torch_dtype(d):
+    if isinstance(d, torch.dtype):
+        if d not in (torch.float32, torch.float64):
+            raise ValueError("volume dtype must be float32 or float64")
+        return d
+    return {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[np.dtype(d)]
+
+
+def to_device(a, dtype=None, device=None):
+    """numpy array or tensor -> contiguous device tensor (copies only when needed)."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    if isinstance(a, torch.Tensor):
+        t = a.to(device=device, dtype=dtype or a.dtype)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype)
+    return t.contiguous()
+
+
+def f32_exact(a):
+    """True if every value of the float array survives a round trip through float32."""
+    a = np.asarray(a)
+    if a.dtype == np.float32:
+        return True
+    return bool(np.array_equal(a.astype(np.float32).astype(a.dtype), a))

@@ -1,0 +1,194 @@
+"""`FusionDM` with the reference's call surface (reference core/fusion_dm.py:53-354),
+running its per-voxel hot methods as HIP kernels on an MI355X.
+
+The reference's own device plug-in is a subclass overriding one numpy-in / numpy-out
+method (class FusionDM_GPU, core/fusion_dm.py:563-574,600); this class keeps the same
+method names, argument order, in-place + return ownership and ValueError behaviour, so
+`FusionDM(tdist, K, tsdf_res=...)` / `.fuseDepths(...)` / `.compute_live_tsdf(...)` /
+`.updateTSDF(...)` / `.computef_lw(...)` / `.solve(...)` call sites keep working.
+
+What differs, on purpose:
+  * volumes live on the GPU as float32 (16 B/voxel read-modify-write; pass
+    `volume_dtype=np.float64` for bit-for-bit float64 volumes).  `_tsdf` / `_tsdfw` are
+    properties that download on read and upload on assignment;
+  * methods accept CUDA tensors wherever the reference takes numpy arrays, and then work
+    in place without host round trips;
+  * semantics are the reference's CPU path (fuseDepths :180-217), not its OpenCL kernel
+    (:600-737), which computes something else;
+  * no CPU fallback: without the HIP library / a GPU the hot methods raise.
+"""
+import numpy as np
+import torch
+from numpy import linalg as la
+
+from . import kernels
+from .device import f32_exact, require_gpu, to_device, torch_dtype
+
+
+def _is_tensor(a):
+    return isinstance(a, torch.Tensor)
+
+
+class FusionDM:
+    def __init__(self, trunc_distance, K, tsdf_res=256, subsample_rate=5.0, knn=4, marching_cubes_step_size=3,
+                 verbose=False, write_warpfield=True, volume_dtype=np.float32):
+        # attribute set of the reference ctor, core/fusion_dm.py:57-81
+        self._itercounter = 0
+        self._curr_tsdf = None
+        self._tdist = abs(trunc_distance)
+        self._tsdf_res = tsdf_res
+        self._vol_dtype = torch_dtype(volume_dtype)
+        self._T = None          # device volumes, allocated lazily (ctor must work without a GPU)
+        self._Wt = None
+        self._lw = np.array([1, 0, 0, 0, 0, 0, 0, 0], dtype=np.float32)
+
+        K = np.asarray(K, dtype=np.float64)
+        if K.shape != (3, 3):
+            raise ValueError('intrinsic matrix K must be 3x3')
+        self._K = K
+        self._Kinv = la.inv(K)
+
+        self._IND = np.eye(4)
+        self._INDinv = la.inv(self._IND)
+
+        self._knn = knn
+        self._marching_cubes_step_size = marching_cubes_step_size
+        self._subsample_rate = subsample_rate
+        self._nodes = []
+        self._neighbor_look_up = []
+        self._correspondences = []
+        self._corridx = []
+        self._vertices = None
+        self._normals = None
+        self._kdtree = None
+        self._verbose = verbose
+        self._write_warpfield = write_warpfield
+
+    # ------------------------------------------------------------------ volumes
+    def _new_volume_pair(self, res=None):
+        require_gpu()
+        r = self._tsdf_res if res is None else res
+        shape = (r, r, r) if np.isscalar(r) else tuple(r)
+        T = torch.full(shape, self._tdist, dtype=self._vol_dtype, device="cuda")      # :61 / :100
+        Wt = torch.zeros(shape, dtype=self._vol_dtype, device="cuda")                 # :62 / :101
+        return T, Wt
+
+    def _ensure_volumes(self):
+        if self._T is None:
+            self._T, self._Wt = self._new_volume_pair()
+
+    @property
+    def _tsdf(self):
+        self._ensure_volumes()
+        return self._T.cpu().numpy().astype(np.float64)
+
+    @_tsdf.setter
+    def _tsdf(self, value):
+        self._T = to_device(value, dtype=self._vol_dtype)
+
+    @property
+    def _tsdfw(self):
+        self._ensure_volumes()
+        return self._Wt.cpu().numpy().astype(np.float64)
+
+    @_tsdfw.setter
+    def _tsdfw(self, value):
+        self._Wt = to_device(value, dtype=self._vol_dtype)
+
+    @property
+    def tsdf_device(self):
+        """The resident TSDF / weight tensors (no copy)."""
+        self._ensure_volumes()
+        return self._T, self._Wt
+
+    # ------------------------------------------------------------------ A1
+    def _depth_to_device(self, dm):
+        if _is_tensor(dm):
+            if dm.dim() != 2:
+                raise ValueError('depth map must be 2-D')
+            d = dm if dm.dtype in (torch.float32, torch.float64) else dm.to(torch.float32)
+            return to_device(d)
+        dm = np.asarray(dm)
+        if dm.ndim != 2:
+            raise ValueError('depth map must be 2-D')
+        # float32 on device unless that would change a value (then masks could flip)
+        return to_device(dm, dtype=torch.float32 if f32_exact(dm) else torch.float64)
+
+    def fuseDepths(self, dm, lw, tsdf, tsdf_w, scale=1.0, center=np.zeros(3), wmax=100.0):
+        """Integrate one depth map into (tsdf, tsdf_w); reference core/fusion_dm.py:180-217.
+
+        numpy volumes are updated in place AND returned (the reference mutates through
+        np.nditer and returns the same arrays, :186,:217); CUDA tensors are updated in place
+        with no host traffic."""
+        lw = np.asarray(lw, dtype=np.float64)
+        if lw.shape != (3, 4):
+            raise ValueError('lw must be a 3x4 camera extrinsic')
+        depth = self._depth_to_device(dm)
+        if _is_tensor(tsdf) != _is_tensor(tsdf_w):
+            raise ValueError('tsdf and tsdf_w must both be numpy arrays or both CUDA tensors')
+        if _is_tensor(tsdf):
+            kernels.integrate_depth(tsdf, tsdf_w, depth, self._K, self._Kinv, lw, scale, center, self._tdist,
+                                    wmax, tsdf_res=self._tsdf_res)
+            return (tsdf, tsdf_w)
+        if tsdf.ndim != 3 or tsdf.shape != tsdf_w.shape:
+            raise ValueError('tsdf and tsdf_w must be 3-D arrays of the same shape')
+        T = to_device(tsdf, dtype=self._vol_dtype)
+        Wt = to_device(tsdf_w, dtype=self._vol_dtype)
+        kernels.integrate_depth(T, Wt, depth, self._K, self._Kinv, lw, scale, center, self._tdist, wmax,
+                                tsdf_res=self._tsdf_res)
+        tsdf[...] = T.cpu().numpy()
+        tsdf_w[...] = Wt.cpu().numpy()
+        return (tsdf, tsdf_w)
+
+    # ------------------------------------------------------------------ driver
+    def _auto_alignment(self, depths, lws):
+        """Centre / spread of the back-projected depth pixels (intent of
+        core/fusion_dm.py:110-134; that loop cannot run for more than one view at HEAD
+        because `avgs` is turned into an ndarray inside it, :131)."""
+        avgs, stds = [], []
+        for dm, A in zip(depths, lws):
+            dm = dm.cpu().numpy() if _is_tensor(dm) else np.asarray(dm)
+            A = np.asarray(A, dtype=np.float64)
+            rows, cols = np.nonzero(dm)
+            uv = -1 * dm[rows, cols][:, None] * np.stack([cols, rows, np.ones_like(rows)], axis=1).astype(float)
+            pos3 = uv @ self._Kinv.T
+            Rinv = la.inv(A[:, :3])
+            pts = (pos3 - A[:, 3]) @ Rinv.T
+            avgs.append(np.average(pts, axis=0))
+            stds.append(np.std(pts, axis=0))
+        return np.average(np.array(avgs), axis=0), float(np.average(np.array(stds)))
+
+    def compute_live_tsdf(self, depths, lws, UseAutoAlignment=False, useICP=False, outputMesh=False,
+                          as_numpy=True):
+        """Fuse a set of depth maps into a fresh volume; reference core/fusion_dm.py:95-178.
+        The volume stays on the GPU across views; `as_numpy=False` returns the CUDA
+        tensors instead of downloading them."""
+        if len(depths) != len(lws):
+            raise ValueError('length of camera matrix array Ks must equal that of depth maps')   # :96-97
+        if useICP:
+            raise NotImplementedError('useICP needs marching-cubes correspondences '
+                                      '(core/fusion_dm.py:219-244), outside this hot path')
+        if outputMesh:
+            raise NotImplementedError('outputMesh needs marching cubes (core/fusion_dm.py:339-354), '
+                                      'outside this hot path')
+        avg = np.array([-0.03, -0.43, -5.6], dtype='float32')       # :106-107
+        std = 1.3
+        if UseAutoAlignment:
+            avg, std = self._auto_alignment(depths, lws)
+
+        res = self._tsdf_res
+        scale = 8 * std / res                                       # :136-141
+        self._IND[0, 0] = scale
+        self._IND[1, 1] = scale
+        self._IND[2, 2] = scale
+        self._IND[0:3, 3] = avg - scale * res / 2
+        self._INDinv = la.inv(self._IND)
+
+        T, Wt = self._new_volume_pair()
+        for idx in range(len(depths)):                              # :166-170
+            self._depthidx = idx
+            self.fuseDepths(depths[idx], lws[idx], T, Wt, scale=12 * std / res, center=avg)
+        self._T, self._Wt = T, Wt
+        if as_numpy:
+            return (self._tsdf, self._tsdfw)
+        return (T, Wt)

@@ -1,0 +1,74 @@
+/* dfusion_hip.h -- C ABI of libdfusion_hip.so, the MI355X (gfx950) implementation of the
+ * per-frame DynamicFusion hot path of nintendops/DynamicFusion_Body.
+ *
+ * The reference has no FFI: its own device plug-in is a Python subclass overriding one
+ * numpy-in/numpy-out method (class FusionDM_GPU, core/fusion_dm.py:563-574,600).  This
+ * library is what such an override binds through ctypes; every entry
+ * point names the reference function whose arithmetic it reproduces.
+ *
+ * Conventions
+ *  - All array pointers are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()) unless
+ *    the parameter is a small fixed-size `const double[...]`, which is HOST memory read
+ *    during the call (mask arithmetic is fp64, so small matrices travel as doubles).
+ *  - Volumes are C-ordered [x][y][z], z fastest (np.nditer order, core/fusion_dm.py:186;
+ *    the OpenCL kernel's idx = x*RES_Z*RES_Y + y*RES_Z + z, :637).  A volume buffer holds
+ *    the axis-0 planes [x0, x1) of a res[0] x res[1] x res[2] grid (slab partition across
+ *    GPUs); voxel indices used in the arithmetic are always GLOBAL.
+ *  - `vol_dtype` / `depth_dtype`: DFH_F32 or DFH_F64.  fp32 volumes are the product
+ *    layout (16 B/voxel read-modify-write); fp64 volumes reproduce the reference's float64
+ *    arrays bit for bit and exist for parity checking.
+ *  - Calls are asynchronous on `stream` (a hipStream_t; NULL = default stream).
+ *  - Return value: 0 on success, <0 on error (DFH_E_*); dfh_last_error() describes the
+ *    last failure on the calling thread.  Nothing throws across the ABI.
+ */
+#ifndef DFUSION_HIP_H
+#define DFUSION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFH_ABI_VERSION 1
+
+#define DFH_F32 0
+#define DFH_F64 1
+
+#define DFH_OK 0
+#define DFH_E_BADARG (-1)
+#define DFH_E_HIP (-2)
+#define DFH_E_UNSUPPORTED (-3)
+
+/* ABI version of the loaded library (== DFH_ABI_VERSION of the header it was built from). */
+int dfh_version(void);
+
+/* Message for the last non-zero return on this thread ("" if none). */
+const char *dfh_last_error(void);
+
+/* Blocks until `stream` has drained (hipStreamSynchronize). */
+int dfh_stream_synchronize(void *stream);
+
+/* A1  FusionDM.fuseDepths(dm, lw, tsdf, tsdf_w, scale, center, wmax)  core/fusion_dm.py:180-217
+ * (CPU-path semantics; the OpenCL variant :600-737 is NOT what is reproduced).
+ * For every voxel i=(x,y,z), x in [x0,x1):
+ *   pos  = scale*(i - tsdf_res/2) + center                       (:183,:191)
+ *   lpos = lw*[pos,1];  (u,v) = (K*lpos)_{0,1}/(K*lpos)_2, skipped if (K*lpos)_2 == 0   (:193-194)
+ *   visible iff 0<=u<W-1 and 0<=v<H-1                            (:195)
+ *   z = -depth[rint(v)][rint(u)] (round-half-even), valid iff z>0   (:196-197)
+ *   sd = (Kinv*(z*[u,v,1]))_2 - lpos_2;  update iff sd > -tdist   (:198-203)
+ *   T <- (scale*T*w + min(tdist,sd)) / (scale*(1+w));  w <- min(1+w, wmax)   (:209-210)
+ * tsdf/tsdf_w: planes [x0,x1) of the volume, dtype vol_dtype.  depth: H x W row-major,
+ * negative depths, 0 = no measurement, dtype depth_dtype.  K, Kinv: 3x3 row-major;
+ * lw: 3x4 row-major; center: 3.  tsdf_res is the ctor's tsdf_res (:60,:183). */
+int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res,
+                        int x0, int x1, const void *depth, int depth_dtype, int H, int W,
+                        const double K[9], const double Kinv[9], const double lw[12],
+                        double scale, const double center[3], double tdist, double wmax,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFUSION_HIP_H */

@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 RES = 256
-VIEW_ANGLES = (0.0, 45.0, 90.0, 135.0)
+VIEW_ANGLES = (0.0, 30.0, -45.0, 60.0)      # all in front of the wall: every view updates voxels
 
 
 def parse():
@@ -43,6 +43,26 @@ def parse():
     ap.add_argument("--res", type=int, default=RES, help="per-rank slab is res^3 (default = BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
+
+
+def pmc_traffic(kernel_substr, res):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    of this same command (profiles/<tag>_summary.json, written by tools/summarize_profile.py:
+    2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md §HBM).  None when no matching profile."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+            line = json.loads(d["bench_line"])
+            if line["config"]["grid"][1] != res:
+                continue
+            for name, t in d["traffic"].items():
+                if kernel_substr in name:
+                    best = (t["hbm_bytes_per_launch"], os.path.basename(f))
+        except Exception:
+            continue
+    return best
 
 
 def main():
@@ -136,6 +156,11 @@ def main():
                      "kernel": "integrate_depth_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
+
+    tr = pmc_traffic("integrate_depth_kernel", R)
+    if tr is not None:
+        out["roofline"]["traffic"] = tr[0]
+        out["roofline"]["traffic_source"] = "profiles/" + tr[1]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle_np as O           # checker timed as the CPU baseline, never the product

@@ -3,11 +3,29 @@
 //
 // Mapping: volumes are [x][y][z] with z fastest, so consecutive lanes take consecutive
 // z-packs (VEC voxels = one 16-byte fp32 access) of one (x,y) row: every wave reads and
-// writes whole 1-KiB lines of T and w.  The geometric chain that decides the masks
-// (projection, bounds, round-half-even pixel, z>0, sd>-tdist) runs in IEEE fp64 with the
-// reference's operation order (library is built with -ffp-contract=off), so the masks are
-// bit-identical to the fp64 CPU path; only the final T is rounded to the volume dtype.
+// writes whole 1-KiB lines of T and w, and only rows that are actually updated are touched.
+//
+// Arithmetic.  The reference decides everything in float64: visible iff 0<=u<W-1 etc.,
+// pixel = round-half-even(u), update iff sd > -tdist.  Two per-voxel evaluators:
+//   exact_voxel() -- IEEE fp64, the reference's operation order (library is built with
+//                    -ffp-contract=off): bit-identical to the fp64 CPU path.
+//   the FAST path -- for fp32 volumes: index -> (p0,p1,p2,l2) through one host-folded affine
+//                    map (one FMA per component and voxel), one v_rcp_f64 + one Newton step
+//                    (measured 2^-48.7 relative, profiles/ubench_r1.txt) instead of two IEEE
+//                    divisions, the pixel / frustum decisions in 2^-20-pixel fixed point on
+//                    the int32 ALU, and the sd > -tdist decision on float32 differences.
+//                    Error budget: < 2^-19 px for u,v; < 2.4e-7*max(|l2|,|z|) m for the
+//                    margin.  Whenever a voxel is closer than a guard band (8*2^-20 px;
+//                    1e-5 + 2e-6*|l2| m) to ANY decision boundary it is re-evaluated with
+//                    exact_voxel(), so the masks are still bit-identical to the fp64 path
+//                    (tests assert this on every voxel).  The running average is evaluated
+//                    as (T*w + m/scale)/(1+w) in float32 (FMA + corrected reciprocal,
+//                    <= 2 ulp), the same quotient as the reference's
+//                    (scale*T*w + m)/(scale*(1+w)).
+// fp64 volumes always use exact_voxel() and IEEE fp64 division for the running average.
 #include "dfh_common.h"
+
+#include <cstdlib>
 
 namespace dfh {
 
@@ -20,78 +38,246 @@ struct IntegrateParams {
     Mat3 K, Kinv;
     Mat34 lw;
     double scale, cx, cy, cz, half, tdist, wmax;
+    // FAST path: component r of (2^20*p0, 2^20*p1, p2, l2) = Ax[r]*x + Ay[r]*y + Az[r]*z + Ac[r]
+    double Ax[4], Ay[4], Az[4], Ac[4];
+    double inv_scale;
+    float tdist_f, ts_f, wmax_f;   // tdist, tdist/scale, wmax rounded to float32
+    int zp_shift;      // log2(zpacks) if zpacks is a power of two, else -1
+    int planes_per_block;   // each block sweeps this many consecutive x planes (tuning knob)
     int X, Y, Z;       // global grid dims
     int x0, nx;        // slab: planes [x0, x0+nx)
     int H, W;
     int zpacks;        // ceil(Z / VEC)
 };
 
-template <typename VolT, typename DepthT, int VEC, bool PINHOLE>
-__global__ __launch_bounds__(256) void integrate_depth_kernel(VolT *__restrict__ tsdf,
-                                                               VolT *__restrict__ tsdf_w,
+constexpr int kFixShift = 20;                   // pixel coordinates in 2^-20 px fixed point
+constexpr int kFixOne = 1 << kFixShift;
+constexpr int kFixHalf = 1 << (kFixShift - 1);
+constexpr int kFixBand = 8;                     // guard band around multiples of 0.5 px
+constexpr int kFastMaxDim = 2048;               // (dim-1) << 20 must fit in int32
+constexpr long kTargetBlocks = 1L << 40;        // measured (profiles/kbench_r1.txt): one plane per block is
+                                                // fastest at 256^3 and 512^3; the plane loop stays as a knob
+
+// The reference's per-voxel chain, fusion_dm.py:191-203, in its own operation order.
+template <typename DepthT, bool PINHOLE>
+__device__ __forceinline__ bool exact_voxel(const IntegrateParams &p, const DepthT *__restrict__ depth,
+                                            int x, int y, int z, double &sd_out) {
+    const double *lw = p.lw.m;
+    const double px = p.scale * ((double)x - p.half) + p.cx;       // :191
+    const double py = p.scale * ((double)y - p.half) + p.cy;
+    const double pz = p.scale * ((double)z - p.half) + p.cz;
+    const double l0 = ((lw[0] * px + lw[1] * py) + lw[2] * pz) + lw[3];     // :193
+    const double l1 = ((lw[4] * px + lw[5] * py) + lw[6] * pz) + lw[7];
+    const double l2 = ((lw[8] * px + lw[9] * py) + lw[10] * pz) + lw[11];
+    double p0, p1, p2;
+    if (PINHOLE) {          // K = [[fx,0,cx],[0,fy,cy],[0,0,1]]: the dropped terms are exact zeros
+        p0 = p.K.m[0] * l0 + p.K.m[2] * l2;
+        p1 = p.K.m[4] * l1 + p.K.m[5] * l2;
+        p2 = l2;
+    } else {
+        p0 = (p.K.m[0] * l0 + p.K.m[1] * l1) + p.K.m[2] * l2;
+        p1 = (p.K.m[3] * l0 + p.K.m[4] * l1) + p.K.m[5] * l2;
+        p2 = (p.K.m[6] * l0 + p.K.m[7] * l1) + p.K.m[8] * l2;
+    }
+    sd_out = 0.0;
+    if (!(p2 != 0.0)) return false;                                 // util.py:318
+    const double u = p0 / p2;
+    const double v = p1 / p2;
+    if (!((u >= 0.0) && (u < (double)(p.W - 1)) && (v >= 0.0) && (v < (double)(p.H - 1)))) return false;  // :195
+    const int ui = (int)rint(u);                                    // Python round(): half to even (:196)
+    const int vi = (int)rint(v);
+    const double zd = -1.0 * (double)depth[(size_t)vi * p.W + ui];
+    if (!(zd > 0.0)) return false;                                  // :197
+    double cz;
+    if (PINHOLE) {
+        cz = zd;                                                    // Kinv row 2 == [0,0,1]
+    } else {
+        cz = (p.Kinv.m[6] * (zd * u) + p.Kinv.m[7] * (zd * v)) + p.Kinv.m[8] * (zd * 1.0);
+    }
+    const double sd = cz - l2;                                      // :201
+    sd_out = sd;
+    return sd > -1.0 * p.tdist;                                     // :203
+}
+
+// Rare-path wrapper: the coordinates are laundered through empty asm so the compiler cannot
+// hoist the exact chain's loop-invariant arithmetic out of the (almost never taken) branch.
+template <typename DepthT, bool PINHOLE>
+__device__ __forceinline__ bool exact_voxel_rare(const IntegrateParams &p, const DepthT *__restrict__ depth,
+                                                 int x, int y, int z, double &sd_out) {
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+    return exact_voxel<DepthT, PINHOLE>(p, depth, x, y, z, sd_out);
+}
+
+__device__ __forceinline__ double rcp_nr1(double d) {      // relative error <= 2^-48.7 (measured)
+    const double r = __builtin_amdgcn_rcp(d);
+    return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+}
+
+__device__ __forceinline__ void pack_coords(const IntegrateParams &p, int &y, int &zp) {
+    const int lin = blockIdx.x * 256 + threadIdx.x;      // (y, zpack) inside one x plane
+    if (p.zp_shift >= 0) {
+        y = lin >> p.zp_shift;
+        zp = lin & ((1 << p.zp_shift) - 1);
+    } else {
+        y = lin / p.zpacks;
+        zp = lin - y * p.zpacks;
+    }
+}
+
+// fp32 volumes: filtered fast path with exact fallback (see file header).
+template <typename DepthT, int VEC, bool PINHOLE>
+__global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict__ tsdf,
+                                                               float *__restrict__ tsdf_w,
                                                                const DepthT *__restrict__ depth,
                                                                const IntegrateParams p) {
-    const int lin = blockIdx.x * 256 + threadIdx.x;      // (y, zpack) inside one x plane
-    const int y = lin / p.zpacks;
-    const int zp = lin - y * p.zpacks;
+    int y, zp;
+    pack_coords(p, y, zp);
     if (y >= p.Y) return;
-    const int xl = blockIdx.y;                           // local plane
     const int z0 = zp * VEC;
+    constexpr int NC = PINHOLE ? 3 : 4;
+    const unsigned ulim = (unsigned)(p.W - 1) << kFixShift;
+    const unsigned vlim = (unsigned)(p.H - 1) << kFixShift;
+    const int xl_end = min(p.nx, (int)(blockIdx.y + 1) * p.planes_per_block);
+  for (int xl = blockIdx.y * p.planes_per_block; xl < xl_end; ++xl) {
+    const int x = p.x0 + xl;
+    double base[NC];
+    {
+        const double xf = (double)x, yf = (double)y, zf = (double)z0;
+#pragma unroll
+        for (int r = 0; r < NC; ++r)
+            base[r] = __builtin_fma(p.Az[r], zf, __builtin_fma(p.Ax[r], xf, __builtin_fma(p.Ay[r], yf, p.Ac[r])));
+    }
+    // p2 is affine in z: if both ends of the pack are well away from the camera plane and on
+    // the same side, so is everything between; otherwise the whole pack goes the exact way.
+    const double p2_last = __builtin_fma(p.Az[2], (double)(VEC - 1), base[2]);
+    const bool pack_singular = !((fabs(base[2]) > 1e-6) & (fabs(p2_last) > 1e-6) & ((base[2] > 0.0) == (p2_last > 0.0)));
 
-    // pos = scale*(i - res/2) + center   (fusion_dm.py:191)
-    const double px = p.scale * ((double)(p.x0 + xl) - p.half) + p.cx;
-    const double py = p.scale * ((double)y - p.half) + p.cy;
-    const double *lw = p.lw.m;
-    // ((lw0*px + lw1*py) + lw2*pz) + lw3: the x/y partial sums are shared by the z-pack
-    const double a0 = lw[0] * px + lw[1] * py;
-    const double a1 = lw[4] * px + lw[5] * py;
-    const double a2 = lw[8] * px + lw[9] * py;
+    // phase 1: project the z-pack; frustum membership and pixel in 2^-20 px fixed point
+    double l2v[VEC];
+    float l2f[VEC];
+    unsigned pix[VEC];
+    bool inside[VEC], amb[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const double jf = (double)j;
+        const double p0 = __builtin_fma(p.Az[0], jf, base[0]);      // 2^20 * p0
+        const double p1 = __builtin_fma(p.Az[1], jf, base[1]);      // 2^20 * p1
+        const double p2 = __builtin_fma(p.Az[2], jf, base[2]);
+        l2v[j] = PINHOLE ? p2 : __builtin_fma(p.Az[NC - 1], jf, base[NC - 1]);
+        l2f[j] = (float)l2v[j];
+        const double r = rcp_nr1(p2);
+        const int qu = (int)(p0 * r);                    // trunc, saturating; NaN -> 0 (inside the band)
+        const int qv = (int)(p1 * r);
+        // distance to the nearest multiple of 0.5 px: pixel ties AND the integer frustum edges
+        const unsigned du = (unsigned)((qu + kFixBand) & (kFixHalf - 1));
+        const unsigned dv = (unsigned)((qv + kFixBand) & (kFixHalf - 1));
+        amb[j] = pack_singular | ((du < dv ? du : dv) <= 2u * kFixBand);
+        inside[j] = ((unsigned)qu < ulim) & ((unsigned)qv < vlim);
+        const int ui = (qu + kFixHalf) >> kFixShift;
+        const int vi = (qv + kFixHalf) >> kFixShift;
+        pix[j] = inside[j] ? (unsigned)(__mul24(vi, p.W) + ui) : 0u;
+    }
+    // phase 2: every depth gather of the pack in flight together (pixel 0 when outside)
+    DepthT dval[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dval[j] = depth[pix[j]];
+    // phase 3: sd > -tdist on float32 differences; guard-banded voxels re-run exactly
+    float ms[VEC];              // min(tdist, sd) / scale
+    bool upd[VEC];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float zdf = -(float)dval[j];
+        const bool hit = inside[j] & (zdf > 0.0f);
+        bool ok, redo, freespace;
+        if (PINHOLE) {
+            const float d32 = zdf - (l2f[j] - p.tdist_f);            // ~ sd + tdist
+            const float band = fmaf(fabsf(l2f[j]), 2e-6f, 1e-5f);
+            ok = hit & (d32 > 0.0f);
+            redo = amb[j] | (hit & (fabsf(d32) <= band));
+            freespace = d32 > 2.0f * p.tdist_f + band;               // sd > tdist for certain
+        } else {
+            ok = hit;
+            redo = amb[j];
+            freespace = false;
+        }
+        float m = p.ts_f;
+        if (__builtin_expect(redo, 0)) {
+            double sd;
+            ok = exact_voxel_rare<DepthT, PINHOLE>(p, depth, x, y, z0 + j, sd);
+            m = (float)((sd < p.tdist ? sd : p.tdist) * p.inv_scale);
+        } else if (ok & !freespace) {
+            double cz = -(double)dval[j];
+            if (!PINHOLE) {
+                // u, v to ~1e-12 px from the folded map; only the value depends on them here
+                const double jf = (double)j;
+                const double r = rcp_nr1(__builtin_fma(p.Az[2], jf, base[2])) * (1.0 / (double)kFixOne);
+                const double u = __builtin_fma(p.Az[0], jf, base[0]) * r;
+                const double v = __builtin_fma(p.Az[1], jf, base[1]) * r;
+                cz = __builtin_fma(p.Kinv.m[6] * cz, u, __builtin_fma(p.Kinv.m[7] * cz, v, p.Kinv.m[8] * cz));
+            }
+            const double sd = cz - l2v[j];
+            if (!PINHOLE) {
+                const double margin = sd + p.tdist;
+                ok = margin > 0.0;
+                if (fabs(margin) < 1e-7) ok = exact_voxel_rare<DepthT, PINHOLE>(p, depth, x, y, z0 + j, cz);
+            }
+            m = (float)((sd < p.tdist ? sd : p.tdist) * p.inv_scale);
+        }
+        ok = ok & (z0 + j < p.Z);
+        ms[j] = m;
+        upd[j] = ok;
+        any = any | ok;
+    }
+    if (!any) continue;
 
+    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
+    using P = Pack<float, VEC>;
+    P t = *reinterpret_cast<const P *>(tsdf + off);
+    P w = *reinterpret_cast<const P *>(tsdf_w + off);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        // T <- (T*w + m/scale)/(1+w);  w <- min(1+w, wmax)          (fusion_dm.py:209-210)
+        const float wt = w.v[j];
+        const float d = wt + 1.0f;
+        const float n = fmaf(t.v[j], wt, ms[j]);
+        const float r = __builtin_amdgcn_rcpf(d);
+        float q = n * r;
+        q = fmaf(fmaf(-d, q, n), r, q);
+        t.v[j] = upd[j] ? q : t.v[j];
+        w.v[j] = upd[j] ? fminf(d, p.wmax_f) : wt;
+    }
+    *reinterpret_cast<P *>(tsdf + off) = t;
+    *reinterpret_cast<P *>(tsdf_w + off) = w;
+  }
+}
+
+// Any volume dtype: the reference's chain evaluated exactly for every voxel.
+template <typename VolT, typename DepthT, int VEC, bool PINHOLE>
+__global__ __launch_bounds__(256) void integrate_depth_exact_kernel(VolT *__restrict__ tsdf,
+                                                                     VolT *__restrict__ tsdf_w,
+                                                                     const DepthT *__restrict__ depth,
+                                                                     const IntegrateParams p) {
+    int y, zp;
+    pack_coords(p, y, zp);
+    if (y >= p.Y) return;
+    const int z0 = zp * VEC;
+    const int xl_end = min(p.nx, (int)(blockIdx.y + 1) * p.planes_per_block);
+  for (int xl = blockIdx.y * p.planes_per_block; xl < xl_end; ++xl) {
+    const int x = p.x0 + xl;
     double sdv[VEC];
     bool upd[VEC];
     bool any = false;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int z = z0 + j;
-        const double pz = p.scale * ((double)z - p.half) + p.cz;
-        const double l0 = (a0 + lw[2] * pz) + lw[3];
-        const double l1 = (a1 + lw[6] * pz) + lw[7];
-        const double l2 = (a2 + lw[10] * pz) + lw[11];
-        double p0, p1, p2;
-        if (PINHOLE) {          // K = [[fx,0,cx],[0,fy,cy],[0,0,1]]: the dropped terms are exact zeros
-            p0 = p.K.m[0] * l0 + p.K.m[2] * l2;
-            p1 = p.K.m[4] * l1 + p.K.m[5] * l2;
-            p2 = l2;
-        } else {
-            p0 = (p.K.m[0] * l0 + p.K.m[1] * l1) + p.K.m[2] * l2;
-            p1 = (p.K.m[3] * l0 + p.K.m[4] * l1) + p.K.m[5] * l2;
-            p2 = (p.K.m[6] * l0 + p.K.m[7] * l1) + p.K.m[8] * l2;
-        }
-        bool ok = (z < p.Z) && (p2 != 0.0);              // util.py:318
-        const double u = p0 / p2;
-        const double v = p1 / p2;
-        ok = ok && (u >= 0.0) && (u < (double)(p.W - 1)) && (v >= 0.0) && (v < (double)(p.H - 1));  // :195
         double sd = 0.0;
-        if (ok) {
-            const int ui = (int)rint(u);                 // Python round(): half to even (:196)
-            const int vi = (int)rint(v);
-            const double zd = -1.0 * (double)depth[(size_t)vi * p.W + ui];
-            ok = zd > 0.0;                               // :197
-            double cz;
-            if (PINHOLE) {
-                cz = zd;                                 // Kinv row 2 == [0,0,1]
-            } else {
-                cz = (p.Kinv.m[6] * (zd * u) + p.Kinv.m[7] * (zd * v)) + p.Kinv.m[8] * (zd * 1.0);
-            }
-            sd = cz - l2;                                // :201
-            ok = ok && (sd > -1.0 * p.tdist);            // :203
-        }
+        const bool ok = (z < p.Z) && exact_voxel<DepthT, PINHOLE>(p, depth, x, y, z, sd);
         sdv[j] = sd;
         upd[j] = ok;
-        any = any || ok;
+        any = any | ok;
     }
-    if (!any) return;
-
+    if (!any) continue;
     const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
     using P = Pack<VolT, VEC>;
     P t = *reinterpret_cast<const P *>(tsdf + off);
@@ -101,31 +287,69 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(VolT *__restrict__
         if (upd[j]) {
             const double wt = (double)w.v[j];
             const double tv = (double)t.v[j];
-            const double m = sdv[j] < p.tdist ? sdv[j] : p.tdist;          // min(tdist, sd)
-            t.v[j] = (VolT)((p.scale * tv * wt + m) / (p.scale * (1.0 + wt)));   // :209
+            const double m = sdv[j] < p.tdist ? sdv[j] : p.tdist;                      // min(tdist, sd)
+            t.v[j] = (VolT)((p.scale * tv * wt + m) / (p.scale * (1.0 + wt)));       // :209
             const double nw = 1.0 + wt;
-            w.v[j] = (VolT)(nw < p.wmax ? nw : p.wmax);                    // :210
+            w.v[j] = (VolT)(nw < p.wmax ? nw : p.wmax);                                // :210
         }
     }
     *reinterpret_cast<P *>(tsdf + off) = t;
     *reinterpret_cast<P *>(tsdf_w + off) = w;
+  }
 }
 
-template <typename VolT, typename DepthT, int VEC>
-static int launch_integrate(void *tsdf, void *tsdf_w, const void *depth, const IntegrateParams &p,
+template <typename VolT, typename DepthT, int VEC, bool FAST>
+static int launch_integrate(void *tsdf, void *tsdf_w, const void *depth, IntegrateParams &p,
                             bool pinhole, hipStream_t stream) {
     const long per_plane = (long)p.Y * p.zpacks;
-    dim3 grid((unsigned)((per_plane + 255) / 256), (unsigned)p.nx);
+    const unsigned gx = (unsigned)((per_plane + 255) / 256);
+    const unsigned gy = (unsigned)((p.nx + p.planes_per_block - 1) / p.planes_per_block);
+    dim3 grid(gx, gy);
     dim3 block(256);
-    if (pinhole) {
-        hipLaunchKernelGGL((integrate_depth_kernel<VolT, DepthT, VEC, true>), grid, block, 0, stream,
-                           (VolT *)tsdf, (VolT *)tsdf_w, (const DepthT *)depth, p);
+    if constexpr (FAST) {
+        if (pinhole) {
+            hipLaunchKernelGGL((integrate_depth_kernel<DepthT, VEC, true>), grid, block, 0, stream,
+                               (float *)tsdf, (float *)tsdf_w, (const DepthT *)depth, p);
+        } else {
+            hipLaunchKernelGGL((integrate_depth_kernel<DepthT, VEC, false>), grid, block, 0, stream,
+                               (float *)tsdf, (float *)tsdf_w, (const DepthT *)depth, p);
+        }
     } else {
-        hipLaunchKernelGGL((integrate_depth_kernel<VolT, DepthT, VEC, false>), grid, block, 0, stream,
-                           (VolT *)tsdf, (VolT *)tsdf_w, (const DepthT *)depth, p);
+        if (pinhole) {
+            hipLaunchKernelGGL((integrate_depth_exact_kernel<VolT, DepthT, VEC, true>), grid, block, 0, stream,
+                               (VolT *)tsdf, (VolT *)tsdf_w, (const DepthT *)depth, p);
+        } else {
+            hipLaunchKernelGGL((integrate_depth_exact_kernel<VolT, DepthT, VEC, false>), grid, block, 0, stream,
+                               (VolT *)tsdf, (VolT *)tsdf_w, (const DepthT *)depth, p);
+        }
     }
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
+}
+
+// Fold index -> pos -> lpos -> K*lpos into one affine map per output component (host, fp64).
+static void fold_affine(IntegrateParams &p) {
+    const double *lw = p.lw.m;
+    const double *K = p.K.m;
+    const double off[3] = {p.cx - p.scale * p.half, p.cy - p.scale * p.half, p.cz - p.scale * p.half};
+    double L[3][4];     // lpos_r = L[r][0..2] . idx + L[r][3]
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) L[r][c] = lw[4 * r + c] * p.scale;
+        L[r][3] = lw[4 * r + 0] * off[0] + lw[4 * r + 1] * off[1] + lw[4 * r + 2] * off[2] + lw[4 * r + 3];
+    }
+    for (int r = 0; r < 3; ++r) {      // p_r = K[r] . lpos
+        double row[4];
+        for (int c = 0; c < 4; ++c) row[c] = K[3 * r + 0] * L[0][c] + K[3 * r + 1] * L[1][c] + K[3 * r + 2] * L[2][c];
+        p.Ax[r] = row[0]; p.Ay[r] = row[1]; p.Az[r] = row[2]; p.Ac[r] = row[3];
+    }
+    p.Ax[3] = L[2][0]; p.Ay[3] = L[2][1]; p.Az[3] = L[2][2]; p.Ac[3] = L[2][3];
+    for (int r = 0; r < 2; ++r) {      // exact power-of-two scaling: u, v come out in 2^-20 px units
+        p.Ax[r] *= (double)kFixOne; p.Ay[r] *= (double)kFixOne; p.Az[r] *= (double)kFixOne; p.Ac[r] *= (double)kFixOne;
+    }
+    p.inv_scale = 1.0 / p.scale;
+    p.tdist_f = (float)p.tdist;
+    p.ts_f = (float)(p.tdist * p.inv_scale);
+    p.wmax_f = (float)p.wmax;
 }
 
 }  // namespace dfh
@@ -154,22 +378,39 @@ extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, cons
     p.tdist = tdist; p.wmax = wmax;
     p.X = res[0]; p.Y = res[1]; p.Z = res[2];
     p.x0 = x0; p.nx = x1 - x0; p.H = H; p.W = W;
-
     const bool pinhole = K[1] == 0.0 && K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0 && K[8] == 1.0 &&
                          Kinv[6] == 0.0 && Kinv[7] == 0.0 && Kinv[8] == 1.0;
     const size_t esz = vol_dtype == DFH_F32 ? 4 : 8;
     const bool vec4 = (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) && ((uintptr_t)tsdf_w % (4 * esz) == 0);
     p.zpacks = vec4 ? res[2] / 4 : res[2];
-    hipStream_t s = static_cast<hipStream_t>(stream);
-
-#define DFH_DISPATCH(VT, DT)                                                                 \
-    return vec4 ? launch_integrate<VT, DT, 4>(tsdf, tsdf_w, depth, p, pinhole, s)            \
-                : launch_integrate<VT, DT, 1>(tsdf, tsdf_w, depth, p, pinhole, s)
-    if (vol_dtype == DFH_F32) {
-        if (depth_dtype == DFH_F32) { DFH_DISPATCH(float, float); }
-        DFH_DISPATCH(float, double);
+    p.zp_shift = -1;
+    for (int b = 0; b < 31; ++b) if (p.zpacks == (1 << b)) p.zp_shift = b;
+    fold_affine(p);
+    {   // ~kTargetBlocks blocks in total, each looping over consecutive x planes
+        const long per_plane_blocks = ((long)p.Y * p.zpacks + 255) / 256;
+        long chunks = (kTargetBlocks + per_plane_blocks - 1) / per_plane_blocks;
+        if (chunks < 1) chunks = 1;
+        if (chunks > p.nx) chunks = p.nx;
+        p.planes_per_block = (int)((p.nx + chunks - 1) / chunks);
+        const char *env = getenv("DFH_PLANES_PER_BLOCK");       // tuning knob for kbench sweeps
+        if (env && atoi(env) > 0) p.planes_per_block = atoi(env);
     }
-    if (depth_dtype == DFH_F32) { DFH_DISPATCH(double, float); }
-    DFH_DISPATCH(double, double);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // fixed-point pixel coordinates need (dim-1) << 20 to fit in int32
+    const bool fast_ok = H <= kFastMaxDim && W <= kFastMaxDim && scale > 0.0 && tdist > 0.0;
+
+#define DFH_DISPATCH(VT, DT, FAST)                                                            \
+    return vec4 ? launch_integrate<VT, DT, 4, FAST>(tsdf, tsdf_w, depth, p, pinhole, s)       \
+                : launch_integrate<VT, DT, 1, FAST>(tsdf, tsdf_w, depth, p, pinhole, s)
+    if (vol_dtype == DFH_F32) {
+        if (fast_ok) {
+            if (depth_dtype == DFH_F32) { DFH_DISPATCH(float, float, true); }
+            DFH_DISPATCH(float, double, true);
+        }
+        if (depth_dtype == DFH_F32) { DFH_DISPATCH(float, float, false); }
+        DFH_DISPATCH(float, double, false);
+    }
+    if (depth_dtype == DFH_F32) { DFH_DISPATCH(double, float, false); }
+    DFH_DISPATCH(double, double, false);
 #undef DFH_DISPATCH
 }

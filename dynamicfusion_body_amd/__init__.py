@@ -6,8 +6,9 @@ reference's own Python call surface.  See DESIGN.md.
 """
 from . import scene  # noqa: F401
 from .fusion_dm import FusionDM  # noqa: F401
+from .fusion import Fusion  # noqa: F401
 
 # the reference selects its device plug-in by class name (test.py:158-161)
 FusionDM_GPU = FusionDM
 
-__all__ = ["FusionDM", "FusionDM_GPU", "scene"]
+__all__ = ["Fusion", "FusionDM", "FusionDM_GPU", "scene"]

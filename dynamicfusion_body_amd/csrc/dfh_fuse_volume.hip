@@ -1,0 +1,380 @@
+// K2  rigid TSDF -> TSDF fusion:    FusionDM.updateTSDF   (reference core/fusion_dm.py:300-316)
+// K3  DQB-warped TSDF -> TSDF fusion: Fusion.updateTSDF   (reference core/fusion.py:153-198)
+//
+// Both sweep the canonical volume [x][y][z] with z fastest (one 16-byte pack of 4 voxels
+// per lane, lanes along z), warp every voxel index into the live volume, sample it with the
+// reference's trilinear scheme and blend.  The warp / sampler arithmetic is the exact fp64
+// restatement in dfh_dq.h; the blend is evaluated in fp64 with IEEE division and rounded
+// once to the volume dtype.
+#include "dfh_dq.h"
+
+namespace dfh {
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) VPack {
+    T v[N];
+};
+
+struct RigidParams {
+    DQ lw;
+    double tdist, wmax;
+    int X, Y, Z;            // canonical grid
+    int LX, LY, LZ;         // live grid
+    int x0, nx;
+    int zpacks, zp_shift;
+};
+
+__device__ __forceinline__ void pack_coords2(int zpacks, int zp_shift, int &y, int &zp) {
+    const int lin = blockIdx.x * 256 + threadIdx.x;
+    if (zp_shift >= 0) {
+        y = lin >> zp_shift;
+        zp = lin & ((1 << zp_shift) - 1);
+    } else {
+        y = lin / zpacks;
+        zp = lin - y * zpacks;
+    }
+}
+
+template <typename VolT, typename LiveT, int VEC>
+__global__ __launch_bounds__(256) void fuse_volume_rigid_kernel(VolT *__restrict__ tsdf, VolT *__restrict__ tsdf_w,
+                                                                 const LiveT *__restrict__ live, const RigidParams p) {
+    int y, zp;
+    pack_coords2(p.zpacks, p.zp_shift, y, zp);
+    if (y >= p.Y) return;
+    const int xl = blockIdx.y;
+    const int x = p.x0 + xl;
+    const int z0 = zp * VEC;
+    double sv[VEC];
+    bool upd[VEC];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int z = z0 + j;
+        const D3 q = dqb_warp_exact(p.lw.q, (double)x, (double)y, (double)z);        // fusion_dm.py:305-306
+        double s = 0.0;
+        bool ok = (z < p.Z) && interpolate_exact(live, p.LX, p.LY, p.LZ, q.x, q.y, q.z, s);   // :307
+        ok = ok && (s > -1.0 * p.tdist);                                               // :308
+        sv[j] = s;
+        upd[j] = ok;
+        any = any | ok;
+    }
+    if (!any) return;
+    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
+    using P = VPack<VolT, VEC>;
+    P t = *reinterpret_cast<const P *>(tsdf + off);
+    P w = *reinterpret_cast<const P *>(tsdf_w + off);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        if (upd[j]) {
+            const double wt = (double)w.v[j];
+            const double m = sv[j] < p.tdist ? sv[j] : p.tdist;
+            t.v[j] = (VolT)(((double)t.v[j] * wt + m * 1.0) / (1.0 + wt));           // :311
+            const double nw = 1.0 + wt;
+            w.v[j] = (VolT)(nw < p.wmax ? nw : p.wmax);                                // :312
+        }
+    }
+    *reinterpret_cast<P *>(tsdf + off) = t;
+    *reinterpret_cast<P *>(tsdf_w + off) = w;
+}
+
+template <typename VolT, typename LiveT>
+static int launch_rigid(void *tsdf, void *tsdf_w, const void *live, RigidParams &p, bool vec4, hipStream_t s) {
+    p.zpacks = vec4 ? p.Z / 4 : p.Z;
+    p.zp_shift = -1;
+    for (int b = 0; b < 31; ++b) if (p.zpacks == (1 << b)) p.zp_shift = b;
+    const long per_plane = (long)p.Y * p.zpacks;
+    dim3 grid((unsigned)((per_plane + 255) / 256), (unsigned)p.nx), block(256);
+    if (vec4) {
+        hipLaunchKernelGGL((fuse_volume_rigid_kernel<VolT, LiveT, 4>), grid, block, 0, s, (VolT *)tsdf, (VolT *)tsdf_w,
+                           (const LiveT *)live, p);
+    } else {
+        hipLaunchKernelGGL((fuse_volume_rigid_kernel<VolT, LiveT, 1>), grid, block, 0, s, (VolT *)tsdf, (VolT *)tsdf_w,
+                           (const LiveT *)live, p);
+    }
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: node search + DQ blending
+// ------------------------------------------------------------------------------------------
+constexpr int kBX = 4, kBY = 4, kBZ = 16;      // brick = one 256-thread block, z fastest (64-B rows)
+constexpr int kCap = 64;                        // candidate nodes kept per brick
+constexpr int kKMax = 8;                        // knn <= 8
+// half diagonal of the voxel-centre span of a brick
+#define DFH_BRICK_RADIUS 7.7942286340599480     /* sqrt(1.5^2 + 1.5^2 + 7.5^2) */
+
+struct DqbParams {
+    DQ lw;
+    double tdist, wmax;
+    int X, Y, Z;
+    int LX, LY, LZ;
+    int x0, nx;
+    int N, k;
+    int nbx, nby, nbz;      // bricks per axis (over the slab)
+};
+
+// sorted (ascending, stable) insertion into an 8-slot list held in registers
+__device__ __forceinline__ void top8_insert(double (&bd)[kKMax], int (&bi)[kKMax], double d2, int idx) {
+#pragma unroll
+    for (int i = 0; i < kKMax; ++i) {
+        const bool lt = d2 < bd[i];
+        const double td = bd[i];
+        const int ti = bi[i];
+        bd[i] = lt ? d2 : td;
+        bi[i] = lt ? idx : ti;
+        d2 = lt ? td : d2;
+        idx = lt ? ti : idx;
+    }
+}
+
+__device__ __forceinline__ double select_k(const double (&bd)[kKMax], int k) {
+    double r = bd[0];
+#pragma unroll
+    for (int i = 1; i < kKMax; ++i) r = (k - 1 == i) ? bd[i] : r;
+    return r;
+}
+
+// Per brick: the nodes that can be among the k nearest of ANY voxel centre p of the brick.
+// With c the brick centre and r its radius: D_k(p) <= d_k(c) + r, hence every such node q has
+// |q - c| <= d_k(c) + 2r.  cand[brick*(kCap+1)] = count (or -1: too many -> scan all nodes).
+__global__ __launch_bounds__(256) void dqb_candidates_kernel(const double *__restrict__ node_pos, int *__restrict__ cand,
+                                                              const DqbParams p) {
+    const long brick = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nbricks = (long)p.nbx * p.nby * p.nbz;
+    if (brick >= nbricks) return;
+    const int bz = (int)(brick % p.nbz);
+    const int by = (int)((brick / p.nbz) % p.nby);
+    const int bx = (int)(brick / ((long)p.nbz * p.nby));
+    const double cx = (double)(p.x0 + bx * kBX) + 0.5 * (kBX - 1);
+    const double cy = (double)(by * kBY) + 0.5 * (kBY - 1);
+    const double cz = (double)(bz * kBZ) + 0.5 * (kBZ - 1);
+    double bd[kKMax];
+    int bi[kKMax];
+#pragma unroll
+    for (int i = 0; i < kKMax; ++i) { bd[i] = __builtin_huge_val(); bi[i] = -1; }
+    for (int n = 0; n < p.N; ++n) {
+        const double dx = cx - node_pos[3 * n], dy = cy - node_pos[3 * n + 1], dz = cz - node_pos[3 * n + 2];
+        const double d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < bd[kKMax - 1]) top8_insert(bd, bi, d2, n);
+    }
+    const double R = sqrt(select_k(bd, p.k)) + 2.0 * DFH_BRICK_RADIUS + 1e-6;
+    const double R2 = R * R;
+    int *c = cand + brick * (kCap + 1);
+    int cnt = 0;
+    for (int n = 0; n < p.N; ++n) {
+        const double dx = cx - node_pos[3 * n], dy = cy - node_pos[3 * n + 1], dz = cz - node_pos[3 * n + 2];
+        const double d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 <= R2) {
+            if (cnt < kCap) c[1 + cnt] = n;
+            ++cnt;
+        }
+    }
+    c[0] = cnt <= kCap ? cnt : -1;
+}
+
+// k nearest nodes of `pos` (ascending distance, ties by node index = stable argsort of the
+// squared distances; what KDTree.query(pos, k+1)[1][:-1] yields, core/fusion.py:175-176).
+// All 256 threads of the block must call this (LDS staging + barriers).
+__device__ __forceinline__ void block_knn(const double *__restrict__ node_pos, const int *__restrict__ c, int N,
+                                          double px, double py, double pz, bool active,
+                                          double (&bd)[kKMax], int (&bi)[kKMax]) {
+    __shared__ double spos[kCap * 3];
+    __shared__ int sidx[kCap];
+    const int cnt = c[0];
+    const int total = cnt >= 0 ? cnt : N;
+#pragma unroll
+    for (int i = 0; i < kKMax; ++i) { bd[i] = __builtin_huge_val(); bi[i] = -1; }
+    for (int base = 0; base < total; base += kCap) {
+        const int n = min(kCap, total - base);
+        if ((int)threadIdx.x < n) {
+            const int gi = cnt >= 0 ? c[1 + base + threadIdx.x] : base + (int)threadIdx.x;
+            sidx[threadIdx.x] = gi;
+            spos[3 * threadIdx.x + 0] = node_pos[3 * gi + 0];
+            spos[3 * threadIdx.x + 1] = node_pos[3 * gi + 1];
+            spos[3 * threadIdx.x + 2] = node_pos[3 * gi + 2];
+        }
+        __syncthreads();
+        if (active) {
+            for (int i = 0; i < n; ++i) {
+                const double dx = px - spos[3 * i], dy = py - spos[3 * i + 1], dz = pz - spos[3 * i + 2];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 < bd[kKMax - 1]) top8_insert(bd, bi, d2, sidx[i]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Fusion.dq_blend + warp (core/fusion.py:502-551) for one point whose k nearest nodes are
+// (bd, bi).  Returns the point warped by the blended DQ and then by m_lw (x1 is re-rounded to
+// float32 inside the second dqb_warp, core/util.py:69); *wi_out = mean node distance (:180-183).
+__device__ __forceinline__ D3 dqb_blend_warp(const double *__restrict__ node_dq, const double *__restrict__ node_w,
+                                             const double (&bd)[kKMax], const int (&bi)[kKMax], int k,
+                                             const double *lw, double px, double py, double pz, double *wi_out,
+                                             double *blended /* 8, optional */) {
+    double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double wi = 0.0;
+#pragma unroll
+    for (int j = 0; j < kKMax; ++j) {
+        if (j < k) {
+            const int gi = bi[j];
+            const double dist = sqrt(bd[j]);
+            const double t = dist / (2.0 * node_w[gi]);
+            const double wgt = exp(-1.0 * (t * t));                      // :537
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b[c] = b[c] + wgt * node_dq[8 * gi + c];   // :538
+            wi = wi + dist / (double)k;
+        }
+    }
+    // 8-norm (:551), pairwise like numpy's reduction of 8 contiguous values
+    const double n2 = ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3])) +
+                      ((b[4] * b[4] + b[5] * b[5]) + (b[6] * b[6] + b[7] * b[7]));
+    const double n = sqrt(n2);
+    if (n == 0.0) {                                                       // :544-549
+        b[0] = 1.0;
+#pragma unroll
+        for (int c = 1; c < 8; ++c) b[c] = 0.0;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c] = b[c] / n;
+    }
+    if (blended) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) blended[c] = b[c];
+    }
+    const D3 x1 = dqb_warp_exact(b, px, py, pz);                          // :510
+    *wi_out = wi;
+    return dqb_warp_exact(lw, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));   // :512
+}
+
+template <typename VolT, typename LiveT>
+__global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__ tsdf, VolT *__restrict__ tsdf_w,
+                                                               const LiveT *__restrict__ live,
+                                                               const double *__restrict__ node_pos,
+                                                               const double *__restrict__ node_dq,
+                                                               const double *__restrict__ node_w,
+                                                               const int *__restrict__ cand, const DqbParams p) {
+    const long brick = blockIdx.x;
+    const int bz = (int)(brick % p.nbz);
+    const int by = (int)((brick / p.nbz) % p.nby);
+    const int bx = (int)(brick / ((long)p.nbz * p.nby));
+    const int lz = threadIdx.x & (kBZ - 1);
+    const int ly = (threadIdx.x >> 4) & (kBY - 1);
+    const int lx = threadIdx.x >> 6;
+    const int xl = bx * kBX + lx, y = by * kBY + ly, z = bz * kBZ + lz;
+    const bool inb = (xl < p.nx) && (y < p.Y) && (z < p.Z);
+    const double px = (double)(p.x0 + xl), py = (double)y, pz = (double)z;
+    double bd[kKMax];
+    int bi[kKMax];
+    block_knn(node_pos, cand + brick * (kCap + 1), p.N, px, py, pz, inb, bd, bi);
+    if (!inb) return;
+    double wi;
+    const D3 q = dqb_blend_warp(node_dq, node_w, bd, bi, p.k, p.lw.q, px, py, pz, &wi, nullptr);   // fusion.py:178
+    double s;
+    if (!interpolate_exact(live, p.LX, p.LY, p.LZ, q.x, q.y, q.z, s)) return;
+    if (!(s > -1.0 * p.tdist)) return;                                                              // :179
+    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z;
+    double wt = (double)tsdf_w[off];
+    if (wt == 0.0) wt = wi;                                                                         // :186-187
+    const double m = s < p.tdist ? s : p.tdist;
+    tsdf[off] = (VolT)(((double)tsdf[off] * wt + m * wi) / (wi + wt));                              // :189
+    const double nw = wi + wt;
+    tsdf_w[off] = (VolT)(nw < p.wmax ? nw : p.wmax);                                                // :190
+}
+
+template <typename VolT, typename LiveT>
+static int launch_dqb(void *tsdf, void *tsdf_w, const void *live, const double *node_pos, const double *node_dq,
+                      const double *node_w, int *cand, const DqbParams &p, hipStream_t s) {
+    const long nbricks = (long)p.nbx * p.nby * p.nbz;
+    hipLaunchKernelGGL((fuse_volume_dqb_kernel<VolT, LiveT>), dim3((unsigned)nbricks), dim3(256), 0, s, (VolT *)tsdf,
+                       (VolT *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, p);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+static void brick_counts(const int res[3], int x0, int x1, int &nbx, int &nby, int &nbz) {
+    nbx = (x1 - x0 + kBX - 1) / kBX;
+    nby = (res[1] + kBY - 1) / kBY;
+    nbz = (res[2] + kBZ - 1) / kBZ;
+}
+
+}  // namespace dfh
+
+extern "C" int dfh_fuse_volume_rigid(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int x0, int x1,
+                                     const void *live, int live_dtype, const int live_res[3],
+                                     const double lw_dq[8], double tdist, double wmax, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(tsdf && tsdf_w && live && res && live_res && lw_dq, "dfh_fuse_volume_rigid: null pointer");
+    DFH_REQUIRE(vol_dtype == DFH_F32 || vol_dtype == DFH_F64, "dfh_fuse_volume_rigid: bad vol_dtype %d", vol_dtype);
+    DFH_REQUIRE(live_dtype == DFH_F32 || live_dtype == DFH_F64, "dfh_fuse_volume_rigid: bad live_dtype %d", live_dtype);
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0, "dfh_fuse_volume_rigid: bad grid");
+    DFH_REQUIRE(live_res[0] > 0 && live_res[1] > 0 && live_res[2] > 0, "dfh_fuse_volume_rigid: bad live grid");
+    DFH_REQUIRE((long)live_res[0] * live_res[1] * live_res[2] < (1L << 40), "dfh_fuse_volume_rigid: live grid too large");
+    DFH_REQUIRE(0 <= x0 && x0 <= x1 && x1 <= res[0], "dfh_fuse_volume_rigid: slab [%d,%d) outside [0,%d)", x0, x1, res[0]);
+    DFH_REQUIRE(x1 - x0 <= 65535, "dfh_fuse_volume_rigid: slab has more than 65535 planes");
+    if (x1 == x0) return DFH_OK;
+    RigidParams p;
+    for (int i = 0; i < 8; ++i) p.lw.q[i] = lw_dq[i];
+    p.tdist = tdist; p.wmax = wmax;
+    p.X = res[0]; p.Y = res[1]; p.Z = res[2];
+    p.LX = live_res[0]; p.LY = live_res[1]; p.LZ = live_res[2];
+    p.x0 = x0; p.nx = x1 - x0;
+    const size_t esz = vol_dtype == DFH_F32 ? 4 : 8;
+    const bool vec4 = (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) && ((uintptr_t)tsdf_w % (4 * esz) == 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vol_dtype == DFH_F32) {
+        if (live_dtype == DFH_F32) return launch_rigid<float, float>(tsdf, tsdf_w, live, p, vec4, s);
+        return launch_rigid<float, double>(tsdf, tsdf_w, live, p, vec4, s);
+    }
+    if (live_dtype == DFH_F32) return launch_rigid<double, float>(tsdf, tsdf_w, live, p, vec4, s);
+    return launch_rigid<double, double>(tsdf, tsdf_w, live, p, vec4, s);
+}
+
+extern "C" size_t dfh_dqb_workspace_bytes(const int res[3], int x0, int x1) {
+    if (!res || x1 <= x0) return 0;
+    int nbx, nby, nbz;
+    dfh::brick_counts(res, x0, x1, nbx, nby, nbz);
+    return (size_t)nbx * nby * nbz * (dfh::kCap + 1) * sizeof(int);
+}
+
+extern "C" int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int x0, int x1,
+                                   const void *live, int live_dtype, const int live_res[3],
+                                   const double *node_pos, const double *node_dq, const double *node_w, int n_nodes,
+                                   int knn, const double lw_dq[8], double tdist, double wmax,
+                                   void *workspace, size_t workspace_bytes, int rebuild_candidates, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(tsdf && tsdf_w && live && res && live_res && lw_dq && node_pos && node_dq && node_w,
+                "dfh_fuse_volume_dqb: null pointer");
+    DFH_REQUIRE(vol_dtype == DFH_F32 || vol_dtype == DFH_F64, "dfh_fuse_volume_dqb: bad vol_dtype %d", vol_dtype);
+    DFH_REQUIRE(live_dtype == DFH_F32 || live_dtype == DFH_F64, "dfh_fuse_volume_dqb: bad live_dtype %d", live_dtype);
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0, "dfh_fuse_volume_dqb: bad grid");
+    DFH_REQUIRE(live_res[0] > 0 && live_res[1] > 0 && live_res[2] > 0, "dfh_fuse_volume_dqb: bad live grid");
+    DFH_REQUIRE(0 <= x0 && x0 <= x1 && x1 <= res[0], "dfh_fuse_volume_dqb: slab [%d,%d) outside [0,%d)", x0, x1, res[0]);
+    DFH_REQUIRE(knn >= 1 && knn <= kKMax, "dfh_fuse_volume_dqb: knn=%d outside [1,%d]", knn, kKMax);
+    DFH_REQUIRE(n_nodes >= knn, "dfh_fuse_volume_dqb: %d nodes < knn=%d", n_nodes, knn);
+    if (x1 == x0) return DFH_OK;
+    DFH_REQUIRE(workspace && workspace_bytes >= dfh_dqb_workspace_bytes(res, x0, x1),
+                "dfh_fuse_volume_dqb: workspace too small (need %zu bytes)", dfh_dqb_workspace_bytes(res, x0, x1));
+    DqbParams p;
+    for (int i = 0; i < 8; ++i) p.lw.q[i] = lw_dq[i];
+    p.tdist = tdist; p.wmax = wmax;
+    p.X = res[0]; p.Y = res[1]; p.Z = res[2];
+    p.LX = live_res[0]; p.LY = live_res[1]; p.LZ = live_res[2];
+    p.x0 = x0; p.nx = x1 - x0; p.N = n_nodes; p.k = knn;
+    brick_counts(res, x0, x1, p.nbx, p.nby, p.nbz);
+    const long nbricks = (long)p.nbx * p.nby * p.nbz;
+    DFH_REQUIRE(nbricks < (1L << 31), "dfh_fuse_volume_dqb: too many bricks");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int *cand = static_cast<int *>(workspace);
+    if (rebuild_candidates) {
+        hipLaunchKernelGGL(dqb_candidates_kernel, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, s, node_pos, cand, p);
+        DFH_HIP_CHECK(hipGetLastError());
+    }
+    if (vol_dtype == DFH_F32) {
+        if (live_dtype == DFH_F32) return launch_dqb<float, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, p, s);
+        return launch_dqb<float, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, p, s);
+    }
+    if (live_dtype == DFH_F32) return launch_dqb<double, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, p, s);
+    return launch_dqb<double, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, p, s);
+}

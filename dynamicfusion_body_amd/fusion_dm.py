@@ -74,8 +74,10 @@ class FusionDM:
         return T, Wt
 
     def _ensure_volumes(self):
-        if self._T is None:
-            self._T, self._Wt = self._new_volume_pair()
+        if self._T is None or self._Wt is None:
+            T, Wt = self._new_volume_pair()
+            self._T = T if self._T is None else self._T
+            self._Wt = Wt if self._Wt is None else self._Wt
 
     @property
     def _tsdf(self):
@@ -139,6 +141,24 @@ class FusionDM:
         tsdf[...] = T.cpu().numpy()
         tsdf_w[...] = Wt.cpu().numpy()
         return (tsdf, tsdf_w)
+
+    # ------------------------------------------------------------------ A3
+    def _live_to_device(self, curr_tsdf):
+        if _is_tensor(curr_tsdf):
+            if curr_tsdf.dim() != 3:
+                raise ValueError('Only accept 3D array as tsdf')
+            t = curr_tsdf if curr_tsdf.dtype in (torch.float32, torch.float64) else curr_tsdf.to(torch.float32)
+            return to_device(t)
+        if type(curr_tsdf) is not np.ndarray or curr_tsdf.ndim != 3:
+            raise ValueError('Only accept 3D np array as tsdf')
+        return to_device(curr_tsdf, dtype=torch.float32 if f32_exact(curr_tsdf) else torch.float64)
+
+    def updateTSDF(self, curr_tsdf, wmax=100.0):
+        """Rigidly warp every canonical voxel by `_lw` into the live TSDF, sample it and fuse;
+        reference core/fusion_dm.py:300-316.  Mutates `_tsdf` / `_tsdfw` (on the GPU)."""
+        live = self._live_to_device(curr_tsdf)
+        self._ensure_volumes()
+        kernels.fuse_volume_rigid(self._T, self._Wt, live, np.asarray(self._lw, dtype=np.float64), self._tdist, wmax)
 
     # ------------------------------------------------------------------ driver
     def _auto_alignment(self, depths, lws):

@@ -52,3 +52,80 @@ def integrate_depth(T, Wt, depth, K, Kinv, lw, scale, center, tdist, wmax=100.0,
                                  float(tdist), float(wmax), current_stream_ptr())
     _lib.check(rc, "dfh_integrate_depth")
     return T, Wt
+
+
+def _check_live(live):
+    if not (isinstance(live, torch.Tensor) and live.is_cuda and live.dim() == 3 and live.is_contiguous()):
+        raise ValueError("live TSDF must be a contiguous 3-D CUDA tensor")
+
+
+def fuse_volume_rigid(T, Wt, live, lw_dq, tdist, wmax=100.0, res=None, x_range=None):
+    """K2 = FusionDM.updateTSDF (reference core/fusion_dm.py:300-316) on device tensors.
+    T, Wt: planes [x0,x1) of the canonical grid `res`; live: the whole live volume."""
+    require_gpu()
+    lib = _lib.load()
+    if res is None:
+        res = tuple(T.shape)
+    if x_range is None:
+        x_range = (0, res[0])
+    _check_volume_pair(T, Wt, res, x_range)
+    _check_live(live)
+    if x_range[1] == x_range[0]:
+        return T, Wt
+    rc = lib.dfh_fuse_volume_rigid(T.data_ptr(), Wt.data_ptr(), dtype_code(T), _lib.iarr(res), int(x_range[0]),
+                                   int(x_range[1]), live.data_ptr(), dtype_code(live), _lib.iarr(live.shape),
+                                   _lib.darr(lw_dq, 8), float(tdist), float(wmax), current_stream_ptr())
+    _lib.check(rc, "dfh_fuse_volume_rigid")
+    return T, Wt
+
+
+def dqb_workspace(res, x_range=None, device=None):
+    """Scratch tensor for the per-brick candidate node lists of fuse_volume_dqb / the solve."""
+    require_gpu()
+    lib = _lib.load()
+    if x_range is None:
+        x_range = (0, res[0])
+    nbytes = lib.dfh_dqb_workspace_bytes(_lib.iarr(res), int(x_range[0]), int(x_range[1]))
+    return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.int32, device=device or "cuda")
+
+
+def _node_tensors(node_pos, node_dq, node_w):
+    def prep(a, shape_tail):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64)))
+        t = t.to(device="cuda", dtype=torch.float64).contiguous()
+        if tuple(t.shape[1:]) != shape_tail:
+            raise ValueError("node array has shape %s, expected (N,%s)" % (tuple(t.shape), ",".join(map(str, shape_tail))))
+        return t
+    P, Q, Wn = prep(node_pos, (3,)), prep(node_dq, (8,)), prep(node_w, ())
+    if not (P.shape[0] == Q.shape[0] == Wn.shape[0]):
+        raise ValueError("node_pos / node_dq / node_w disagree on the number of nodes")
+    return P, Q, Wn
+
+
+def fuse_volume_dqb(T, Wt, live, node_pos, node_dq, node_w, knn, lw_dq, tdist, wmax=100.0, res=None,
+                    x_range=None, workspace=None, rebuild_candidates=True):
+    """K3 = Fusion.updateTSDF (reference core/fusion.py:153-198) on device tensors.
+    node_pos (N,3), node_dq (N,8), node_w (N,) fp64 (numpy or CUDA).  `workspace` (from
+    dqb_workspace) may be kept across calls; pass rebuild_candidates=False while the node
+    positions, knn and slab are unchanged."""
+    require_gpu()
+    lib = _lib.load()
+    if res is None:
+        res = tuple(T.shape)
+    if x_range is None:
+        x_range = (0, res[0])
+    _check_volume_pair(T, Wt, res, x_range)
+    _check_live(live)
+    P, Q, Wn = _node_tensors(node_pos, node_dq, node_w)
+    if x_range[1] == x_range[0]:
+        return T, Wt
+    if workspace is None:
+        workspace = dqb_workspace(res, x_range)
+        rebuild_candidates = True
+    rc = lib.dfh_fuse_volume_dqb(T.data_ptr(), Wt.data_ptr(), dtype_code(T), _lib.iarr(res), int(x_range[0]),
+                                 int(x_range[1]), live.data_ptr(), dtype_code(live), _lib.iarr(live.shape),
+                                 P.data_ptr(), Q.data_ptr(), Wn.data_ptr(), int(P.shape[0]), int(knn),
+                                 _lib.darr(lw_dq, 8), float(tdist), float(wmax), workspace.data_ptr(),
+                                 workspace.numel() * 4, 1 if rebuild_candidates else 0, current_stream_ptr())
+    _lib.check(rc, "dfh_fuse_volume_dqb")
+    return T, Wt

@@ -68,6 +68,38 @@ int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3
                         double scale, const double center[3], double tdist, double wmax,
                         void *stream);
 
+/* A3  FusionDM.updateTSDF(curr_tsdf, wmax)                     core/fusion_dm.py:300-316
+ * For every canonical voxel i, x in [x0,x1):
+ *   q = dqb_warp(lw_dq, float32(i))          (core/util.py:68-72; lw_dq = `_lw`, 8 doubles, voxel-index
+ *                                             space, may be non-unit after solve, fusion_dm.py:282)
+ *   s = interpolate_tsdf(q, live)            (core/util.py:102-137: None outside [0,R-1]^3, ceil() upper
+ *                                             corner, y/z fractions swapped -- reproduced)
+ *   update iff s is not None and s > -tdist: T <- (T*w + min(tdist,s))/(1+w); w <- min(1+w, wmax)
+ * live: the full live volume live_res[0] x live_res[1] x live_res[2] (every rank holds all of it: the warp
+ * gathers across slab boundaries), dtype live_dtype. */
+int dfh_fuse_volume_rigid(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int x0, int x1,
+                          const void *live, int live_dtype, const int live_res[3],
+                          const double lw_dq[8], double tdist, double wmax, void *stream);
+
+/* A4-A6  Fusion.updateTSDF(curr_tsdf, wmax)                    core/fusion.py:153-198
+ * For every canonical voxel i, x in [x0,x1):
+ *   loc = the knn nearest nodes of float32(i), nearest first       (KDTree.query(pos,k=knn+1)[1][:-1], :175-176)
+ *   b   = sum_j exp(-(|i - v_j| / (2*w_j))^2) * dq_j ; b^ = b/|b|_8 (identity if |b|_8 == 0)   (dq_blend, :527-551)
+ *   q   = dqb_warp(lw_dq, float32(dqb_warp(b^, i)))                (warp, :502-520; util.py:69)
+ *   s   = interpolate_tsdf(q, live); update iff s is not None and s > -tdist              (:178-179)
+ *   wi  = sum_j |v_j - i| / knn ; wt = w, or wi if w == 0                                 (:180-187)
+ *   T <- (T*wt + min(tdist,s)*wi)/(wi + wt) ; w <- min(wi + wt, wmax)                      (:189-190)
+ * node_pos: n_nodes x 3, node_dq: n_nodes x 8, node_w: n_nodes (the nodes' 4th tuple entry, 2*radius,
+ * :116), all device fp64.  1 <= knn <= 8.  workspace: device scratch of dfh_dqb_workspace_bytes() bytes
+ * holding per-brick candidate node lists; they depend only on (node_pos, knn, grid, slab) and are rebuilt
+ * when rebuild_candidates != 0. */
+size_t dfh_dqb_workspace_bytes(const int res[3], int x0, int x1);
+int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int x0, int x1,
+                        const void *live, int live_dtype, const int live_res[3],
+                        const double *node_pos, const double *node_dq, const double *node_w, int n_nodes,
+                        int knn, const double lw_dq[8], double tdist, double wmax,
+                        void *workspace, size_t workspace_bytes, int rebuild_candidates, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

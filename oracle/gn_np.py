@@ -1,0 +1,241 @@
+"""fp64 numpy Gauss-Newton for the warp-field solve -- TEST INFRASTRUCTURE ONLY.
+
+The reference has no Gauss-Newton: it hands its residual functions (FusionDM.computef_lw,
+core/fusion_dm.py:285-297; Fusion.computef, core/fusion.py:459-491) to
+scipy.optimize.least_squares with finite-difference Jacobians.  What is pinned against the
+reference is therefore (1) the residual vectors (oracle_np.computef*, golden g5) and (2) the
+analytic Jacobians below, which must match central finite differences of the REFERENCE's
+own computef / computef_lw with respect to left twists  dq <- exp(xi) (x) dq  (golden g5:
+fd_cols, rigid_fd_cols).  The normal-equation assembly, the linear solve and the update are
+this build's own algorithm; this file is its CPU statement, used to check the HIP kernels
+(tests/test_gn_oracle.py, tests/test_gpu_solve.py).
+
+Parametrisation: xi = (omega, v) in R^6 per node, exp(xi) = unit dual quaternion with
+rotation exp(omega) and translation v (to first order [1, omega/2 | 0, v/2]).
+"""
+import numpy as np
+
+from . import oracle_np as O
+
+
+# ---------------------------------------------------------------- quaternion helpers (w first)
+def qmul(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bw - ax * bx - ay * by - az * bz,
+                     aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw], axis=-1)
+
+
+def qconj(a):
+    return np.asarray(a, dtype=np.float64) * np.array([1.0, -1.0, -1.0, -1.0])
+
+
+def pure(v):
+    v = np.asarray(v, dtype=np.float64)
+    return np.concatenate([np.zeros(v.shape[:-1] + (1,)), v], axis=-1)
+
+
+def dq_mul(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.concatenate([qmul(a[..., :4], b[..., :4]), qmul(a[..., :4], b[..., 4:]) + qmul(a[..., 4:], b[..., :4])], axis=-1)
+
+
+def twist_exp_dq(xi):
+    """exp of a twist: rotation exp(omega) (exact), translation v."""
+    xi = np.asarray(xi, dtype=np.float64)
+    om, v = xi[..., :3], xi[..., 3:]
+    th = np.sqrt(np.sum(om * om, axis=-1))
+    half = 0.5 * th
+    # sin(th/2)/th with the series near 0
+    small = th < 1e-8
+    s = np.where(small, 0.5 - th * th / 48.0, np.sin(half) / np.where(small, 1.0, th))
+    q = np.concatenate([np.cos(half)[..., None], s[..., None] * om], axis=-1)
+    qe = 0.5 * qmul(pure(v), q)
+    return np.concatenate([q, qe], axis=-1)
+
+
+def apply_twists(dqs, xi):
+    """dq_a <- exp(xi_a) (x) dq_a for every node (keeps the 8-float layout)."""
+    return dq_mul(twist_exp_dq(xi), dqs)
+
+
+def warp_closed(q, p):
+    """dqb_warp without the float32 rounding: vec(r P r*) + 2 vec(d r*)."""
+    r, d = q[..., :4], q[..., 4:]
+    return (qmul(qmul(r, pure(p)), qconj(r)) + 2.0 * qmul(d, qconj(r)))[..., 1:]
+
+
+def f32(x):
+    return np.asarray(x).astype(np.float32).astype(np.float64)
+
+
+# ---------------------------------------------------------------- rigid (global lw) term, A9
+def rigid_residual_jacobian(x, vertices, normals, corr):
+    """r_i = dqb_warp_normal(x, n_i) . (dqb_warp(x, v_i) - c_i) and d r_i / d xi for the left
+    twist on x:  J = [ c x m | s*m ],  m = warped normal, s = |r_x|^2."""
+    x = np.asarray(x, dtype=np.float64)
+    m = O.dqb_warp_normal(x, normals)
+    y = O.dqb_warp(x, vertices)
+    c = np.asarray(corr, dtype=np.float64)
+    r = np.sum(m * (y - c), axis=-1)
+    s = np.sum(x[:4] * x[:4])
+    J = np.concatenate([np.cross(c, m), s * m], axis=-1)
+    return r, J
+
+
+# ---------------------------------------------------------------- non-rigid data term, A10
+def blend_weights(vertices, node_pos_k, node_w_k):
+    """Gaussian DQB weights of core/fusion.py:537 (pos rounded to float32 by the caller's
+    convention is NOT applied here: dq_blend uses the raw position)."""
+    d = np.asarray(vertices, dtype=np.float64)[..., None, :] - node_pos_k
+    dist = np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2 + d[..., 2] ** 2)
+    return np.exp(-1.0 * (dist / (2 * node_w_k)) ** 2)
+
+
+def data_residual_jacobian(dqs, vertices, normals, corr, nbr, node_pos, node_w, lw, round_f32=True):
+    """Data rows of Fusion.computef and their Jacobian w.r.t. the left twists of the k nodes of
+    each vertex.  Returns r (V,), J (V,k,6).  Derivation: r = n'.(x'-c), x' = A x1 + t,
+    n' = A n1 (A = |r_lw|^2 R(lw)), x1 = W(b^,p), n1 = Wn(b^,n0), b^ = b/|b|_8, b = sum w_a q_a.
+    With u = A^T n', h = A^T (x'-c):  grad_{b^} = [ -2 U r P - 2 U d - 2 H r N | 2 U r ],
+    grad_b = (grad_{b^} - (grad_{b^}.b^) b^)/|b|,  J_a[omega] = w_a/2 (vec(g_r r_a*) + vec(g_d d_a*)),
+    J_a[v] = w_a/2 vec(g_d r_a*).  round_f32=False drops the reference's float32 roundings
+    (util.py:69), giving the smooth function whose derivative the Jacobian is."""
+    dqs = np.asarray(dqs, dtype=np.float64)
+    lw = np.asarray(lw, dtype=np.float64)
+    V = len(vertices)
+    qk = dqs[nbr]                                          # (V,k,8)
+    w = blend_weights(vertices, node_pos[nbr], node_w[nbr])            # (V,k)
+    b = np.sum(w[..., None] * qk, axis=1)                  # (V,8)
+    nb = np.sqrt(np.sum(b * b, axis=-1))
+    bh = b / nb[:, None]
+    rnd = f32 if round_f32 else (lambda a: np.asarray(a, dtype=np.float64))
+    p = rnd(vertices); n0 = rnd(normals)
+    x1 = warp_closed(bh, p)
+    n1 = qmul(qmul(bh[:, :4], pure(n0)), qconj(bh[:, :4]))[:, 1:]
+    x1r, n1r = rnd(x1), rnd(n1)
+    xp = warp_closed(lw, x1r)
+    rl = lw[:4]
+    npr = qmul(qmul(rl, pure(n1r)), qconj(rl))[..., 1:]
+    c = np.asarray(corr, dtype=np.float64)
+    r = np.sum(npr * (xp - c), axis=-1)
+    # A^T y = vec(rl* Y rl)
+    def AT(yv):
+        return qmul(qmul(qconj(rl), pure(yv)), rl)[..., 1:]
+    U = pure(AT(npr)); H = pure(AT(xp - c))
+    rr, dd = bh[:, :4], bh[:, 4:]
+    g_r = -2.0 * qmul(qmul(U, rr), pure(p)) - 2.0 * qmul(U, dd) - 2.0 * qmul(qmul(H, rr), pure(n0))
+    g_d = 2.0 * qmul(U, rr)
+    g = np.concatenate([g_r, g_d], axis=-1)
+    g = (g - np.sum(g * bh, axis=-1, keepdims=True) * bh) / nb[:, None]
+    gr, gd = g[:, None, :4], g[:, None, 4:]
+    ra, da = qk[..., :4], qk[..., 4:]
+    Jw = 0.5 * (qmul(gr, qconj(ra)) + qmul(gd, qconj(da)))[..., 1:]
+    Jv = 0.5 * qmul(gd, qconj(ra))[..., 1:]
+    J = w[..., None] * np.concatenate([Jw, Jv], axis=-1)   # (V,k,6)
+    return r, J
+
+
+def reg_residual_jacobian(dqs, node_vidx, nbr, node_pos, node_w, rw):
+    """Regularisation rows (core/fusion.py:475-484) rho_ij = c_ij (W(q_i,v_j) - W(q_j,v_j)),
+    c_ij = rw*max(w_i,w_j), and their Jacobians w.r.t. xi_i and xi_j:
+      d W(exp(xi) q, p)/d xi = [ -[y]x | s I ],  y = W(q,p), s = |r_q|^2.
+    Returns rho (N,k,3), nb (N,k) neighbour node index, Ji (N,k,3,6), Jj (N,k,3,6)."""
+    dqs = np.asarray(dqs, dtype=np.float64)
+    nb = nbr[node_vidx]
+    vj = node_pos[nb]
+    yi = O.dqb_warp(dqs[:, None, :], vj)
+    yj = O.dqb_warp(dqs[nb], vj)
+    cij = rw * np.maximum(node_w[:, None], node_w[nb])
+    rho = cij[..., None] * (yi - yj)
+
+    def skew(y):
+        z = np.zeros(y.shape[:-1])
+        return np.stack([np.stack([z, -y[..., 2], y[..., 1]], -1),
+                         np.stack([y[..., 2], z, -y[..., 0]], -1),
+                         np.stack([-y[..., 1], y[..., 0], z], -1)], -2)
+    s_all = np.sum(dqs[:, :4] ** 2, axis=-1)
+    si = np.broadcast_to(s_all[:, None], nb.shape)
+    sj = s_all[nb]
+    I3 = np.eye(3)
+    Ji = cij[..., None, None] * np.concatenate([-skew(yi), si[..., None, None] * I3], axis=-1)
+    Jj = -cij[..., None, None] * np.concatenate([-skew(yj), sj[..., None, None] * I3], axis=-1)
+    same = (nb == np.arange(len(dqs))[:, None])
+    Ji = np.where(same[..., None, None], 0.0, Ji)
+    Jj = np.where(same[..., None, None], 0.0, Jj)
+    return rho, nb, Ji, Jj
+
+
+def assemble_dense(N, r_data, J_data, nbr, rho, nb, Ji, Jj, valid=None, lm=0.0):
+    """Dense normal equations  (J^T J + lm I) dx = -J^T r  over all rows; returns JtJ (6N,6N),
+    Jtr (6N,), cost = 0.5*|r|^2."""
+    k = nbr.shape[1]
+    JtJ = np.zeros((6 * N, 6 * N)); Jtr = np.zeros(6 * N)
+    V = len(r_data)
+    if valid is None:
+        valid = np.ones(V, dtype=bool)
+    rd = np.where(valid, r_data, 0.0)
+    Jd = np.where(valid[:, None, None], J_data, 0.0)
+    for a in range(k):
+        ia = nbr[:, a]
+        np.add.at(Jtr.reshape(N, 6), ia, Jd[:, a, :] * rd[:, None])
+        for b_ in range(k):
+            ib = nbr[:, b_]
+            blk = Jd[:, a, :, None] * Jd[:, b_, None, :]
+            np.add.at(JtJ.reshape(N, 6, N, 6).transpose(0, 2, 1, 3), (ia, ib), blk)
+    cost = 0.5 * float(np.sum(rd * rd))
+    Nn, kk = nb.shape
+    ii = np.repeat(np.arange(Nn)[:, None], kk, axis=1)
+    JtJ4 = JtJ.reshape(N, 6, N, 6).transpose(0, 2, 1, 3)
+    np.add.at(JtJ4, (ii, ii), np.einsum('nkci,nkcj->nkij', Ji, Ji))
+    np.add.at(JtJ4, (nb, nb), np.einsum('nkci,nkcj->nkij', Jj, Jj))
+    np.add.at(JtJ4, (ii, nb), np.einsum('nkci,nkcj->nkij', Ji, Jj))
+    np.add.at(JtJ4, (nb, ii), np.einsum('nkci,nkcj->nkij', Jj, Ji))
+    np.add.at(Jtr.reshape(N, 6), ii, np.einsum('nkci,nkc->nki', Ji, rho))
+    np.add.at(Jtr.reshape(N, 6), nb, np.einsum('nkci,nkc->nki', Jj, rho))
+    cost += 0.5 * float(np.sum(rho * rho))
+    JtJ += lm * np.eye(6 * N)
+    return JtJ, Jtr, cost
+
+
+def gn_step(dqs, vertices, normals, corr, nbr, node_vidx, node_pos, node_w, lw, rw, valid=None, lm=1e-6):
+    """One Gauss-Newton step on the reference's residual (computef) -> (new dqs, cost before, dx)."""
+    N = len(dqs)
+    r, J = data_residual_jacobian(dqs, vertices, normals, corr, nbr, node_pos, node_w, lw)
+    rho, nb, Ji, Jj = reg_residual_jacobian(dqs, node_vidx, nbr, node_pos, node_w, rw)
+    JtJ, Jtr, cost = assemble_dense(N, r, J, nbr, rho, nb, Ji, Jj, valid=valid, lm=lm)
+    dx = np.linalg.solve(JtJ, -Jtr)
+    return apply_twists(dqs, dx.reshape(N, 6)), cost, dx
+
+
+def gn_step_rigid(x, vertices, normals, corr, lm=0.0):
+    r, J = rigid_residual_jacobian(x, vertices, normals, corr)
+    dx = np.linalg.solve(J.T @ J + lm * np.eye(6), -(J.T @ r))
+    return dq_mul(twist_exp_dq(dx), x), 0.5 * float(r @ r), dx
+
+
+# ---------------------------------------------------------------- projective data association
+def associate_depth(points_idx, K, Kinv, lw_cam, dm, scale, center, half):
+    """Projective association of warped points (voxel-index space) against a depth map, with the
+    reference's primitives: index -> world (fusion_dm.py:191), world -> camera (:193), pixel
+    (util.py:317-320), nearest pixel round-half-even and z = -dm (:196), back-projection
+    K^-1 (z [u,v,1]) (:198-200), then back to index space through the inverse extrinsic.
+    Returns (corr_idx (S,3), valid (S,))."""
+    P = np.asarray(points_idx, dtype=np.float64)
+    H, W = dm.shape
+    world = scale * (P - half) + center
+    R, t = lw_cam[:, :3], lw_cam[:, 3]
+    cam = world @ R.T + t
+    u, v, ok = O.project_to_pixel(K, cam)
+    vis = ok & (u >= 0) & (u < W - 1) & (v >= 0) & (v < H - 1)
+    ui = np.where(vis, np.rint(u), 0).astype(np.int64)
+    vi = np.where(vis, np.rint(v), 0).astype(np.int64)
+    z = -1.0 * dm[vi, ui].astype(np.float64)
+    valid = vis & (z > 0)
+    uc = z[:, None] * np.stack([u, v, np.ones_like(u)], axis=-1)
+    ccam = uc @ np.asarray(Kinv, dtype=np.float64).T
+    cworld = (ccam - t) @ np.linalg.inv(R).T
+    cidx = (cworld - center) / scale + half
+    return np.where(valid[:, None], cidx, 0.0), valid

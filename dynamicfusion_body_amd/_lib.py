@@ -31,6 +31,18 @@ _SIGNATURES = {
     "dfh_dqb_workspace_bytes": (ctypes.c_size_t, [_c_int_p, _int, _int]),
     "dfh_fuse_volume_dqb": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _vp, _int, _c_int_p, _vp, _vp, _vp, _int,
                                    _int, _c_double_p, _dbl, _dbl, _vp, ctypes.c_size_t, _int, _vp]),
+    "dfh_residual_rigid": (_int, [_vp, _vp, _vp, _int, _c_double_p, _vp, _vp]),
+    "dfh_gn_build_rigid": (_int, [_vp, _vp, _vp, _vp, _int, _c_double_p, _vp, _vp]),
+    "dfh_residual_data": (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _int, _c_double_p, _vp, _vp]),
+    "dfh_residual_reg": (_int, [_vp, _int, _int, _vp, _vp, _vp, _dbl, _vp, _vp]),
+    "dfh_sample_knn": (_int, [_vp, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
+    "dfh_gn_associate": (_int, [_vp, _vp, _vp, _int, _int, _vp, _c_double_p, _vp, _int, _int, _int, _c_double_p,
+                                _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, _vp, _vp]),
+    "dfh_gn_build": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _c_double_p, _dbl,
+                            _vp, _vp, _int, _vp, _vp, _vp, _vp]),
+    "dfh_pcg_workspace_bytes": (ctypes.c_size_t, [_int, _int]),
+    "dfh_pcg_solve": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dfh_apply_twist": (_int, [_vp, _vp, _int, _dbl, _vp]),
 }
 
 _lib = None

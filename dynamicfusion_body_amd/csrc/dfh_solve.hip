@@ -1,0 +1,879 @@
+// Warp-field solve.
+//
+//  * Residual evaluators with the reference's definitions, for parity:
+//      dfh_residual_rigid  = FusionDM.computef_lw      (reference core/fusion_dm.py:285-297)
+//      dfh_residual_data   = data rows of Fusion.computef / computef_lw (core/fusion.py:444-473)
+//      dfh_residual_reg    = regularisation rows of Fusion.computef     (core/fusion.py:475-484)
+//  * The Gauss-Newton machinery the reference does not have (it calls scipy's trust-region
+//    solver with finite-difference Jacobians, core/fusion.py:382-392): per-sample node search and
+//    static blend weights, projective data association with fuseDepths' projection primitives
+//    (core/fusion_dm.py:191-200), analytic 6-DoF left-twist Jacobians (derivation in
+//    oracle/gn_np.py, pinned against finite differences of the reference's residual), normal
+//    equations in 6x6 block-sparse rows, block-Jacobi PCG, and the update dq <- exp(xi) (x) dq.
+//
+// Everything is fp64: per GN iteration the work is ~1 kflop/sample over ~1e5..1e6 samples, far
+// from any roofline that would justify fp32, and fp64 keeps the residual bit-comparable with the
+// CPU path.  J^T J accumulation: samples arrive sorted by their k-node tuple; a 256-sample tile
+// stages its Jacobian rows in LDS, threads own matrix entries and walk the tile in order, and
+// one fp64 atomic per entry and run of equal tuples reaches HBM (no per-sample atomics).
+// f32-input MFMA runs at the vector rate on gfx950 and bf16 would break the 1e-4 residual bar,
+// so the contraction stays on the VALU (BASELINE north_star: "MFMA only if ...").
+#include "dfh_dq.h"
+
+namespace dfh {
+
+constexpr int kKMaxS = 8;
+
+struct Q4 { double w, x, y, z; };
+
+__device__ __forceinline__ Q4 qmul(const Q4 &a, const Q4 &b) {
+    Q4 o;
+    o.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    o.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    o.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    o.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return o;
+}
+__device__ __forceinline__ Q4 qconj(const Q4 &a) { return Q4{a.w, -a.x, -a.y, -a.z}; }
+__device__ __forceinline__ Q4 qpure(double x, double y, double z) { return Q4{0.0, x, y, z}; }
+__device__ __forceinline__ Q4 qadd(const Q4 &a, const Q4 &b) { return Q4{a.w + b.w, a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ Q4 qscale(const Q4 &a, double s) { return Q4{a.w * s, a.x * s, a.y * s, a.z * s}; }
+
+// Blend the k node DQs of one point (explicit indices, weights from positions exactly like
+// Fusion.dq_blend, core/fusion.py:527-551), then warp point (and normal) through the blend and
+// m_lw like Fusion.warp (:502-520).  bh receives the normalised blend, wts the raw weights.
+__device__ __forceinline__ void blend_from_indices(const double *__restrict__ node_dq, const double *__restrict__ node_pos,
+                                                   const double *__restrict__ node_w, const int *idx, int k,
+                                                   double px, double py, double pz, double *bh, double *nb_out,
+                                                   double *wts) {
+    double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) {
+        if (j < k) {
+            const int gi = idx[j];
+            const double dx = px - node_pos[3 * gi], dy = py - node_pos[3 * gi + 1], dz = pz - node_pos[3 * gi + 2];
+            const double dist = sqrt((dx * dx + dy * dy) + dz * dz);
+            const double t = dist / (2.0 * node_w[gi]);
+            const double wgt = exp(-1.0 * (t * t));
+            if (wts) wts[j] = wgt;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b[c] = b[c] + wgt * node_dq[8 * gi + c];
+        }
+    }
+    const double n2 = ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3])) +
+                      ((b[4] * b[4] + b[5] * b[5]) + (b[6] * b[6] + b[7] * b[7]));
+    const double n = sqrt(n2);
+    if (n == 0.0) {
+        bh[0] = 1.0;
+#pragma unroll
+        for (int c = 1; c < 8; ++c) bh[c] = 0.0;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bh[c] = b[c] / n;
+    }
+    if (nb_out) *nb_out = n;
+}
+
+// ------------------------------------------------------------------------------- residuals
+__global__ __launch_bounds__(256) void residual_rigid_kernel(const double *__restrict__ verts, const double *__restrict__ norms,
+                                                              const double *__restrict__ corr, int n, DQ x,
+                                                              double *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const D3 wn = dqb_warp_normal_exact(x.q, round_f32(norms[3 * i]), round_f32(norms[3 * i + 1]), round_f32(norms[3 * i + 2]));
+    const D3 vp = dqb_warp_exact(x.q, round_f32(verts[3 * i]), round_f32(verts[3 * i + 1]), round_f32(verts[3 * i + 2]));
+    const double d0 = vp.x - corr[3 * i], d1 = vp.y - corr[3 * i + 1], d2 = vp.z - corr[3 * i + 2];
+    out[i] = (wn.x * d0 + wn.y * d1) + wn.z * d2;                    // fusion_dm.py:293
+}
+
+__global__ __launch_bounds__(256) void residual_data_kernel(const double *__restrict__ verts, const double *__restrict__ norms,
+                                                             const double *__restrict__ corr, const int *__restrict__ nbr,
+                                                             int V, int k, const double *__restrict__ node_dq,
+                                                             const double *__restrict__ node_pos,
+                                                             const double *__restrict__ node_w, DQ lw,
+                                                             double *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    int idx[kKMaxS];
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) idx[j] = j < k ? nbr[(size_t)i * k + j] : 0;
+    const double px = verts[3 * i], py = verts[3 * i + 1], pz = verts[3 * i + 2];
+    double bh[8];
+    blend_from_indices(node_dq, node_pos, node_w, idx, k, px, py, pz, bh, nullptr, nullptr);     // fusion.py:508
+    const D3 x1 = dqb_warp_exact(bh, round_f32(px), round_f32(py), round_f32(pz));                // :510
+    const D3 xp = dqb_warp_exact(lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));        // :512
+    const D3 n1 = dqb_warp_normal_exact(bh, round_f32(norms[3 * i]), round_f32(norms[3 * i + 1]), round_f32(norms[3 * i + 2]));  // :515
+    const D3 np_ = dqb_warp_normal_exact(lw.q, round_f32(n1.x), round_f32(n1.y), round_f32(n1.z));                             // :517
+    const double d0 = xp.x - corr[3 * i], d1 = xp.y - corr[3 * i + 1], d2 = xp.z - corr[3 * i + 2];
+    out[i] = (np_.x * d0 + np_.y * d1) + np_.z * d2;                 // fusion.py:470
+}
+
+__global__ __launch_bounds__(256) void residual_reg_kernel(const int *__restrict__ node_nbr, int N, int k,
+                                                            const double *__restrict__ node_dq,
+                                                            const double *__restrict__ node_pos,
+                                                            const double *__restrict__ node_w, double rw,
+                                                            double *__restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * k) return;
+    const int i = t / k;
+    const int j = node_nbr[t];
+    const double vx = round_f32(node_pos[3 * j]), vy = round_f32(node_pos[3 * j + 1]), vz = round_f32(node_pos[3 * j + 2]);
+    const D3 yi = dqb_warp_exact(node_dq + 8 * i, vx, vy, vz);
+    const D3 yj = dqb_warp_exact(node_dq + 8 * j, vx, vy, vz);
+    const double wi = node_w[i], wj = node_w[j];
+    const double c = rw * (wi > wj ? wi : wj);                       // rw * max(w_i, w_j), fusion.py:482
+    out[3 * t + 0] = c * (yi.x - yj.x);
+    out[3 * t + 1] = c * (yi.y - yj.y);
+    out[3 * t + 2] = c * (yi.z - yj.z);
+}
+
+// Rigid 6-DoF normal equations for the global `_lw`: r_i as above, J_i = [ c_i x m_i | s m_i ]
+// (m = warped normal, s = |r_x|^2; derivation in oracle/gn_np.py).  out: 36 (J^T J) + 6 (J^T r)
+// + 1 (0.5|r|^2) + 1 (count) doubles, accumulated with one atomic per block and entry.
+__global__ __launch_bounds__(256) void gn_build_rigid_kernel(const double *__restrict__ verts, const double *__restrict__ norms,
+                                                              const double *__restrict__ corr,
+                                                              const unsigned char *__restrict__ valid, int n, DQ x,
+                                                              double *__restrict__ out) {
+    __shared__ double red[256];
+    double acc[29];
+    for (int e = 0; e < 29; ++e) acc[e] = 0.0;
+    const double s = (x.q[0] * x.q[0] + x.q[1] * x.q[1]) + (x.q[2] * x.q[2] + x.q[3] * x.q[3]);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (valid && !valid[i]) continue;
+        const D3 m = dqb_warp_normal_exact(x.q, round_f32(norms[3 * i]), round_f32(norms[3 * i + 1]), round_f32(norms[3 * i + 2]));
+        const D3 y = dqb_warp_exact(x.q, round_f32(verts[3 * i]), round_f32(verts[3 * i + 1]), round_f32(verts[3 * i + 2]));
+        const double c0 = corr[3 * i], c1 = corr[3 * i + 1], c2 = corr[3 * i + 2];
+        const double r = (m.x * (y.x - c0) + m.y * (y.y - c1)) + m.z * (y.z - c2);
+        const double J[6] = {c1 * m.z - c2 * m.y, c2 * m.x - c0 * m.z, c0 * m.y - c1 * m.x, s * m.x, s * m.y, s * m.z};
+        int e = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) acc[e++] += J[a] * J[b];
+        for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+        acc[27] += 0.5 * r * r;
+        acc[28] += 1.0;
+    }
+    for (int e = 0; e < 29; ++e) {
+        red[threadIdx.x] = acc[e];
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && red[0] != 0.0) {
+            if (e < 21) {
+                int a = 0, rem = e;
+                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+                const int b = a + rem;
+                atomicAdd(out + 6 * a + b, red[0]);
+                if (a != b) atomicAdd(out + 6 * b + a, red[0]);
+            } else {
+                atomicAdd(out + 36 + (e - 21), red[0]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------- sample setup
+constexpr int kSBX = 4, kSBY = 4, kSBZ = 16, kSCap = 64;     // must match dfh_fuse_volume.hip bricks
+
+__device__ __forceinline__ void top8_insert_s(double (&bd)[kKMaxS], int (&bi)[kKMaxS], double d2, int idx) {
+#pragma unroll
+    for (int i = 0; i < kKMaxS; ++i) {
+        const bool lt = d2 < bd[i];
+        const double td = bd[i];
+        const int ti = bi[i];
+        bd[i] = lt ? d2 : td;
+        bi[i] = lt ? idx : ti;
+        d2 = lt ? td : d2;
+        idx = lt ? ti : idx;
+    }
+}
+
+// k nearest nodes + Gaussian blend weights of arbitrary sample points (brute force over all
+// nodes: runs once per frame, S*N distance evaluations).
+__global__ __launch_bounds__(256) void sample_knn_kernel(const double *__restrict__ spos, int S, const double *__restrict__ node_pos,
+                                                          const double *__restrict__ node_w, int N, int k,
+                                                          int *__restrict__ nbr, double *__restrict__ wts) {
+    __shared__ double sp[256 * 3];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < S;
+    const double px = act ? spos[3 * (size_t)i] : 0.0, py = act ? spos[3 * (size_t)i + 1] : 0.0, pz = act ? spos[3 * (size_t)i + 2] : 0.0;
+    double bd[kKMaxS];
+    int bi[kKMaxS];
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) { bd[j] = __builtin_huge_val(); bi[j] = -1; }
+    for (int base = 0; base < N; base += 256) {
+        const int n = min(256, N - base);
+        if ((int)threadIdx.x < n) {
+            sp[3 * threadIdx.x] = node_pos[3 * (base + threadIdx.x)];
+            sp[3 * threadIdx.x + 1] = node_pos[3 * (base + threadIdx.x) + 1];
+            sp[3 * threadIdx.x + 2] = node_pos[3 * (base + threadIdx.x) + 2];
+        }
+        __syncthreads();
+        if (act) {
+            for (int j = 0; j < n; ++j) {
+                const double dx = px - sp[3 * j], dy = py - sp[3 * j + 1], dz = pz - sp[3 * j + 2];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 < bd[kKMaxS - 1]) top8_insert_s(bd, bi, d2, base + j);
+            }
+        }
+        __syncthreads();
+    }
+    if (!act) return;
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) {
+        if (j < k) {
+            const int gi = bi[j];
+            nbr[(size_t)i * k + j] = gi;
+            const double t = sqrt(bd[j]) / (2.0 * node_w[gi]);
+            wts[(size_t)i * k + j] = exp(-1.0 * (t * t));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- association
+struct AssocParams {
+    Mat3 K, Kinv;
+    Mat34 lw_cam;
+    Mat3 Rinv;            // inverse of lw_cam's 3x3 part
+    DQ lw;
+    double scale, cx, cy, cz, half, max_dist;
+    int H, W, k;
+};
+
+// Warp every sample with the current field, project it into the live depth frame with the
+// reference's primitives and back-project the nearest depth pixel: corr (index space), valid.
+template <typename DepthT>
+__global__ __launch_bounds__(256) void associate_kernel(const double *__restrict__ spos, const int *__restrict__ nbr,
+                                                         const double *__restrict__ wts, int S,
+                                                         const double *__restrict__ node_dq, const DepthT *__restrict__ depth,
+                                                         const AssocParams p, double *__restrict__ corr,
+                                                         unsigned char *__restrict__ valid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) {
+        if (j < p.k) {
+            const int gi = nbr[(size_t)i * p.k + j];
+            const double w = wts[(size_t)i * p.k + j];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b[c] = b[c] + w * node_dq[8 * gi + c];
+        }
+    }
+    const double n = sqrt(((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3])) +
+                          ((b[4] * b[4] + b[5] * b[5]) + (b[6] * b[6] + b[7] * b[7])));
+    if (n == 0.0) { b[0] = 1.0; for (int c = 1; c < 8; ++c) b[c] = 0.0; }
+    else { for (int c = 0; c < 8; ++c) b[c] = b[c] / n; }
+    const double px = spos[3 * (size_t)i], py = spos[3 * (size_t)i + 1], pz = spos[3 * (size_t)i + 2];
+    const D3 x1 = dqb_warp_exact(b, round_f32(px), round_f32(py), round_f32(pz));
+    const D3 xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
+    // index -> world -> camera -> pixel (fusion_dm.py:191-195)
+    const double wx = p.scale * (xp.x - p.half) + p.cx, wy = p.scale * (xp.y - p.half) + p.cy, wz = p.scale * (xp.z - p.half) + p.cz;
+    const double *lw = p.lw_cam.m;
+    const double l0 = ((lw[0] * wx + lw[1] * wy) + lw[2] * wz) + lw[3];
+    const double l1 = ((lw[4] * wx + lw[5] * wy) + lw[6] * wz) + lw[7];
+    const double l2 = ((lw[8] * wx + lw[9] * wy) + lw[10] * wz) + lw[11];
+    const double p0 = (p.K.m[0] * l0 + p.K.m[1] * l1) + p.K.m[2] * l2;
+    const double p1 = (p.K.m[3] * l0 + p.K.m[4] * l1) + p.K.m[5] * l2;
+    const double p2 = (p.K.m[6] * l0 + p.K.m[7] * l1) + p.K.m[8] * l2;
+    bool ok = p2 != 0.0;
+    const double u = p0 / p2, v = p1 / p2;
+    ok = ok && (u >= 0.0) && (u < (double)(p.W - 1)) && (v >= 0.0) && (v < (double)(p.H - 1));
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (ok) {
+        const int ui = (int)rint(u), vi = (int)rint(v);
+        const double z = -1.0 * (double)depth[(size_t)vi * p.W + ui];                  // :196
+        ok = z > 0.0;
+        // back-projection K^-1 (z [u,v,1]) (:198-200), camera -> world -> index
+        const double a0 = z * u, a1 = z * v, a2 = z * 1.0;
+        const double q0 = (p.Kinv.m[0] * a0 + p.Kinv.m[1] * a1) + p.Kinv.m[2] * a2 - lw[3];
+        const double q1 = (p.Kinv.m[3] * a0 + p.Kinv.m[4] * a1) + p.Kinv.m[5] * a2 - lw[7];
+        const double q2 = (p.Kinv.m[6] * a0 + p.Kinv.m[7] * a1) + p.Kinv.m[8] * a2 - lw[11];
+        const double X = (p.Rinv.m[0] * q0 + p.Rinv.m[1] * q1) + p.Rinv.m[2] * q2;
+        const double Y = (p.Rinv.m[3] * q0 + p.Rinv.m[4] * q1) + p.Rinv.m[5] * q2;
+        const double Z = (p.Rinv.m[6] * q0 + p.Rinv.m[7] * q1) + p.Rinv.m[8] * q2;
+        c0 = (X - p.cx) / p.scale + p.half;
+        c1 = (Y - p.cy) / p.scale + p.half;
+        c2 = (Z - p.cz) / p.scale + p.half;
+        if (ok && p.max_dist > 0.0) {
+            const double dx = c0 - xp.x, dy = c1 - xp.y, dz = c2 - xp.z;
+            ok = (dx * dx + dy * dy + dz * dz) <= p.max_dist * p.max_dist;
+        }
+    }
+    corr[3 * (size_t)i] = ok ? c0 : 0.0;
+    corr[3 * (size_t)i + 1] = ok ? c1 : 0.0;
+    corr[3 * (size_t)i + 2] = ok ? c2 : 0.0;
+    valid[i] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------- normal equations
+// Block-sparse rows: node a owns blocks vals[row_ptr[a] .. row_ptr[a+1]) with sorted column
+// nodes col[]; a block is 36 doubles, row-major 6x6.
+__device__ __forceinline__ int find_block(const int *__restrict__ row_ptr, const int *__restrict__ col, int a, int b) {
+    int lo = row_ptr[a], hi = row_ptr[a + 1] - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = col[mid];
+        if (c == b) return mid;
+        if (c < b) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+struct BuildParams {
+    DQ lw;
+    int S, k, N;
+};
+
+constexpr int kTile = 256;
+
+// Residual and 6-DoF Jacobian rows of one data sample (formulas: oracle/gn_np.py
+// data_residual_jacobian).  J is written as k x 6 into Jrow (row-major), returns r.
+__device__ __forceinline__ double data_row(const double *__restrict__ node_dq, const int *idx, const double *w, int k,
+                                           const double *lwq, double px, double py, double pz, double nx, double ny,
+                                           double nz, double c0, double c1, double c2, double *Jrow) {
+    double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) {
+        if (j < k) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b[c] = b[c] + w[j] * node_dq[8 * idx[j] + c];
+        }
+    }
+    double nb = sqrt(((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3])) +
+                     ((b[4] * b[4] + b[5] * b[5]) + (b[6] * b[6] + b[7] * b[7])));
+    double bh[8];
+    if (nb == 0.0) { bh[0] = 1.0; for (int c = 1; c < 8; ++c) bh[c] = 0.0; nb = 1.0; }
+    else { for (int c = 0; c < 8; ++c) bh[c] = b[c] / nb; }
+    const double pfx = round_f32(px), pfy = round_f32(py), pfz = round_f32(pz);
+    const double nfx = round_f32(nx), nfy = round_f32(ny), nfz = round_f32(nz);
+    const D3 x1 = dqb_warp_exact(bh, pfx, pfy, pfz);
+    const D3 n1 = dqb_warp_normal_exact(bh, nfx, nfy, nfz);
+    const D3 xp = dqb_warp_exact(lwq, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
+    const D3 np_ = dqb_warp_normal_exact(lwq, round_f32(n1.x), round_f32(n1.y), round_f32(n1.z));
+    const double d0 = xp.x - c0, d1 = xp.y - c1, d2 = xp.z - c2;
+    const double r = (np_.x * d0 + np_.y * d1) + np_.z * d2;
+    // u = A^T n', h = A^T (x' - c),  A^T y = vec(rl* Y rl)
+    const Q4 rl{lwq[0], lwq[1], lwq[2], lwq[3]};
+    const Q4 rlc = qconj(rl);
+    const Q4 U = qmul(qmul(rlc, qpure(np_.x, np_.y, np_.z)), rl);
+    const Q4 Hq = qmul(qmul(rlc, qpure(d0, d1, d2)), rl);
+    const Q4 Up = qpure(U.x, U.y, U.z), Hp = qpure(Hq.x, Hq.y, Hq.z);
+    const Q4 rr{bh[0], bh[1], bh[2], bh[3]}, dd{bh[4], bh[5], bh[6], bh[7]};
+    const Q4 Ur = qmul(Up, rr);
+    Q4 g_r = qadd(qadd(qmul(Ur, qpure(pfx, pfy, pfz)), qmul(Up, dd)), qmul(qmul(Hp, rr), qpure(nfx, nfy, nfz)));
+    g_r = qscale(g_r, -2.0);
+    Q4 g_d = qscale(Ur, 2.0);
+    const double gb = (g_r.w * bh[0] + g_r.x * bh[1] + g_r.y * bh[2] + g_r.z * bh[3]) +
+                      (g_d.w * bh[4] + g_d.x * bh[5] + g_d.y * bh[6] + g_d.z * bh[7]);
+    const double inv = 1.0 / nb;
+    g_r = Q4{(g_r.w - gb * bh[0]) * inv, (g_r.x - gb * bh[1]) * inv, (g_r.y - gb * bh[2]) * inv, (g_r.z - gb * bh[3]) * inv};
+    g_d = Q4{(g_d.w - gb * bh[4]) * inv, (g_d.x - gb * bh[5]) * inv, (g_d.y - gb * bh[6]) * inv, (g_d.z - gb * bh[7]) * inv};
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) {
+        if (j < k) {
+            const double *q = node_dq + 8 * idx[j];
+            const Q4 rac{q[0], -q[1], -q[2], -q[3]}, dac{q[4], -q[5], -q[6], -q[7]};
+            const Q4 a = qadd(qmul(g_r, rac), qmul(g_d, dac));
+            const Q4 t = qmul(g_d, rac);
+            const double hw = 0.5 * w[j];
+            Jrow[6 * j + 0] = hw * a.x; Jrow[6 * j + 1] = hw * a.y; Jrow[6 * j + 2] = hw * a.z;
+            Jrow[6 * j + 3] = hw * t.x; Jrow[6 * j + 4] = hw * t.y; Jrow[6 * j + 5] = hw * t.z;
+        }
+    }
+    return r;
+}
+
+// One 256-sample tile per block.  Samples must be sorted by their k-tuple of nodes (any order
+// is CORRECT; sorted order just means few runs per tile and therefore few atomics).
+template <int K>
+__global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
+                                                             const int *__restrict__ nbr, const double *__restrict__ wts,
+                                                             const double *__restrict__ corr,
+                                                             const unsigned char *__restrict__ valid,
+                                                             const double *__restrict__ node_dq, const BuildParams p,
+                                                             const int *__restrict__ row_ptr, const int *__restrict__ col,
+                                                             double *__restrict__ vals, double *__restrict__ rhs,
+                                                             double *__restrict__ cost_count) {
+    constexpr int NJ = 6 * K;                   // Jacobian entries per sample
+    constexpr int LD = NJ + 1;                  // + residual
+    __shared__ double sJ[kTile * LD];
+    __shared__ int sIdx[kTile * K];
+    __shared__ int sHead[kTile];                // 1 where a run of equal tuples starts
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x * kTile + tid;
+    const int tile_n = min(kTile, p.S - blockIdx.x * kTile);
+    double r = 0.0;
+    {
+        double Jrow[NJ];
+        int idx[kKMaxS];
+        double w[kKMaxS];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) Jrow[j] = 0.0;
+        if (tid < tile_n) {
+#pragma unroll
+            for (int j = 0; j < kKMaxS; ++j) {
+                idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
+                w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
+            }
+            if (valid[s]) {
+                r = data_row(node_dq, idx, w, K, p.lw.q, spos[3 * (size_t)s], spos[3 * (size_t)s + 1], spos[3 * (size_t)s + 2],
+                             snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], corr[3 * (size_t)s],
+                             corr[3 * (size_t)s + 1], corr[3 * (size_t)s + 2], Jrow);
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) sIdx[tid * K + j] = idx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) sJ[tid * LD + j] = Jrow[j];
+        sJ[tid * LD + NJ] = r;
+    }
+    __syncthreads();
+    if (tid < tile_n) {
+        bool head = tid == 0;
+        if (!head) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) head = head || (sIdx[tid * K + j] != sIdx[(tid - 1) * K + j]);
+        }
+        sHead[tid] = head ? 1 : 0;
+    }
+    __syncthreads();
+    // entries: upper triangle of the NJ x NJ Gram matrix, then NJ entries of J^T r, then cost
+    constexpr int NUP = NJ * (NJ + 1) / 2;
+    for (int e = tid; e < NUP + NJ + 1; e += 256) {
+        int pa, pb;                              // Jacobian columns of this entry (pb == NJ: residual)
+        if (e < NUP) {
+            // unrank e -> (pa <= pb)
+            int row = 0, rem = e;
+            while (rem >= NJ - row) { rem -= NJ - row; ++row; }
+            pa = row; pb = row + rem;
+        } else if (e < NUP + NJ) {
+            pa = e - NUP; pb = NJ;
+        } else {
+            pa = NJ; pb = NJ;
+        }
+        double acc = 0.0;
+        int run_start = 0;
+        for (int t = 0; t <= tile_n; ++t) {
+            if (t == tile_n || (t > 0 && sHead[t])) {
+                // flush run [run_start, t)
+                if (acc != 0.0) {
+                    if (pb == NJ && pa == NJ) {
+                        atomicAdd(cost_count, 0.5 * acc);
+                    } else if (pb == NJ) {
+                        atomicAdd(rhs + 6 * sIdx[run_start * K + pa / 6] + pa % 6, acc);
+                    } else {
+                        const int na = sIdx[run_start * K + pa / 6], nbn = sIdx[run_start * K + pb / 6];
+                        const int ia = pa % 6, ib = pb % 6;
+                        const int blk = find_block(row_ptr, col, na, nbn);
+                        if (blk >= 0) atomicAdd(vals + 36 * (size_t)blk + 6 * ia + ib, acc);
+                        if (!(na == nbn && ia == ib)) {
+                            const int blk2 = na == nbn ? blk : find_block(row_ptr, col, nbn, na);
+                            if (blk2 >= 0) atomicAdd(vals + 36 * (size_t)blk2 + 6 * ib + ia, acc);
+                        }
+                    }
+                }
+                acc = 0.0;
+                run_start = t;
+                if (t == tile_n) break;
+            }
+            acc += sJ[t * LD + pa] * sJ[t * LD + pb];
+        }
+    }
+    // valid-sample count rides in cost_count[1]
+    if (tid < tile_n && valid[s]) atomicAdd(cost_count + 1, 1.0);
+}
+
+// Regularisation rows rho_ij = c_ij (W(q_i,v_j) - W(q_j,v_j)): one thread per (i, slot).
+__global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict__ node_nbr, int N, int k,
+                                                            const double *__restrict__ node_dq,
+                                                            const double *__restrict__ node_pos,
+                                                            const double *__restrict__ node_w, double rw,
+                                                            const int *__restrict__ row_ptr, const int *__restrict__ col,
+                                                            double *__restrict__ vals, double *__restrict__ rhs,
+                                                            double *__restrict__ cost_count) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * k) return;
+    const int i = t / k;
+    const int j = node_nbr[t];
+    if (i == j) return;                                            // zero rows, zero Jacobian
+    const double vx = round_f32(node_pos[3 * j]), vy = round_f32(node_pos[3 * j + 1]), vz = round_f32(node_pos[3 * j + 2]);
+    const double *qi = node_dq + 8 * i, *qj = node_dq + 8 * j;
+    const D3 yi = dqb_warp_exact(qi, vx, vy, vz);
+    const D3 yj = dqb_warp_exact(qj, vx, vy, vz);
+    const double wi = node_w[i], wj = node_w[j];
+    const double c = rw * (wi > wj ? wi : wj);
+    const double rho[3] = {c * (yi.x - yj.x), c * (yi.y - yj.y), c * (yi.z - yj.z)};
+    const double si = (qi[0] * qi[0] + qi[1] * qi[1]) + (qi[2] * qi[2] + qi[3] * qi[3]);
+    const double sj = (qj[0] * qj[0] + qj[1] * qj[1]) + (qj[2] * qj[2] + qj[3] * qj[3]);
+    // J_i = c [ -[y_i]x | s_i I ],  J_j = -c [ -[y_j]x | s_j I ]   (3 x 6 each)
+    double Ji[3][6], Jj[3][6];
+    const double yiv[3] = {yi.x, yi.y, yi.z}, yjv[3] = {yj.x, yj.y, yj.z};
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 6; ++b) { Ji[a][b] = 0.0; Jj[a][b] = 0.0; }
+    // -[y]x = [[0, y2, -y1], [-y2, 0, y0], [y1, -y0, 0]]
+    Ji[0][1] = c * yiv[2];  Ji[0][2] = -c * yiv[1]; Ji[1][0] = -c * yiv[2]; Ji[1][2] = c * yiv[0];
+    Ji[2][0] = c * yiv[1];  Ji[2][1] = -c * yiv[0];
+    Jj[0][1] = -c * yjv[2]; Jj[0][2] = c * yjv[1];  Jj[1][0] = c * yjv[2];  Jj[1][2] = -c * yjv[0];
+    Jj[2][0] = -c * yjv[1]; Jj[2][1] = c * yjv[0];
+    for (int a = 0; a < 3; ++a) { Ji[a][3 + a] = c * si; Jj[a][3 + a] = -c * sj; }
+    const int bii = find_block(row_ptr, col, i, i), bjj = find_block(row_ptr, col, j, j);
+    const int bij = find_block(row_ptr, col, i, j), bji = find_block(row_ptr, col, j, i);
+    for (int a = 0; a < 6; ++a) {
+        double gi = 0.0, gj = 0.0;
+        for (int m = 0; m < 3; ++m) { gi += Ji[m][a] * rho[m]; gj += Jj[m][a] * rho[m]; }
+        atomicAdd(rhs + 6 * i + a, gi);
+        atomicAdd(rhs + 6 * j + a, gj);
+        for (int b = 0; b < 6; ++b) {
+            double vii = 0.0, vjj = 0.0, vij = 0.0;
+            for (int m = 0; m < 3; ++m) {
+                vii += Ji[m][a] * Ji[m][b];
+                vjj += Jj[m][a] * Jj[m][b];
+                vij += Ji[m][a] * Jj[m][b];
+            }
+            if (bii >= 0 && vii != 0.0) atomicAdd(vals + 36 * (size_t)bii + 6 * a + b, vii);
+            if (bjj >= 0 && vjj != 0.0) atomicAdd(vals + 36 * (size_t)bjj + 6 * a + b, vjj);
+            if (bij >= 0 && vij != 0.0) atomicAdd(vals + 36 * (size_t)bij + 6 * a + b, vij);
+            if (bji >= 0 && vij != 0.0) atomicAdd(vals + 36 * (size_t)bji + 6 * b + a, vij);
+        }
+    }
+    atomicAdd(cost_count, 0.5 * ((rho[0] * rho[0] + rho[1] * rho[1]) + rho[2] * rho[2]));
+}
+
+// ------------------------------------------------------------------------------- PCG
+// Solves (A + lm_abs I + lm_rel diag(A)) x = -rhs with block-Jacobi preconditioning; one thread
+// per node row; scalars live in `scal` (3 doubles per iteration: rz, pAp, rz_next).
+__device__ __forceinline__ void inv6(const double *A, double *Ainv) {
+    // Gauss-Jordan with partial pivoting on a 6x6 SPD-ish block
+    double M[6][12];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) { M[i][j] = A[6 * i + j]; M[i][6 + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        double best = fabs(M[c][c]);
+        for (int r = c + 1; r < 6; ++r) if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); piv = r; }
+        if (piv != c) for (int j = 0; j < 12; ++j) { const double t = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = t; }
+        const double d = M[c][c];
+        const double id = d != 0.0 ? 1.0 / d : 0.0;
+        for (int j = 0; j < 12; ++j) M[c][j] *= id;
+        for (int r = 0; r < 6; ++r) {
+            if (r == c) continue;
+            const double f = M[r][c];
+            for (int j = 0; j < 12; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) Ainv[6 * i + j] = M[i][6 + j];
+}
+
+struct PcgParams {
+    int N;
+    double lm_abs, lm_rel;
+};
+
+__global__ __launch_bounds__(256) void pcg_init_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col,
+                                                        double *__restrict__ vals, const double *__restrict__ rhs,
+                                                        const PcgParams p, double *__restrict__ Minv, double *__restrict__ x,
+                                                        double *__restrict__ r, double *__restrict__ pv, double *__restrict__ scal) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= p.N) return;
+    const int blk = find_block(row_ptr, col, a, a);
+    double D[36];
+    for (int i = 0; i < 36; ++i) D[i] = blk >= 0 ? vals[36 * (size_t)blk + i] : 0.0;
+    for (int i = 0; i < 6; ++i) D[7 * i] = D[7 * i] + p.lm_abs + p.lm_rel * D[7 * i];
+    if (blk >= 0) for (int i = 0; i < 6; ++i) vals[36 * (size_t)blk + 7 * i] = D[7 * i];     // damping lives in the matrix
+    double Di[36];
+    inv6(D, Di);
+    for (int i = 0; i < 36; ++i) Minv[36 * (size_t)a + i] = Di[i];
+    double rz = 0.0;
+    double rl[6], zl[6];
+    for (int i = 0; i < 6; ++i) { rl[i] = -rhs[6 * a + i]; x[6 * a + i] = 0.0; r[6 * a + i] = rl[i]; }
+    for (int i = 0; i < 6; ++i) {
+        double z = 0.0;
+        for (int j = 0; j < 6; ++j) z += Di[6 * i + j] * rl[j];
+        zl[i] = z;
+        pv[6 * a + i] = z;
+        rz += rl[i] * z;
+    }
+    atomicAdd(scal + 0, rz);
+}
+
+__global__ __launch_bounds__(256) void pcg_spmv_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col,
+                                                        const double *__restrict__ vals, int N, const double *__restrict__ pv,
+                                                        double *__restrict__ Ap, double *__restrict__ scal) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= N) return;
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = row_ptr[a]; b < row_ptr[a + 1]; ++b) {
+        const double *B = vals + 36 * (size_t)b;
+        const double *pj = pv + 6 * col[b];
+        for (int i = 0; i < 6; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < 6; ++j) acc += B[6 * i + j] * pj[j];
+            y[i] += acc;
+        }
+    }
+    double pAp = 0.0;
+    for (int i = 0; i < 6; ++i) { Ap[6 * a + i] = y[i]; pAp += pv[6 * a + i] * y[i]; }
+    atomicAdd(scal + 1, pAp);
+}
+
+__global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double *__restrict__ Minv, double *__restrict__ x,
+                                                             double *__restrict__ r, const double *__restrict__ pv,
+                                                             const double *__restrict__ Ap, double *__restrict__ z,
+                                                             double *__restrict__ scal) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= N) return;
+    const double rz = scal[0], pAp = scal[1];
+    const double alpha = pAp != 0.0 ? rz / pAp : 0.0;
+    double rl[6];
+    for (int i = 0; i < 6; ++i) {
+        x[6 * a + i] += alpha * pv[6 * a + i];
+        rl[i] = r[6 * a + i] - alpha * Ap[6 * a + i];
+        r[6 * a + i] = rl[i];
+    }
+    double rzn = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        double zz = 0.0;
+        for (int j = 0; j < 6; ++j) zz += Minv[36 * (size_t)a + 6 * i + j] * rl[j];
+        z[6 * a + i] = zz;
+        rzn += rl[i] * zz;
+    }
+    atomicAdd(scal + 2, rzn);
+}
+
+// p = z + beta p; also rotates the scalars for the next iteration (thread 0 of block 0, after
+// every thread has read them: the rotation happens in the NEXT iteration's slot).
+__global__ __launch_bounds__(256) void pcg_update_p_kernel(int N, double *__restrict__ pv, const double *__restrict__ z,
+                                                            const double *__restrict__ scal, double *__restrict__ scal_next) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    const double rz = scal[0], rzn = scal[2];
+    const double beta = rz != 0.0 ? rzn / rz : 0.0;
+    if (a == 0) { scal_next[0] = rzn; scal_next[1] = 0.0; scal_next[2] = 0.0; }
+    if (a >= N) return;
+    for (int i = 0; i < 6; ++i) pv[6 * a + i] = z[6 * a + i] + beta * pv[6 * a + i];
+}
+
+// dq_a <- exp(xi_a) (x) dq_a  (exp: rotation exp(omega), translation v; oracle/gn_np.py)
+__global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ node_dq, const double *__restrict__ xi, int N,
+                                                           double step) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= N) return;
+    const double ox = step * xi[6 * a], oy = step * xi[6 * a + 1], oz = step * xi[6 * a + 2];
+    const double vx = step * xi[6 * a + 3], vy = step * xi[6 * a + 4], vz = step * xi[6 * a + 5];
+    const double th = sqrt(ox * ox + oy * oy + oz * oz);
+    const double half = 0.5 * th;
+    const double s = th < 1e-8 ? 0.5 - th * th / 48.0 : sin(half) / th;
+    const Q4 q{cos(half), s * ox, s * oy, s * oz};
+    const Q4 qe = qscale(qmul(qpure(vx, vy, vz), q), 0.5);
+    double *d = node_dq + 8 * a;
+    const Q4 r{d[0], d[1], d[2], d[3]}, dd{d[4], d[5], d[6], d[7]};
+    const Q4 nr = qmul(q, r);
+    const Q4 nd = qadd(qmul(q, dd), qmul(qe, r));
+    d[0] = nr.w; d[1] = nr.x; d[2] = nr.y; d[3] = nr.z;
+    d[4] = nd.w; d[5] = nd.x; d[6] = nd.y; d[7] = nd.z;
+}
+
+}  // namespace dfh
+
+// =================================================================================== C ABI
+extern "C" {
+
+int dfh_residual_rigid(const double *verts, const double *normals, const double *corr, int n, const double x[8],
+                       double *out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n >= 0, "dfh_residual_rigid: negative count");
+    if (n == 0) return DFH_OK;
+    DFH_REQUIRE(verts && normals && corr && x && out, "dfh_residual_rigid: null pointer");
+    DQ q;
+    for (int i = 0; i < 8; ++i) q.q[i] = x[i];
+    hipLaunchKernelGGL(residual_rigid_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, verts, normals, corr, n, q, out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_gn_build_rigid(const double *verts, const double *normals, const double *corr, const unsigned char *valid, int n,
+                       const double x[8], double *out44, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n >= 0 && x && out44, "dfh_gn_build_rigid: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DFH_HIP_CHECK(hipMemsetAsync(out44, 0, sizeof(double) * 44, s));
+    if (n == 0) return DFH_OK;
+    DFH_REQUIRE(verts && normals && corr, "dfh_gn_build_rigid: null pointer");
+    DQ q;
+    for (int i = 0; i < 8; ++i) q.q[i] = x[i];
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(gn_build_rigid_kernel, dim3(blocks), dim3(256), 0, s, verts, normals, corr, valid, n, q, out44);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_residual_data(const double *verts, const double *normals, const double *corr, const int *nbr, int n_verts,
+                      int knn, const double *node_dq, const double *node_pos, const double *node_w, int n_nodes,
+                      const double lw_dq[8], double *out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_verts >= 0 && n_nodes >= 1, "dfh_residual_data: bad sizes");
+    DFH_REQUIRE(knn >= 1 && knn <= kKMaxS, "dfh_residual_data: knn=%d outside [1,%d]", knn, kKMaxS);
+    if (n_verts == 0) return DFH_OK;
+    DFH_REQUIRE(verts && normals && corr && nbr && node_dq && node_pos && node_w && lw_dq && out, "dfh_residual_data: null pointer");
+    DQ q;
+    for (int i = 0; i < 8; ++i) q.q[i] = lw_dq[i];
+    hipLaunchKernelGGL(residual_data_kernel, dim3((n_verts + 255) / 256), dim3(256), 0, (hipStream_t)stream, verts, normals,
+                       corr, nbr, n_verts, knn, node_dq, node_pos, node_w, q, out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_residual_reg(const int *node_nbr, int n_nodes, int knn, const double *node_dq, const double *node_pos,
+                     const double *node_w, double rw, double *out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_nodes >= 0 && knn >= 1 && knn <= kKMaxS, "dfh_residual_reg: bad sizes");
+    if (n_nodes == 0) return DFH_OK;
+    DFH_REQUIRE(node_nbr && node_dq && node_pos && node_w && out, "dfh_residual_reg: null pointer");
+    const int n = n_nodes * knn;
+    hipLaunchKernelGGL(residual_reg_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, node_nbr, n_nodes, knn,
+                       node_dq, node_pos, node_w, rw, out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_sample_knn(const double *sample_pos, int n_samples, const double *node_pos, const double *node_w, int n_nodes,
+                   int knn, int *nbr_out, double *weights_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_samples >= 0 && knn >= 1 && knn <= kKMaxS && n_nodes >= knn, "dfh_sample_knn: bad sizes");
+    if (n_samples == 0) return DFH_OK;
+    DFH_REQUIRE(sample_pos && node_pos && node_w && nbr_out && weights_out, "dfh_sample_knn: null pointer");
+    hipLaunchKernelGGL(sample_knn_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, (hipStream_t)stream, sample_pos,
+                       n_samples, node_pos, node_w, n_nodes, knn, nbr_out, weights_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *weights, int n_samples, int knn,
+                     const double *node_dq, const double lw_dq[8], const void *depth, int depth_dtype, int H, int W,
+                     const double K[9], const double Kinv[9], const double lw_cam[12], double scale,
+                     const double center[3], double half, double max_dist, double *corr_out,
+                     unsigned char *valid_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_samples >= 0 && knn >= 1 && knn <= kKMaxS, "dfh_gn_associate: bad sizes");
+    DFH_REQUIRE(depth_dtype == DFH_F32 || depth_dtype == DFH_F64, "dfh_gn_associate: bad depth_dtype");
+    DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "dfh_gn_associate: bad depth map / scale");
+    if (n_samples == 0) return DFH_OK;
+    DFH_REQUIRE(sample_pos && nbr && weights && node_dq && lw_dq && depth && K && Kinv && lw_cam && center && corr_out && valid_out,
+                "dfh_gn_associate: null pointer");
+    AssocParams p;
+    for (int i = 0; i < 9; ++i) { p.K.m[i] = K[i]; p.Kinv.m[i] = Kinv[i]; }
+    for (int i = 0; i < 12; ++i) p.lw_cam.m[i] = lw_cam[i];
+    for (int i = 0; i < 8; ++i) p.lw.q[i] = lw_dq[i];
+    {   // inverse of the 3x3 part (adjugate)
+        const double *m = lw_cam;
+        const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+        const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+        DFH_REQUIRE(det != 0.0, "dfh_gn_associate: singular extrinsic");
+        const double id = 1.0 / det;
+        p.Rinv.m[0] = (e * i - f * h) * id; p.Rinv.m[1] = (c * h - b * i) * id; p.Rinv.m[2] = (b * f - c * e) * id;
+        p.Rinv.m[3] = (f * g - d * i) * id; p.Rinv.m[4] = (a * i - c * g) * id; p.Rinv.m[5] = (c * d - a * f) * id;
+        p.Rinv.m[6] = (d * h - e * g) * id; p.Rinv.m[7] = (b * g - a * h) * id; p.Rinv.m[8] = (a * e - b * d) * id;
+    }
+    p.scale = scale; p.cx = center[0]; p.cy = center[1]; p.cz = center[2]; p.half = half; p.max_dist = max_dist;
+    p.H = H; p.W = W; p.k = knn;
+    dim3 grid((n_samples + 255) / 256), block(256);
+    if (depth_dtype == DFH_F32) {
+        hipLaunchKernelGGL(associate_kernel<float>, grid, block, 0, (hipStream_t)stream, sample_pos, nbr, weights, n_samples,
+                           node_dq, (const float *)depth, p, corr_out, valid_out);
+    } else {
+        hipLaunchKernelGGL(associate_kernel<double>, grid, block, 0, (hipStream_t)stream, sample_pos, nbr, weights, n_samples,
+                           node_dq, (const double *)depth, p, corr_out, valid_out);
+    }
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                 const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,
+                 const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                 const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                 double *rhs, double *cost_count, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_samples >= 0 && n_nodes >= 1 && n_blocks >= 1, "dfh_gn_build: bad sizes");
+    DFH_REQUIRE(knn >= 1 && knn <= kKMaxS, "dfh_gn_build: knn=%d outside [1,%d]", knn, kKMaxS);
+    DFH_REQUIRE(node_dq && node_pos && node_w && lw_dq && row_ptr && col && vals && rhs && cost_count, "dfh_gn_build: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    DFH_HIP_CHECK(hipMemsetAsync(vals, 0, sizeof(double) * 36 * (size_t)n_blocks, s));
+    DFH_HIP_CHECK(hipMemsetAsync(rhs, 0, sizeof(double) * 6 * (size_t)n_nodes, s));
+    DFH_HIP_CHECK(hipMemsetAsync(cost_count, 0, sizeof(double) * 2, s));
+    if (n_samples > 0) {
+        DFH_REQUIRE(sample_pos && sample_nrm && nbr && weights && corr && valid, "dfh_gn_build: null sample pointer");
+        BuildParams p;
+        for (int i = 0; i < 8; ++i) p.lw.q[i] = lw_dq[i];
+        p.S = n_samples; p.k = knn; p.N = n_nodes;
+        dim3 grid((n_samples + kTile - 1) / kTile), block(256);
+#define DFH_BUILD(KK)                                                                                               \
+    case KK:                                                                                                        \
+        hipLaunchKernelGGL(gn_build_data_kernel<KK>, grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, valid, \
+                           node_dq, p, row_ptr, col, vals, rhs, cost_count);                                        \
+        break
+        switch (knn) {
+            DFH_BUILD(1); DFH_BUILD(2); DFH_BUILD(3); DFH_BUILD(4); DFH_BUILD(5); DFH_BUILD(6); DFH_BUILD(7); DFH_BUILD(8);
+        }
+#undef DFH_BUILD
+        DFH_HIP_CHECK(hipGetLastError());
+    }
+    if (node_nbr && rw != 0.0) {
+        const int n = n_nodes * knn;
+        hipLaunchKernelGGL(gn_build_reg_kernel, dim3((n + 255) / 256), dim3(256), 0, s, node_nbr, n_nodes, knn, node_dq, node_pos,
+                           node_w, rw, row_ptr, col, vals, rhs, cost_count);
+        DFH_HIP_CHECK(hipGetLastError());
+    }
+    return DFH_OK;
+}
+
+size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
+    if (n_nodes <= 0 || iters < 0) return 0;
+    // Minv (36N) + x,r,p,Ap,z (5*6N) + scalars (3 per iteration + 3)
+    return sizeof(double) * ((size_t)36 * n_nodes + (size_t)30 * n_nodes + 3 * ((size_t)iters + 2));
+}
+
+int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
+                  double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_nodes >= 1 && iters >= 1, "dfh_pcg_solve: bad sizes");
+    DFH_REQUIRE(row_ptr && col && vals && rhs && x_out && workspace, "dfh_pcg_solve: null pointer");
+    DFH_REQUIRE(workspace_bytes >= dfh_pcg_workspace_bytes(n_nodes, iters), "dfh_pcg_solve: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    double *ws = static_cast<double *>(workspace);
+    const size_t N6 = 6 * (size_t)n_nodes;
+    double *Minv = ws; ws += 36 * (size_t)n_nodes;
+    double *r = ws; ws += N6;
+    double *pv = ws; ws += N6;
+    double *Ap = ws; ws += N6;
+    double *z = ws; ws += N6;
+    double *scal = ws + N6;               // ws..ws+N6 stays spare
+    DFH_HIP_CHECK(hipMemsetAsync(scal, 0, sizeof(double) * 3 * ((size_t)iters + 2), s));
+    PcgParams p{n_nodes, lm_abs, lm_rel};
+    dim3 grid((n_nodes + 255) / 256), block(256);
+    hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, pv, scal);
+    for (int it = 0; it < iters; ++it) {
+        double *sc = scal + 3 * (size_t)it;
+        hipLaunchKernelGGL(pcg_spmv_kernel, grid, block, 0, s, row_ptr, col, vals, n_nodes, pv, Ap, sc);
+        hipLaunchKernelGGL(pcg_update_xr_kernel, grid, block, 0, s, n_nodes, Minv, x_out, r, pv, Ap, z, sc);
+        hipLaunchKernelGGL(pcg_update_p_kernel, grid, block, 0, s, n_nodes, pv, z, sc, sc + 3);
+    }
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_nodes >= 0, "dfh_apply_twist: negative count");
+    if (n_nodes == 0) return DFH_OK;
+    DFH_REQUIRE(node_dq && xi, "dfh_apply_twist: null pointer");
+    hipLaunchKernelGGL(apply_twist_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, (hipStream_t)stream, node_dq, xi, n_nodes, step);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+}  // extern "C"

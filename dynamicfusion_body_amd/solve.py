@@ -1,0 +1,301 @@
+"""Host side of the warp-field solve: device buffers, the block-sparse pattern of J^T J and the
+Gauss-Newton / Levenberg-Marquardt loop around the HIP kernels of csrc/dfh_solve.hip.
+
+The reference's solve is scipy.optimize.least_squares on `computef` with finite-difference
+Jacobians (core/fusion.py:327-412); what is kept from it is the residual definition, the
+hyper-parameters (`regularization_weight`, its /8 relaxation while the cost reduction stays in
+(5 %, 90 %), :405-412) and the call surface (see fusion.py / fusion_dm.py in this package).
+torch is used for allocation and for the once-per-frame index bookkeeping (sorting samples by
+node tuple, unique node pairs); every per-iteration step is a HIP kernel behind the C ABI.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .device import current_stream_ptr, dtype_code, require_gpu
+
+
+def _f64(a, shape_tail=None):
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64)))
+    t = t.to(device="cuda", dtype=torch.float64).contiguous()
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError("array has shape %s, expected (n,%s)" % (tuple(t.shape), ",".join(map(str, shape_tail))))
+    return t
+
+
+def _i32(a, shape_tail=None):
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+    t = t.to(device="cuda", dtype=torch.int32).contiguous()
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError("index array has shape %s, expected (n,%s)" % (tuple(t.shape), ",".join(map(str, shape_tail))))
+    return t
+
+
+# ------------------------------------------------------------------------------ residual evaluators
+def residual_rigid(x, verts, normals, corr):
+    """FusionDM.computef_lw rows (reference core/fusion_dm.py:285-297) -> CUDA fp64 tensor."""
+    require_gpu()
+    lib = _lib.load()
+    V, Nn, C = _f64(verts, (3,)), _f64(normals, (3,)), _f64(corr, (3,))
+    if not (V.shape[0] == Nn.shape[0] == C.shape[0]):
+        raise ValueError("vertices / normals / correspondences disagree in length")
+    out = torch.empty(V.shape[0], dtype=torch.float64, device="cuda")
+    _lib.check(lib.dfh_residual_rigid(V.data_ptr(), Nn.data_ptr(), C.data_ptr(), V.shape[0], _lib.darr(x, 8),
+                                      out.data_ptr(), current_stream_ptr()), "dfh_residual_rigid")
+    return out
+
+
+def residual_data(node_dq, verts, normals, corr, nbr, node_pos, node_w, lw_dq):
+    """Data rows of Fusion.computef / computef_lw (reference core/fusion.py:444-473)."""
+    require_gpu()
+    lib = _lib.load()
+    V, Nn, C = _f64(verts, (3,)), _f64(normals, (3,)), _f64(corr, (3,))
+    Q, P, Wn = _f64(node_dq, (8,)), _f64(node_pos, (3,)), _f64(node_w, ())
+    nb = _i32(nbr)
+    if nb.dim() != 2 or nb.shape[0] != V.shape[0]:
+        raise ValueError("neighbour table must be (n_vertices, knn)")
+    if not (V.shape[0] == Nn.shape[0] == C.shape[0]):
+        raise ValueError("Please first call setupCorrespondences to compute point to point correspondences "
+                         "between canonical and live frame vertices!")         # core/fusion.py:337-338
+    if int(nb.max()) >= Q.shape[0] or int(nb.min()) < 0:
+        raise ValueError("neighbour table refers to a node that does not exist")
+    out = torch.empty(V.shape[0], dtype=torch.float64, device="cuda")
+    _lib.check(lib.dfh_residual_data(V.data_ptr(), Nn.data_ptr(), C.data_ptr(), nb.data_ptr(), V.shape[0], nb.shape[1],
+                                     Q.data_ptr(), P.data_ptr(), Wn.data_ptr(), Q.shape[0], _lib.darr(lw_dq, 8),
+                                     out.data_ptr(), current_stream_ptr()), "dfh_residual_data")
+    return out
+
+
+def residual_reg(node_dq, node_nbr, node_pos, node_w, rw):
+    """Regularisation rows of Fusion.computef (reference core/fusion.py:475-484), node-major."""
+    require_gpu()
+    lib = _lib.load()
+    Q, P, Wn = _f64(node_dq, (8,)), _f64(node_pos, (3,)), _f64(node_w, ())
+    nb = _i32(node_nbr)
+    if nb.dim() != 2 or nb.shape[0] != Q.shape[0]:
+        raise ValueError("node neighbour table must be (n_nodes, knn)")
+    if int(nb.max()) >= Q.shape[0] or int(nb.min()) < 0:
+        raise ValueError("node neighbour table refers to a node that does not exist")
+    out = torch.empty(Q.shape[0] * nb.shape[1] * 3, dtype=torch.float64, device="cuda")
+    _lib.check(lib.dfh_residual_reg(nb.data_ptr(), Q.shape[0], nb.shape[1], Q.data_ptr(), P.data_ptr(), Wn.data_ptr(),
+                                    float(rw), out.data_ptr(), current_stream_ptr()), "dfh_residual_reg")
+    return out
+
+
+def sample_knn(sample_pos, node_pos, node_w, knn):
+    """(nbr (S,k) int32, weights (S,k) fp64) of arbitrary points: k nearest nodes, nearest first."""
+    require_gpu()
+    lib = _lib.load()
+    Sp, P, Wn = _f64(sample_pos, (3,)), _f64(node_pos, (3,)), _f64(node_w, ())
+    S = Sp.shape[0]
+    nbr = torch.empty((S, knn), dtype=torch.int32, device="cuda")
+    wts = torch.empty((S, knn), dtype=torch.float64, device="cuda")
+    _lib.check(lib.dfh_sample_knn(Sp.data_ptr(), S, P.data_ptr(), Wn.data_ptr(), P.shape[0], int(knn), nbr.data_ptr(),
+                                  wts.data_ptr(), current_stream_ptr()), "dfh_sample_knn")
+    return nbr, wts
+
+
+def solve_rigid_gn(x0, verts, normals, corr, valid=None, iters=10, lm=0.0):
+    """Gauss-Newton on 0.5*|FusionDM.computef_lw(x)|^2 over the 6-DoF left twist of x.
+    Returns (x, [cost before each step])."""
+    require_gpu()
+    lib = _lib.load()
+    V, Nn, C = _f64(verts, (3,)), _f64(normals, (3,)), _f64(corr, (3,))
+    val = None if valid is None else valid.to(device="cuda", dtype=torch.uint8).contiguous()
+    out = torch.empty(44, dtype=torch.float64, device="cuda")
+    x = np.asarray(x0, dtype=np.float64).copy()
+    costs = []
+    from .dq import dq_mul, twist_exp_dq
+    for _ in range(iters):
+        _lib.check(lib.dfh_gn_build_rigid(V.data_ptr(), Nn.data_ptr(), C.data_ptr(), 0 if val is None else val.data_ptr(),
+                                          V.shape[0], _lib.darr(x, 8), out.data_ptr(), current_stream_ptr()),
+                   "dfh_gn_build_rigid")
+        h = out.cpu().numpy()
+        A, g = h[:36].reshape(6, 6), h[36:42]
+        costs.append(float(h[42]))
+        dx = np.linalg.solve(A + lm * np.eye(6), -g)
+        x = dq_mul(twist_exp_dq(dx), x)
+    return x, costs
+
+
+# ------------------------------------------------------------------------------ non-rigid solver
+class WarpSolver:
+    """Gauss-Newton / LM solver for the node dual quaternions.
+
+    set_graph()   node positions, DQs, weights and the node-node table of the regulariser
+    set_samples() canonical sample points + normals; computes (or takes) their k nearest nodes and
+                  static blend weights, sorts the samples by node tuple and builds the 6x6
+                  block pattern of J^T J
+    set_correspondences() / associate_depth()  fixed correspondences or projective association
+    step()        one iteration: build -> PCG -> twist update (asynchronous)
+    """
+
+    def __init__(self, knn=4, pcg_iters=10):
+        require_gpu()
+        self.lib = _lib.load()
+        self.knn = int(knn)
+        self.pcg_iters = int(pcg_iters)
+        self.node_nbr = None
+        self.S = 0
+
+    # -- graph -------------------------------------------------------------------------------
+    def set_graph(self, node_pos, node_dq, node_w, node_nbr=None):
+        self.node_pos = _f64(node_pos, (3,))
+        self.node_dq = _f64(node_dq, (8,)).clone()
+        self.node_w = _f64(node_w, ())
+        self.N = self.node_pos.shape[0]
+        if not (self.node_dq.shape[0] == self.N == self.node_w.shape[0]):
+            raise ValueError("node arrays disagree on the number of nodes")
+        self.node_nbr = None if node_nbr is None else _i32(node_nbr, (self.knn,))
+        self._pattern = None
+
+    # -- samples -----------------------------------------------------------------------------
+    def set_samples(self, pos, nrm, nbr=None, weights=None, sort=True):
+        pos, nrm = _f64(pos, (3,)), _f64(nrm, (3,))
+        if pos.shape[0] != nrm.shape[0]:
+            raise ValueError("sample positions and normals disagree in length")
+        if nbr is None:
+            nbr, weights = sample_knn(pos, self.node_pos, self.node_w, self.knn)
+        else:
+            nbr = _i32(nbr, (self.knn,))
+            if weights is None:
+                d = pos[:, None, :] - self.node_pos[nbr.long()]
+                dist = torch.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2])
+                weights = torch.exp(-1.0 * (dist / (2 * self.node_w[nbr.long()])) ** 2)
+            weights = _f64(weights, (self.knn,))
+        self.order = None
+        if sort and pos.shape[0] > 0:
+            # group samples with the same ordered node tuple: few runs per 256-sample tile
+            _, inv = torch.unique(nbr, dim=0, return_inverse=True)
+            self.order = torch.argsort(inv, stable=True)
+            pos, nrm, nbr, weights = pos[self.order], nrm[self.order], nbr[self.order], weights[self.order]
+        self.spos, self.snrm = pos.contiguous(), nrm.contiguous()
+        self.snbr, self.swts = nbr.contiguous(), weights.contiguous()
+        self.S = pos.shape[0]
+        self.corr = torch.zeros((self.S, 3), dtype=torch.float64, device="cuda")
+        self.valid = torch.zeros(self.S, dtype=torch.uint8, device="cuda")
+        self._pattern = None
+
+    def _build_pattern(self):
+        N, k = self.N, self.knn
+        keys = [torch.arange(N, device="cuda", dtype=torch.int64) * (N + 1)]             # diagonal
+        if self.S > 0:
+            # distinct node tuples only (the pattern is a function of the tuples, not of the samples)
+            tup = torch.unique(self.snbr, dim=0).long()
+            keys.append((tup[:, :, None] * N + tup[:, None, :]).reshape(-1))
+        if self.node_nbr is not None:
+            i = torch.arange(N, device="cuda", dtype=torch.int64)[:, None].expand(N, k)
+            j = self.node_nbr.long()
+            keys += [(i * N + j).reshape(-1), (j * N + i).reshape(-1)]
+        keys = torch.unique(torch.cat(keys))                                               # sorted
+        rows = (keys // N).to(torch.int32)
+        self.col = (keys % N).to(torch.int32).contiguous()
+        self.row_ptr = torch.searchsorted(rows.contiguous(), torch.arange(N + 1, device="cuda", dtype=torch.int32)).to(torch.int32).contiguous()
+        self.B = int(keys.numel())
+        self.vals = torch.empty(self.B * 36, dtype=torch.float64, device="cuda")
+        self.rhs = torch.empty(6 * N, dtype=torch.float64, device="cuda")
+        self.cost_count = torch.zeros(2, dtype=torch.float64, device="cuda")
+        self.dx = torch.empty(6 * N, dtype=torch.float64, device="cuda")
+        nbytes = self.lib.dfh_pcg_workspace_bytes(N, self.pcg_iters)
+        self.pcg_ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device="cuda")
+        self._pattern = True
+
+    # -- correspondences ---------------------------------------------------------------------
+    def set_correspondences(self, corr, valid=None):
+        c = _f64(corr, (3,))
+        if c.shape[0] != self.S:
+            raise ValueError("Please first call setupCorrespondences to compute point to point correspondences "
+                             "between canonical and live frame vertices!")         # core/fusion.py:337-338
+        self.corr = c[self.order].contiguous() if self.order is not None else c
+        if valid is None:
+            self.valid = torch.ones(self.S, dtype=torch.uint8, device="cuda")
+        else:
+            v = valid if isinstance(valid, torch.Tensor) else torch.from_numpy(np.asarray(valid))
+            v = v.to(device="cuda", dtype=torch.uint8)
+            self.valid = v[self.order].contiguous() if self.order is not None else v.contiguous()
+
+    def associate_depth(self, depth, K, Kinv, lw_cam, scale, center, half, lw_dq, max_dist=0.0):
+        """Projective association of the warped samples against a live depth map (CUDA tensor)."""
+        if not (isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dim() == 2 and depth.is_contiguous()):
+            raise ValueError("depth must be a contiguous 2-D CUDA tensor")
+        H, W = depth.shape
+        _lib.check(self.lib.dfh_gn_associate(self.spos.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.S, self.knn,
+                                             self.node_dq.data_ptr(), _lib.darr(lw_dq, 8), depth.data_ptr(), dtype_code(depth),
+                                             int(H), int(W), _lib.darr(K, 9), _lib.darr(Kinv, 9), _lib.darr(lw_cam, 12),
+                                             float(scale), _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half),
+                                             float(max_dist), self.corr.data_ptr(), self.valid.data_ptr(),
+                                             current_stream_ptr()), "dfh_gn_associate")
+
+    # -- iteration ---------------------------------------------------------------------------
+    def build(self, lw_dq, rw):
+        """J^T J (block-sparse), J^T r and the cost 0.5*|computef|^2 at the current node DQs."""
+        if self._pattern is None:
+            self._build_pattern()
+        nn = 0 if (self.node_nbr is None or rw == 0.0) else self.node_nbr.data_ptr()
+        _lib.check(self.lib.dfh_gn_build(self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(),
+                                         self.corr.data_ptr(), self.valid.data_ptr(), self.S, self.knn,
+                                         self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(), nn, self.N,
+                                         _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
+                                         self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(),
+                                         current_stream_ptr()), "dfh_gn_build")
+
+    def solve_linear(self, lm_abs=0.0, lm_rel=0.0):
+        _lib.check(self.lib.dfh_pcg_solve(self.row_ptr.data_ptr(), self.col.data_ptr(), self.vals.data_ptr(), self.rhs.data_ptr(),
+                                          self.N, self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(),
+                                          self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, current_stream_ptr()),
+                   "dfh_pcg_solve")
+
+    def apply(self, step=1.0):
+        _lib.check(self.lib.dfh_apply_twist(self.node_dq.data_ptr(), self.dx.data_ptr(), self.N, float(step),
+                                            current_stream_ptr()), "dfh_apply_twist")
+
+    def step(self, lw_dq, rw, lm_abs=0.0, lm_rel=0.0):
+        """One asynchronous GN iteration (no host synchronisation)."""
+        self.build(lw_dq, rw)
+        self.solve_linear(lm_abs, lm_rel)
+        self.apply()
+
+    def cost(self):
+        """(0.5*|r|^2, valid sample count) of the last build (synchronises)."""
+        h = self.cost_count.cpu().numpy()
+        return float(h[0]), int(h[1])
+
+    def dense_normal_equations(self):
+        """Dense (6N x 6N) copy of the last build, for tests."""
+        N = self.N
+        A = torch.zeros((N, N, 6, 6), dtype=torch.float64, device="cuda")
+        rows = torch.repeat_interleave(torch.arange(N, device="cuda"), (self.row_ptr[1:] - self.row_ptr[:-1]).long())
+        A[rows, self.col.long()] = self.vals.view(self.B, 6, 6)
+        return A.permute(0, 2, 1, 3).reshape(6 * N, 6 * N).cpu().numpy(), self.rhs.cpu().numpy()
+
+    def solve_lm(self, lw_dq, rw, iters=10, lm_abs=1e-6, lm_rel=0.0, adaptive=True):
+        """Levenberg-Marquardt loop.  A step that raises the cost is undone and retried with 10x
+        the damping; an accepted step relaxes the damping by 3x.  Returns the costs
+        [initial, after step 1, ...] (0.5*|computef|^2 over valid rows)."""
+        lam_a, lam_r = float(lm_abs), float(lm_rel)
+        self.build(lw_dq, rw)
+        c_cur, _ = self.cost()
+        costs = [c_cur]
+        for _ in range(iters):
+            saved_dq = self.node_dq.clone()
+            saved_vals, saved_rhs = self.vals.clone(), self.rhs.clone()
+            accepted = False
+            for _attempt in range(8):
+                self.vals.copy_(saved_vals)
+                self.rhs.copy_(saved_rhs)
+                self.solve_linear(lam_a, lam_r)
+                self.apply()
+                self.build(lw_dq, rw)                   # cost at the trial point = next iteration's system
+                c_new, _ = self.cost()
+                if not adaptive or c_new <= c_cur * (1 + 1e-12):
+                    accepted = True
+                    break
+                self.node_dq.copy_(saved_dq)
+                lam_a, lam_r = max(lam_a, 1e-9) * 10.0, max(lam_r, 1e-6) * 10.0
+            if not accepted:
+                self.build(lw_dq, rw)
+                break
+            c_cur = c_new
+            costs.append(c_cur)
+            lam_a, lam_r = lam_a / 3.0, lam_r / 3.0
+        return costs

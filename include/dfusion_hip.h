@@ -100,6 +100,73 @@ int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3
                         int knn, const double lw_dq[8], double tdist, double wmax,
                         void *workspace, size_t workspace_bytes, int rebuild_candidates, void *stream);
 
+/* ---- warp-field solve ------------------------------------------------------------------------------
+ * All arrays device fp64 unless noted; point / normal / node arrays are row-major (n x 3, n x 8).
+ *
+ * A9   FusionDM.computef_lw(x)                                   core/fusion_dm.py:285-297
+ *   out[i] = dqb_warp_normal(x, normals[i]) . (dqb_warp(x, verts[i]) - corr[i])
+ *   (verts/normals already restricted to `_corridx`; row i pairs with corr[i]). */
+int dfh_residual_rigid(const double *verts, const double *normals, const double *corr, int n, const double x[8],
+                       double *out, void *stream);
+
+/* Rigid Gauss-Newton normal equations of 0.5*|computef_lw(x)|^2 for the left twist on x:
+ * out44[0..35] = J^T J (6x6 row-major), out44[36..41] = J^T r, out44[42] = 0.5|r|^2, out44[43] = rows
+ * used.  valid (uint8 per row) may be NULL. */
+int dfh_gn_build_rigid(const double *verts, const double *normals, const double *corr, const unsigned char *valid, int n,
+                       const double x[8], double *out44, void *stream);
+
+/* A10  data rows of Fusion.computef(x, tdw, trw, rw) / Fusion.computef_lw   core/fusion.py:444-473
+ *   (x', n') = warp(verts[s], node_dq[nbr[s]], nbr[s], normals[s], m_lw=lw_dq)   (:502-520)
+ *   out[s] = n' . (x' - corr[s]);  nbr: n_verts x knn int32 (`_neighbor_look_up`, :121-123). */
+int dfh_residual_data(const double *verts, const double *normals, const double *corr, const int *nbr, int n_verts,
+                      int knn, const double *node_dq, const double *node_pos, const double *node_w, int n_nodes,
+                      const double lw_dq[8], double *out, void *stream);
+
+/* A10  regularisation rows of Fusion.computef                      core/fusion.py:475-484
+ *   node_nbr[i][j] = _neighbor_look_up[_nodes[i][0]][j]  (n_nodes x knn int32)
+ *   out[(i*knn + j)*3 + c] = rw * max(w_i, w_j) * (dqb_warp(dq_i, v_j) - dqb_warp(dq_j, v_j))[c]. */
+int dfh_residual_reg(const int *node_nbr, int n_nodes, int knn, const double *node_dq, const double *node_pos,
+                     const double *node_w, double rw, double *out, void *stream);
+
+/* k nearest nodes (nearest first; KDTree.query order, core/fusion.py:121-123) and the Gaussian DQB
+ * weights exp(-(|p - v_j| / (2 w_j))^2) (:537) of arbitrary sample points.  Both are static while the
+ * graph is unchanged.  nbr_out: n_samples x knn int32; weights_out: n_samples x knn. */
+int dfh_sample_knn(const double *sample_pos, int n_samples, const double *node_pos, const double *node_w, int n_nodes,
+                   int knn, int *nbr_out, double *weights_out, void *stream);
+
+/* Projective data association (not in the reference, which matches marching-cubes vertices through a
+ * KD-tree, core/fusion.py:255-276): warp each sample with the current field (Fusion.warp), map index ->
+ * world (pos = scale*(i - half) + center, fusion_dm.py:191) -> camera (lw_cam, :193) -> pixel (:194-195),
+ * take the nearest depth pixel z = -depth[rint(v)][rint(u)] (:196), back-project K^-1 (z [u,v,1])
+ * (:198-200) and map back to index space.  valid_out[s] = 0 when outside the image, no depth, or farther
+ * than max_dist voxels from the warped sample (max_dist <= 0: no gate). */
+int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *weights, int n_samples, int knn,
+                     const double *node_dq, const double lw_dq[8], const void *depth, int depth_dtype, int H, int W,
+                     const double K[9], const double Kinv[9], const double lw_cam[12], double scale,
+                     const double center[3], double half, double max_dist, double *corr_out,
+                     unsigned char *valid_out, void *stream);
+
+/* Gauss-Newton normal equations of 0.5*|computef|^2 in 6-DoF left twists (dq_a <- exp(xi_a) (x) dq_a):
+ * vals (n_blocks x 36, block-sparse rows row_ptr/col with sorted columns) <- J^T J, rhs (6 n_nodes) <-
+ * J^T r, cost_count[0] <- 0.5 |r|^2, cost_count[1] <- number of valid samples.  Data rows use the static
+ * weights of dfh_sample_knn; node_nbr == NULL or rw == 0 skips the regularisation rows.  The block
+ * pattern must contain every node pair of every sample tuple and every (i, j) of node_nbr (both
+ * orders) plus the diagonal; missing blocks are silently dropped. */
+int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                 const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,
+                 const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                 const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                 double *rhs, double *cost_count, void *stream);
+
+/* Block-Jacobi preconditioned CG on (A + lm_abs I + lm_rel diag(A)) x = -rhs, `iters` iterations, no
+ * host synchronisation.  The damping is written into vals' diagonal (vals is consumed). */
+size_t dfh_pcg_workspace_bytes(int n_nodes, int iters);
+int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
+                  double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* node_dq[a] <- exp(step * xi[a]) (x) node_dq[a]; exp = rotation exp(omega), translation v. */
+int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 from numpy import linalg as la
 
-from . import kernels
+from . import kernels, solve as _solve
 from .device import f32_exact, require_gpu, to_device, torch_dtype
 
 
@@ -159,6 +159,36 @@ class FusionDM:
         live = self._live_to_device(curr_tsdf)
         self._ensure_volumes()
         kernels.fuse_volume_rigid(self._T, self._Wt, live, np.asarray(self._lw, dtype=np.float64), self._tdist, wmax)
+
+    # ------------------------------------------------------------------ A9
+    def _corr_state(self):
+        if self._vertices is None or self._normals is None:
+            raise ValueError('canonical vertices / normals have not been set')
+        idx = np.asarray(self._corridx, dtype=np.int64)
+        C = np.asarray(self._correspondences, dtype=np.float64).reshape(-1, 3)
+        if len(idx) != len(C):
+            raise ValueError('_corridx and _correspondences disagree in length')
+        V = np.asarray(self._vertices, dtype=np.float64)[idx]
+        Nn = np.asarray(self._normals, dtype=np.float64)[idx]
+        return V, Nn, C
+
+    def computef_lw(self, x):
+        """Point-to-plane residual of the kept correspondences under the global transform x;
+        reference core/fusion_dm.py:285-297."""
+        V, Nn, C = self._corr_state()
+        return _solve.residual_rigid(x, V, Nn, C).cpu().numpy()
+
+    def solve(self, curr_tsdf=None, iterations=10):
+        """Rigid alignment `_lw` for the current correspondences; call surface of reference
+        core/fusion_dm.py:264-282.  The reference re-extracts correspondences with marching
+        cubes + KD-tree three times around scipy's least_squares; here `_corridx` /
+        `_correspondences` are the caller's (or the projective association's) and `_lw` is
+        found by Gauss-Newton on 0.5*|computef_lw|^2 (6-DoF left twist, HIP kernels)."""
+        self._itercounter += 1
+        V, Nn, C = self._corr_state()
+        x, costs = _solve.solve_rigid_gn(np.asarray(self._lw, dtype=np.float64), V, Nn, C, iters=iterations)
+        self._lw = x
+        self.last_costs = costs
 
     # ------------------------------------------------------------------ driver
     def _auto_alignment(self, depths, lws):

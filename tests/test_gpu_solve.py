@@ -197,3 +197,51 @@ def test_projective_association_vs_oracle():
     sv.associate_depth(torch.from_numpy(dm).cuda(), K, Kinv, lw_cam, scale, center, R / 2, lw, max_dist=3.0)
     gate = vo & (np.linalg.norm(co - warped, axis=1) <= 3.0)
     assert np.array_equal(sv.valid.cpu().numpy().astype(bool), gate)
+
+
+def test_class_surface_matches_reference(golden):
+    """Fusion.computef / computef_lw / warp / dq_blend / solve and FusionDM.computef_lw / solve with
+    the reference's call shapes; values against the reference's golden outputs."""
+    from dynamicfusion_body_amd import Fusion, FusionDM
+    g, verts, norms, corr, nbr, vidx, npos, ndq, nw, lw, rw = load(golden)
+    fu = Fusion(np.zeros((4, 4, 4)), 1.0, knn=nbr.shape[1])
+    fu._nodes = [(int(vidx[i]), npos[i], ndq[i], float(nw[i])) for i in range(len(npos))]
+    fu._vertices, fu._normals, fu._correspondences = verts, norms, corr
+    fu._neighbor_look_up = [row for row in nbr]
+    fu._lw = lw
+    f = fu.computef(ndq.flatten(), 0.2, 0.001, rw)
+    assert f.shape == g["computef_out"].shape and np.abs(f - g["computef_out"]).max() <= 1e-12
+    assert np.abs(fu.computef_lw(g["lw2"], 0.2, 1) - g["computef_lw_out"]).max() <= 1e-12
+    with pytest.raises(ValueError):
+        fu.solve(correspondences=corr[:10])
+    fu._correspondences = corr
+    c0 = 0.5 * float(f @ f)
+    fu.solve(precompute_lw=False, regularization_weight=rw, iterations=5)
+    x = np.concatenate([n[2] for n in fu._nodes])
+    f1 = fu.computef(x, 0.2, 0.001, rw)
+    assert 0.5 * float(f1 @ f1) < 0.5 * c0
+    # single-point helpers against the reference's outputs (golden g4)
+    g4 = golden("g4_dqb")
+    fu2 = Fusion(np.zeros((4, 4, 4)), 1.0, knn=int(g4["knn"]))
+    fu2._nodes = [(0, g4["node_pos"][i], g4["node_dq"][i], float(g4["node_w"][i])) for i in range(len(g4["node_pos"]))]
+    for i in range(6):
+        p, n = g4["warp_P"][i], g4["warp_N"][i]
+        loc = g4["warp_loc"][i]
+        dqs = [fu2._nodes[j][2] for j in loc]
+        assert np.abs(fu2.dq_blend(p, dqs, loc) - g4["blend_out"][i]).max() <= 1e-14
+        a, b = fu2.warp(p, dqs, loc, normal=n, m_lw=g4["lw"])
+        assert np.abs(a - g4["warp_pos_out"][i]).max() <= 1e-12 and np.abs(b - g4["warp_nrm_out"][i]).max() <= 1e-12
+        a2, b2 = fu2.warp(p, normal=n, m_lw=g4["lw"])             # kd-tree form: knn+1 query, last dropped
+        assert np.abs(a2 - a).max() <= 1e-12
+    # FusionDM
+    fd = FusionDM(1.0, np.eye(3), tsdf_res=4)
+    keep = g["rigid_keep"]
+    fd._vertices, fd._normals = verts, norms
+    fd._corridx = list(keep); fd._correspondences = [corr[i] for i in keep]
+    assert np.abs(fd.computef_lw(g["rigid_x"]) - g["rigid_out"]).max() <= 1e-12
+    x_true = G.twist_exp_dq(np.array([0.03, 0.01, -0.04, 0.2, 0.1, -0.3]))
+    fd._correspondences = list(O.dqb_warp(x_true, verts[keep]))
+    fd._lw = np.array([1, 0, 0, 0, 0, 0, 0, 0], dtype=np.float32)
+    fd.solve(None)
+    assert np.abs(O.DQTSE3(fd._lw) - O.DQTSE3(x_true)).max() < 1e-3
+    assert fd.last_costs[-1] < 1e-8

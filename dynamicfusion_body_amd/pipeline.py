@@ -1,0 +1,76 @@
+"""Per-frame orchestration of the hot path: surface samples from the canonical volume, their
+node neighbourhoods, then GN iterations (associate -> build -> all-reduce -> PCG -> update), then
+the TSDF update.  Mirrors the reference's frame loop (test.py:116-131: setupCorrespondences ->
+solve -> updateTSDF) with projective association in place of marching cubes + KD-tree.
+
+`extract_surface_samples` is bookkeeping on torch ops (mask, nonzero, central differences); a
+HIP band-compaction kernel is the first "next" row of SURVEY.md §8(f)."""
+import numpy as np
+import torch
+
+from . import kernels
+from .solve import WarpSolver, sample_knn
+
+
+def extract_surface_samples(T, Wt, band, x0=0, max_samples=None):
+    """Band voxels (w > 0, |T| < band; T in voxel units as fuseDepths stores it) of a slab
+    starting at global plane x0 -> (surface points (S,3) in global index space, unit normals).
+    Normals are central differences of T inside the slab (one-sided at its faces); points are the
+    voxel centres projected onto the zero level set along the normal."""
+    Tf = T.to(torch.float64)
+    mask = (Wt > 0) & (Tf.abs() < band)
+    idx = mask.nonzero(as_tuple=False)
+    if max_samples is not None and idx.shape[0] > max_samples:
+        idx = idx[torch.linspace(0, idx.shape[0] - 1, max_samples, device=idx.device).long()]
+    X, Y, Z = T.shape
+    ix, iy, iz = idx[:, 0], idx[:, 1], idx[:, 2]
+
+    def diff(axis_idx, n, take):
+        lo, hi = (axis_idx - 1).clamp(min=0), (axis_idx + 1).clamp(max=n - 1)
+        return (take(hi) - take(lo)) / (hi - lo).to(torch.float64)
+    gx = diff(ix, X, lambda a: Tf[a, iy, iz])
+    gy = diff(iy, Y, lambda a: Tf[ix, a, iz])
+    gz = diff(iz, Z, lambda a: Tf[ix, iy, a])
+    g = torch.stack([gx, gy, gz], dim=1)
+    nrm = g.norm(dim=1, keepdim=True)
+    ok = nrm[:, 0] > 1e-6
+    idx, g, nrm = idx[ok], g[ok], nrm[ok]
+    n = g / nrm
+    pos = idx.to(torch.float64)
+    pos[:, 0] += x0
+    pos = pos - Tf[idx[:, 0], idx[:, 1], idx[:, 2]][:, None] * n
+    return pos.contiguous(), n.contiguous()
+
+
+class FrameSolver:
+    """Warp-field estimation of one live depth frame against the canonical volume."""
+
+    def __init__(self, K, scale, center, half, knn=4, pcg_iters=10):
+        self.K = np.asarray(K, dtype=np.float64)
+        self.Kinv = np.linalg.inv(self.K)
+        self.scale, self.center, self.half = float(scale), np.asarray(center, dtype=np.float64), float(half)
+        self.solver = WarpSolver(knn=knn, pcg_iters=pcg_iters)
+        self.knn = knn
+        self.lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+
+    def set_graph(self, node_pos, node_dq, node_w):
+        node_nbr, _ = sample_knn(node_pos, node_pos, node_w, self.knn)        # a node's own k nearest nodes
+        self.solver.set_graph(node_pos, node_dq, node_w, node_nbr=node_nbr)
+
+    def set_canonical(self, T, Wt, band=1.0, x0=0, max_samples=None):
+        pos, nrm = extract_surface_samples(T, Wt, band, x0=x0, max_samples=max_samples)
+        self.solver.set_samples(pos, nrm)
+        return pos.shape[0]
+
+    def gn_iteration(self, depth, lw_cam, rw, lm_abs=1e-3, lm_rel=1e-3, max_dist=4.0):
+        """associate -> build (+ all-reduce) -> PCG -> twist update; asynchronous."""
+        sv = self.solver
+        sv.associate_depth(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, max_dist)
+        sv.step(self.lw, rw, lm_abs, lm_rel)
+
+    def solve(self, depth, lw_cam, rw, iters=10, **kw):
+        costs = []
+        for _ in range(iters):
+            self.gn_iteration(depth, lw_cam, rw, **kw)
+            costs.append(self.solver.cost())
+        return costs

@@ -11,7 +11,7 @@ node tuple, unique node pairs); every per-iteration step is a HIP kernel behind 
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, dist as _dist
 from .device import current_stream_ptr, dtype_code, require_gpu
 
 
@@ -187,14 +187,16 @@ class WarpSolver:
             i = torch.arange(N, device="cuda", dtype=torch.int64)[:, None].expand(N, k)
             j = self.node_nbr.long()
             keys += [(i * N + j).reshape(-1), (j * N + i).reshape(-1)]
-        keys = torch.unique(torch.cat(keys))                                               # sorted
+        keys = _dist.union_sorted_keys(torch.cat(keys))          # sorted; identical on every rank
         rows = (keys // N).to(torch.int32)
         self.col = (keys % N).to(torch.int32).contiguous()
         self.row_ptr = torch.searchsorted(rows.contiguous(), torch.arange(N + 1, device="cuda", dtype=torch.int32)).to(torch.int32).contiguous()
         self.B = int(keys.numel())
-        self.vals = torch.empty(self.B * 36, dtype=torch.float64, device="cuda")
-        self.rhs = torch.empty(6 * N, dtype=torch.float64, device="cuda")
-        self.cost_count = torch.zeros(2, dtype=torch.float64, device="cuda")
+        # one flat allocation {J^T J blocks | J^T r | cost, count}: a single all-reduce per iteration
+        self.system = torch.zeros(self.B * 36 + 6 * N + 2, dtype=torch.float64, device="cuda")
+        self.vals = self.system[:self.B * 36]
+        self.rhs = self.system[self.B * 36:self.B * 36 + 6 * N]
+        self.cost_count = self.system[self.B * 36 + 6 * N:]
         self.dx = torch.empty(6 * N, dtype=torch.float64, device="cuda")
         nbytes = self.lib.dfh_pcg_workspace_bytes(N, self.pcg_iters)
         self.pcg_ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device="cuda")
@@ -238,6 +240,7 @@ class WarpSolver:
                                          _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
                                          self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(),
                                          current_stream_ptr()), "dfh_gn_build")
+        _dist.allreduce_system(self.system)       # no-op on one GPU; samples are sharded by slab
 
     def solve_linear(self, lm_abs=0.0, lm_rel=0.0):
         _lib.check(self.lib.dfh_pcg_solve(self.row_ptr.data_ptr(), self.col.data_ptr(), self.vals.data_ptr(), self.rhs.data_ptr(),

@@ -1,0 +1,77 @@
+"""CPU, world_size 2, gloo: the multi-GPU host logic -- slab partition, union of the block
+pattern, single all-reduce of the flat normal-equation buffer, max-over-ranks timing."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dynamicfusion_body_amd import dist as D
+
+
+def test_slab_range_covers_exactly():
+    for n in (1, 7, 64, 256, 513):
+        for ws in (1, 2, 3, 8):
+            cur = 0
+            sizes = []
+            for r in range(ws):
+                a, b = D.slab_range(n, r, ws)
+                assert a == cur and b >= a
+                sizes.append(b - a)
+                cur = b
+            assert cur == n and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        D.slab_range(10, 2, 2)
+    assert D.world() == (0, 1)
+    t = torch.arange(4.0)
+    assert D.allreduce_system(t) is t and D.max_over_ranks([1.0, 2.0]) == [1.0, 2.0]
+    assert torch.equal(D.union_sorted_keys(torch.tensor([5, 1, 5, 3])), torch.tensor([1, 3, 5]))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, ws, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        assert D.world() == (rank, ws)
+        # slabs of a 10-plane grid: each rank contributes the node pairs its own samples touch
+        a, b = D.slab_range(10, rank, ws)
+        keys = torch.tensor([[0, 4, 9], [4, 7, 11, 12]][rank], dtype=torch.int64)
+        u = D.union_sorted_keys(keys)
+        assert torch.equal(u, torch.tensor([0, 4, 7, 9, 11, 12]))
+        # normal equations: partial sums per slab add up to the full system
+        full = torch.arange(20, dtype=torch.float64) * 0.5
+        part = torch.zeros(20, dtype=torch.float64)
+        part[2 * a:2 * b] = full[2 * a:2 * b]
+        D.allreduce_system(part)
+        assert torch.equal(part, full)
+        mx = D.max_over_ranks([float(rank), 1.0 - rank])
+        assert mx == [float(ws - 1), 1.0]
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    ws = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Array("i", [0] * ws)
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, out)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    assert list(out) == [1] * ws

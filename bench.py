@@ -42,7 +42,79 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=RES, help="per-rank slab is res^3 (default = BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gn", action="store_true", help="skip the warp-solve (GN-iters/s) leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                                                      "rehearsing >1 rank on a single GPU)")
+    ap.add_argument("--gn-nodes", type=int, default=512)
+    ap.add_argument("--gn-solves", type=int, default=5, help="timed solves of 10 GN iterations each")
     return ap.parse_args()
+
+
+def gn_leg(args, torch, dist, scene, rank, world, barrier):
+    """BASELINE config 3: 256^3 canonical volume, 512-node warp field, DQB warp + projective data
+    association + 10 GN iterations per solve.  Strong scaling at N > 1: the canonical samples are
+    sharded by axis-0 slab of the SAME grid and the normal equations are all-reduced each iteration."""
+    import time as _t
+    from dynamicfusion_body_amd import kernels
+    from dynamicfusion_body_amd import dist as D
+    from dynamicfusion_body_amd.pipeline import FrameSolver
+    R = args.res
+    H, W, fx, cx, cy = scene.CAMERAS["C2" if R <= 256 else "C5"]
+    K = scene.intrinsics(fx, cx, cy)
+    Kinv = np.linalg.inv(K)
+    scale, center, tdist = scene.grid_params(R)
+    T = torch.full((R, R, R), tdist, dtype=torch.float32, device="cuda")
+    Wt = torch.zeros((R, R, R), dtype=torch.float32, device="cuda")
+    for a in (0.0, 40.0, -40.0):
+        lw = scene.view_extrinsic(a)
+        d = torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda()
+        kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist)
+    N, k, iters = args.gn_nodes, 4, 10
+    fs = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=10)
+    node_pos, node_w = scene.fibonacci_nodes(N, R)
+    ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
+    fs.set_graph(node_pos, ident, node_w)
+    a, b = D.slab_range(R, rank, world)
+    S = fs.set_canonical(T[a:b], Wt[a:b], band=4.0, x0=a)
+    lw_cam = scene.view_extrinsic(0.0)
+    live = scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=np.array([0.6, -0.4, 0.3]) * scale,
+                              sphere_r=scene.SPHERE_R * 1.02)
+    depth = torch.from_numpy(live).cuda()
+    sv = fs.solver
+    ident_t = torch.from_numpy(ident).cuda()
+
+    def one_solve():
+        sv.node_dq.copy_(ident_t)
+        for _ in range(iters):
+            fs.gn_iteration(depth, lw_cam, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0)
+
+    one_solve()                                   # warm-up (also builds the block pattern)
+    c_first = None
+    barrier()
+    t0 = _t.perf_counter()
+    for _ in range(args.gn_solves):
+        one_solve()
+    barrier()
+    dt = _t.perf_counter() - t0
+    dt = D.max_over_ranks([dt])[0]
+    cost, cnt = sv.cost()
+    tot = torch.tensor([float(S)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot)
+    A = int(tot.item())
+    B = sv.B
+    n_it = args.gn_solves * iters
+    # HBM bytes one iteration has to move (fp64 layout of this build): associate reads pos/nbr/wts and
+    # writes corr/valid; build reads pos/nrm/nbr/wts/corr/valid; system + PCG vectors per PCG iteration
+    per_sample = (24 + 4 * k + 8 * k + 24 + 1) + (24 + 24 + 4 * k + 8 * k + 24 + 1)
+    alg = per_sample * A / world + 4 * H * W + 8 * (36 * B + 6 * N) * (2 + sv.pcg_iters) + 64 * N
+    return {"gn_iters_per_s": n_it / dt, "ms_per_gn_iter": dt / n_it * 1e3, "gn_iters_per_solve": iters,
+            "solves_timed": args.gn_solves, "active_samples": A, "nodes": N, "knn": k, "blocks_6x6": B,
+            "pcg_iters": sv.pcg_iters, "scaling": "strong" if world > 1 else "n/a",
+            "final_cost": cost, "valid_samples_rank0": cnt,
+            "hbm_bytes_per_iter_algorithmic": alg, "hbm_GBps_algorithmic": alg / (dt / n_it) / 1e9,
+            "workload": "%d^3 canonical volume, %d-node warp field, DQB warp + projective association + %d GN "
+                        "iterations per solve (fp64), samples sharded by axis-0 slab" % (R, N, iters)}
 
 
 def pmc_traffic(kernel_substr, res):
@@ -77,10 +149,14 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % max(1, torch.cuda.device_count())      # == local_rank on a real node
+    torch.cuda.set_device(dev)
     distributed = world > 1
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
 
     R = args.res
     cam = "C2" if R <= 256 else "C5"
@@ -180,6 +256,10 @@ def main():
         # the bench doubles as a parity spot check: GPU state after warmup+steps of the same
         # 4-view cycle has identical update masks to the oracle after one cycle
         out["cpu_baseline"]["mask_match"] = bool(np.array_equal(Wo > 0, (Wt > 0).cpu().numpy())) if nviews == len(lws) else None
+
+    if not args.no_gn:
+        del T, Wt
+        out["gn"] = gn_leg(args, torch, dist, scene, rank, world, barrier)
 
     if distributed:
         dist.barrier()

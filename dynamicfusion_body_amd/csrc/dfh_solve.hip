@@ -430,22 +430,38 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         for (int j = 0; j < NJ; ++j) sJ[tid * LD + j] = Jrow[j];
         sJ[tid * LD + NJ] = r;
     }
-    __syncthreads();
-    if (tid < tile_n) {
-        bool head = tid == 0;
-        if (!head) {
+    // tiles without a single valid sample contribute nothing
+    const int n_valid = __syncthreads_count(tid < tile_n && valid[s] != 0);
+    if (n_valid == 0) return;
+    if (tid == 0) atomicAdd(cost_count + 1, (double)n_valid);      // valid-sample count
+    // run boundaries: sRun[0..n_runs] are the tile offsets where the node tuple changes
+    __shared__ int sRun[kTile + 1];
+    __shared__ int sNRuns;
+    {
+        bool head = false;
+        if (tid < tile_n) {
+            head = tid == 0;
+            if (!head) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) head = head || (sIdx[tid * K + j] != sIdx[(tid - 1) * K + j]);
+                for (int j = 0; j < K; ++j) head = head || (sIdx[tid * K + j] != sIdx[(tid - 1) * K + j]);
+            }
         }
         sHead[tid] = head ? 1 : 0;
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int t = 0; t < tile_n; ++t) if (sHead[t]) sRun[n++] = t;
+            sRun[n] = tile_n;
+            sNRuns = n;
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    const int n_runs = sNRuns;
     // entries: upper triangle of the NJ x NJ Gram matrix, then NJ entries of J^T r, then cost
     constexpr int NUP = NJ * (NJ + 1) / 2;
     for (int e = tid; e < NUP + NJ + 1; e += 256) {
         int pa, pb;                              // Jacobian columns of this entry (pb == NJ: residual)
         if (e < NUP) {
-            // unrank e -> (pa <= pb)
             int row = 0, rem = e;
             while (rem >= NJ - row) { rem -= NJ - row; ++row; }
             pa = row; pb = row + rem;
@@ -454,36 +470,33 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         } else {
             pa = NJ; pb = NJ;
         }
-        double acc = 0.0;
-        int run_start = 0;
-        for (int t = 0; t <= tile_n; ++t) {
-            if (t == tile_n || (t > 0 && sHead[t])) {
-                // flush run [run_start, t)
-                if (acc != 0.0) {
-                    if (pb == NJ && pa == NJ) {
-                        atomicAdd(cost_count, 0.5 * acc);
-                    } else if (pb == NJ) {
-                        atomicAdd(rhs + 6 * sIdx[run_start * K + pa / 6] + pa % 6, acc);
-                    } else {
-                        const int na = sIdx[run_start * K + pa / 6], nbn = sIdx[run_start * K + pb / 6];
-                        const int ia = pa % 6, ib = pb % 6;
-                        const int blk = find_block(row_ptr, col, na, nbn);
-                        if (blk >= 0) atomicAdd(vals + 36 * (size_t)blk + 6 * ia + ib, acc);
-                        if (!(na == nbn && ia == ib)) {
-                            const int blk2 = na == nbn ? blk : find_block(row_ptr, col, nbn, na);
-                            if (blk2 >= 0) atomicAdd(vals + 36 * (size_t)blk2 + 6 * ib + ia, acc);
-                        }
-                    }
-                }
-                acc = 0.0;
-                run_start = t;
-                if (t == tile_n) break;
+        for (int rn = 0; rn < n_runs; ++rn) {
+            const int t0 = sRun[rn], t1 = sRun[rn + 1];
+            double acc0 = 0.0, acc1 = 0.0;
+            int t = t0;
+            for (; t + 1 < t1; t += 2) {
+                acc0 += sJ[t * LD + pa] * sJ[t * LD + pb];
+                acc1 += sJ[(t + 1) * LD + pa] * sJ[(t + 1) * LD + pb];
             }
-            acc += sJ[t * LD + pa] * sJ[t * LD + pb];
+            if (t < t1) acc0 += sJ[t * LD + pa] * sJ[t * LD + pb];
+            const double acc = acc0 + acc1;
+            if (acc == 0.0) continue;
+            if (pb == NJ && pa == NJ) {
+                atomicAdd(cost_count, 0.5 * acc);
+            } else if (pb == NJ) {
+                atomicAdd(rhs + 6 * sIdx[t0 * K + pa / 6] + pa % 6, acc);
+            } else {
+                const int na = sIdx[t0 * K + pa / 6], nbn = sIdx[t0 * K + pb / 6];
+                const int ia = pa % 6, ib = pb % 6;
+                const int blk = find_block(row_ptr, col, na, nbn);
+                if (blk >= 0) atomicAdd(vals + 36 * (size_t)blk + 6 * ia + ib, acc);
+                if (!(na == nbn && ia == ib)) {
+                    const int blk2 = na == nbn ? blk : find_block(row_ptr, col, nbn, na);
+                    if (blk2 >= 0) atomicAdd(vals + 36 * (size_t)blk2 + 6 * ib + ia, acc);
+                }
+            }
         }
     }
-    // valid-sample count rides in cost_count[1]
-    if (tid < tile_n && valid[s]) atomicAdd(cost_count + 1, 1.0);
 }
 
 // Regularisation rows rho_ij = c_ij (W(q_i,v_j) - W(q_j,v_j)): one thread per (i, slot).
@@ -546,26 +559,54 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
 // Solves (A + lm_abs I + lm_rel diag(A)) x = -rhs with block-Jacobi preconditioning; one thread
 // per node row; scalars live in `scal` (3 doubles per iteration: rz, pAp, rz_next).
 __device__ __forceinline__ void inv6(const double *A, double *Ainv) {
-    // Gauss-Jordan with partial pivoting on a 6x6 SPD-ish block
-    double M[6][12];
+    // A = L L^T (SPD after damping), A^-1 = L^-T L^-1; every loop has compile-time bounds so the
+    // 6x6 arrays live in registers.  A non-positive pivot (rank-deficient block) is replaced by 1:
+    // the preconditioner only has to be SPD, not exact.
+    double L[6][6], Li[6][6];
+#pragma unroll
     for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) { M[i][j] = A[6 * i + j]; M[i][6 + j] = i == j ? 1.0 : 0.0; }
-    for (int c = 0; c < 6; ++c) {
-        int piv = c;
-        double best = fabs(M[c][c]);
-        for (int r = c + 1; r < 6; ++r) if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); piv = r; }
-        if (piv != c) for (int j = 0; j < 12; ++j) { const double t = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = t; }
-        const double d = M[c][c];
-        const double id = d != 0.0 ? 1.0 / d : 0.0;
-        for (int j = 0; j < 12; ++j) M[c][j] *= id;
-        for (int r = 0; r < 6; ++r) {
-            if (r == c) continue;
-            const double f = M[r][c];
-            for (int j = 0; j < 12; ++j) M[r][j] -= f * M[c][j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { L[i][j] = 0.0; Li[i][j] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[6 * j + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= L[j][k] * L[j][k];
+        d = d > 0.0 ? sqrt(d) : 1.0;
+        L[j][j] = d;
+        const double id = 1.0 / d;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i > j) {
+                double v = A[6 * i + j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if (k < j) v -= L[i][k] * L[j][k];
+                L[i][j] = v * id;
+            }
         }
     }
+    // Li = L^-1 (lower triangular), column by column
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i >= c) {
+                double v = i == c ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if (k >= c && k < i) v -= L[i][k] * Li[k][c];
+                Li[i][c] = v / L[i][i];
+            }
+        }
+    }
+#pragma unroll
     for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) Ainv[6 * i + j] = M[i][6 + j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k >= i && k >= j) v += Li[k][i] * Li[k][j];
+            Ainv[6 * i + j] = v;
+        }
 }
 
 struct PcgParams {
@@ -600,24 +641,42 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(const int *__restrict__ r
     atomicAdd(scal + 0, rz);
 }
 
+// One 64-lane wave per node row: lane = (block slot b in 0..9) x (output component i in 0..5);
+// each lane multiplies row i of its block with the 6 entries of p at the block's column node, the
+// ten slots are folded with DPP-free shuffles, lanes 0..5 hold y and lane 0 adds p.Ap once.
 __global__ __launch_bounds__(256) void pcg_spmv_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col,
                                                         const double *__restrict__ vals, int N, const double *__restrict__ pv,
                                                         double *__restrict__ Ap, double *__restrict__ scal) {
-    const int a = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= N) return;
-    double y[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = row_ptr[a]; b < row_ptr[a + 1]; ++b) {
-        const double *B = vals + 36 * (size_t)b;
-        const double *pj = pv + 6 * col[b];
-        for (int i = 0; i < 6; ++i) {
-            double acc = 0.0;
-            for (int j = 0; j < 6; ++j) acc += B[6 * i + j] * pj[j];
-            y[i] += acc;
+    const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63: slot 10 (idle)
+    double acc = 0.0;
+    const int beg = row_ptr[a], end = row_ptr[a + 1];
+    if (slot < 10) {
+        for (int b = beg + slot; b < end; b += 10) {
+            const double *B = vals + 36 * (size_t)b + 6 * i;
+            const double *pj = pv + 6 * col[b];
+            acc += ((B[0] * pj[0] + B[1] * pj[1]) + (B[2] * pj[2] + B[3] * pj[3])) + (B[4] * pj[4] + B[5] * pj[5]);
         }
     }
-    double pAp = 0.0;
-    for (int i = 0; i < 6; ++i) { Ap[6 * a + i] = y[i]; pAp += pv[6 * a + i] * y[i]; }
-    atomicAdd(scal + 1, pAp);
+    // fold slots: lane l accumulates lanes l+6k (k = 1..9)
+    double y = acc;
+#pragma unroll
+    for (int k = 1; k < 10; ++k) {
+        const double o = __shfl(acc, lane + 6 * k, 64);
+        y += (lane + 6 * k < 60) ? o : 0.0;
+    }
+    double contrib = 0.0;
+    if (lane < 6) {
+        Ap[6 * a + lane] = y;
+        contrib = pv[6 * a + lane] * y;
+    }
+    // p.Ap over the 6 components
+    contrib += __shfl_down(contrib, 4, 64);
+    contrib += __shfl_down(contrib, 2, 64);
+    contrib += __shfl_down(contrib, 1, 64);
+    if (lane == 0) atomicAdd(scal + 1, contrib);
 }
 
 __global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double *__restrict__ Minv, double *__restrict__ x,
@@ -858,7 +917,7 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
     hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, pv, scal);
     for (int it = 0; it < iters; ++it) {
         double *sc = scal + 3 * (size_t)it;
-        hipLaunchKernelGGL(pcg_spmv_kernel, grid, block, 0, s, row_ptr, col, vals, n_nodes, pv, Ap, sc);
+        hipLaunchKernelGGL(pcg_spmv_kernel, dim3((n_nodes + 3) / 4), block, 0, s, row_ptr, col, vals, n_nodes, pv, Ap, sc);
         hipLaunchKernelGGL(pcg_update_xr_kernel, grid, block, 0, s, n_nodes, Minv, x_out, r, pv, Ap, z, sc);
         hipLaunchKernelGGL(pcg_update_p_kernel, grid, block, 0, s, n_nodes, pv, z, sc, sc + 3);
     }

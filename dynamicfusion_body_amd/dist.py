@@ -56,7 +56,7 @@ def max_over_ranks(values):
     _, ws = world()
     if ws == 1:
         return list(values)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    dev = "cuda" if (dist.get_backend() == "nccl" and torch.cuda.is_available()) else "cpu"
     t = torch.tensor(list(values), dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t]

@@ -130,11 +130,12 @@ class WarpSolver:
     step()        one iteration: build -> PCG -> twist update (asynchronous)
     """
 
-    def __init__(self, knn=4, pcg_iters=10):
+    def __init__(self, knn=4, pcg_iters=10, distributed=True):
         require_gpu()
         self.lib = _lib.load()
         self.knn = int(knn)
         self.pcg_iters = int(pcg_iters)
+        self.distributed = bool(distributed)      # False: ignore an initialised process group
         self.node_nbr = None
         self.S = 0
 
@@ -187,7 +188,8 @@ class WarpSolver:
             i = torch.arange(N, device="cuda", dtype=torch.int64)[:, None].expand(N, k)
             j = self.node_nbr.long()
             keys += [(i * N + j).reshape(-1), (j * N + i).reshape(-1)]
-        keys = _dist.union_sorted_keys(torch.cat(keys))          # sorted; identical on every rank
+        keys = torch.cat(keys)
+        keys = _dist.union_sorted_keys(keys) if self.distributed else torch.unique(keys)   # sorted; same on every rank
         rows = (keys // N).to(torch.int32)
         self.col = (keys % N).to(torch.int32).contiguous()
         self.row_ptr = torch.searchsorted(rows.contiguous(), torch.arange(N + 1, device="cuda", dtype=torch.int32)).to(torch.int32).contiguous()
@@ -233,14 +235,18 @@ class WarpSolver:
         """J^T J (block-sparse), J^T r and the cost 0.5*|computef|^2 at the current node DQs."""
         if self._pattern is None:
             self._build_pattern()
-        nn = 0 if (self.node_nbr is None or rw == 0.0) else self.node_nbr.data_ptr()
+        # data rows are sharded with the samples; the regularisation rows (one per node pair) are
+        # not, so exactly one rank adds them before the all-reduce
+        reg_here = (not self.distributed) or _dist.world()[0] == 0
+        nn = 0 if (self.node_nbr is None or rw == 0.0 or not reg_here) else self.node_nbr.data_ptr()
         _lib.check(self.lib.dfh_gn_build(self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(),
                                          self.corr.data_ptr(), self.valid.data_ptr(), self.S, self.knn,
                                          self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(), nn, self.N,
                                          _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
                                          self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(),
                                          current_stream_ptr()), "dfh_gn_build")
-        _dist.allreduce_system(self.system)       # no-op on one GPU; samples are sharded by slab
+        if self.distributed:
+            _dist.allreduce_system(self.system)   # no-op on one GPU; samples are sharded by slab
 
     def solve_linear(self, lm_abs=0.0, lm_rel=0.0):
         _lib.check(self.lib.dfh_pcg_solve(self.row_ptr.data_ptr(), self.col.data_ptr(), self.vals.data_ptr(), self.rhs.data_ptr(),

@@ -1,0 +1,107 @@
+"""GPU, 2 ranks sharing cuda:0 over gloo (RCCL refuses two ranks on one device; the collective
+semantics are the same): canonical samples sharded by axis-0 slab, block pattern unioned, normal
+equations all-reduced every GN iteration.  Must reproduce the non-distributed solver run over the
+union of the same samples: identical pattern, system to 1e-12 relative, identical iterates."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, ws, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from dynamicfusion_body_amd import FusionDM, scene, kernels
+        from dynamicfusion_body_amd import dist as D
+        from dynamicfusion_body_amd.pipeline import FrameSolver, extract_surface_samples
+        from dynamicfusion_body_amd.solve import WarpSolver
+        torch.cuda.set_device(0)
+        R, N, k = 64, 40, 4
+        H, W, fx, cx, cy = scene.CAMERAS["C1"]
+        K = scene.intrinsics(fx, cx, cy); Kinv = np.linalg.inv(K)
+        scale, center, tdist = scene.grid_params(R)
+        a, b = D.slab_range(R, rank, ws)
+        # TSDF integration needs no exchange: every rank sweeps only its own slab
+        T = torch.full((b - a, R, R), tdist, dtype=torch.float32, device="cuda"); Wt = torch.zeros_like(T)
+        Tf = torch.full((R, R, R), tdist, dtype=torch.float32, device="cuda"); Wf = torch.zeros_like(Tf)
+        for ang in (0.0, 40.0, -40.0):
+            lw = scene.view_extrinsic(ang)
+            d = torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda()
+            kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist, tsdf_res=R, res=(R, R, R), x_range=(a, b))
+            kernels.integrate_depth(Tf, Wf, d, K, Kinv, lw, scale, center, tdist)
+        assert torch.equal(T, Tf[a:b]) and torch.equal(Wt, Wf[a:b])
+        node_pos, node_w = scene.fibonacci_nodes(N, R)
+        ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
+        fs = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=300)
+        fs.set_graph(node_pos, ident, node_w)
+        S = fs.set_canonical(T, Wt, band=2.0, x0=a)
+        lw_cam = scene.view_extrinsic(0.0)
+        live = scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=np.array([0.6, -0.4, 0.3]) * scale,
+                                  sphere_r=scene.SPHERE_R * 1.02)
+        depth = torch.from_numpy(live).cuda()
+        # reference: every rank also solves the union of all slabs' samples without collectives
+        pos, nrm = extract_surface_samples(T, Wt, 2.0, x0=a)
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(ws)]
+        dist.all_gather(sizes, torch.tensor([pos.shape[0]], dtype=torch.int64))
+        m = int(max(int(s_) for s_ in sizes))
+        buf = torch.zeros((m, 6), dtype=torch.float64)
+        buf[:pos.shape[0], :3] = pos.cpu(); buf[:pos.shape[0], 3:] = nrm.cpu()
+        parts = [torch.zeros_like(buf) for _ in range(ws)]
+        dist.all_gather(parts, buf)
+        allp = torch.cat([p_[:int(n_)] for p_, n_ in zip(parts, sizes)]).cuda()
+        ref = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=300)
+        ref.solver = WarpSolver(knn=k, pcg_iters=300, distributed=False)
+        ref.set_graph(node_pos, ident, node_w)
+        ref.solver.set_samples(allp[:, :3].contiguous(), allp[:, 3:].contiguous())
+        assert ref.solver.S == sum(int(s_) for s_ in sizes) and S == int(sizes[rank])
+        for it in range(3):
+            fs.gn_iteration(depth, lw_cam, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0)
+            ref.gn_iteration(depth, lw_cam, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0)
+            if it == 0:
+                assert torch.equal(fs.solver.row_ptr, ref.solver.row_ptr) and torch.equal(fs.solver.col, ref.solver.col)
+            c1, n1 = fs.solver.cost(); c2, n2 = ref.solver.cost()
+            dv = float((fs.solver.vals - ref.solver.vals).abs().max() / ref.solver.vals.abs().max())
+            dr = float((fs.solver.rhs - ref.solver.rhs).abs().max() / ref.solver.rhs.abs().max())
+            dx = float((fs.solver.dx - ref.solver.dx).abs().max() / ref.solver.dx.abs().max())
+            dq = float((fs.solver.node_dq - ref.solver.node_dq).abs().max())
+            if it == 0:
+                # same iterate on both sides: the system agrees to summation order
+                assert n1 == n2 and n1 > 100, (n1, n2)
+                assert abs(c1 - c2) <= 1e-11 * c2 and dv <= 1e-10 and dr <= 1e-10, (c1, c2, dv, dr)
+            # 300 PCG iterations on 240 unknowns: converged, so the step is a well-defined function of the
+            # system and the iterates stay together (a truncated PCG amplifies summation-order noise)
+            assert dx <= 1e-6 and dq <= 1e-7, (it, dx, dq)
+            assert abs(c1 - c2) <= 1e-7 * c2 and abs(n1 - n2) <= 1, (it, c1, c2, n1, n2)
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_single_process():
+    ws = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Array("i", [0] * ws)
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, out)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs)
+    assert list(out) == [1] * ws

@@ -125,7 +125,10 @@ __device__ __forceinline__ void pack_coords(const IntegrateParams &p, int &y, in
 }
 
 // fp32 volumes: filtered fast path with exact fallback (see file header).
-template <typename DepthT, int VEC, bool PINHOLE>
+// STRIDED: the 4 voxels of a lane are z, z+64, z+128, z+192 of its wave's 256-voxel run instead of
+// 4 consecutive ones, so that in every depth gather and every T/w access consecutive lanes touch
+// consecutive voxels (a gather instruction then spans ~6-12 cache lines instead of ~50).
+template <typename DepthT, int VEC, bool PINHOLE, bool STRIDED>
 __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict__ tsdf,
                                                                float *__restrict__ tsdf_w,
                                                                const DepthT *__restrict__ depth,
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
     int y, zp;
     pack_coords(p, y, zp);
     if (y >= p.Y) return;
-    const int z0 = zp * VEC;
+    const int lane = threadIdx.x & 63;
+    const int z0 = STRIDED ? (zp - lane) * VEC + lane : zp * VEC;
+    constexpr int ZS = STRIDED ? 64 : 1;                 // z step between a lane's voxels
     constexpr int NC = PINHOLE ? 3 : 4;
     const unsigned ulim = (unsigned)(p.W - 1) << kFixShift;
     const unsigned vlim = (unsigned)(p.H - 1) << kFixShift;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
     }
     // p2 is affine in z: if both ends of the pack are well away from the camera plane and on
     // the same side, so is everything between; otherwise the whole pack goes the exact way.
-    const double p2_last = __builtin_fma(p.Az[2], (double)(VEC - 1), base[2]);
+    const double p2_last = __builtin_fma(p.Az[2], (double)((VEC - 1) * ZS), base[2]);
     const bool pack_singular = !((fabs(base[2]) > 1e-6) & (fabs(p2_last) > 1e-6) & ((base[2] > 0.0) == (p2_last > 0.0)));
 
     // phase 1: project the z-pack; frustum membership and pixel in 2^-20 px fixed point
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
     bool inside[VEC], amb[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const double jf = (double)j;
+        const double jf = (double)(j * ZS);
         const double p0 = __builtin_fma(p.Az[0], jf, base[0]);      // 2^20 * p0
         const double p1 = __builtin_fma(p.Az[1], jf, base[1]);      // 2^20 * p1
         const double p2 = __builtin_fma(p.Az[2], jf, base[2]);
@@ -204,13 +209,13 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
         float m = p.ts_f;
         if (__builtin_expect(redo, 0)) {
             double sd;
-            ok = exact_voxel_rare<DepthT, PINHOLE>(p, depth, x, y, z0 + j, sd);
+            ok = exact_voxel_rare<DepthT, PINHOLE>(p, depth, x, y, z0 + j * ZS, sd);
             m = (float)((sd < p.tdist ? sd : p.tdist) * p.inv_scale);
         } else if (ok & !freespace) {
             double cz = -(double)dval[j];
             if (!PINHOLE) {
                 // u, v to ~1e-12 px from the folded map; only the value depends on them here
-                const double jf = (double)j;
+                const double jf = (double)(j * ZS);
                 const double r = rcp_nr1(__builtin_fma(p.Az[2], jf, base[2])) * (1.0 / (double)kFixOne);
                 const double u = __builtin_fma(p.Az[0], jf, base[0]) * r;
                 const double v = __builtin_fma(p.Az[1], jf, base[1]) * r;
@@ -220,11 +225,11 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
             if (!PINHOLE) {
                 const double margin = sd + p.tdist;
                 ok = margin > 0.0;
-                if (fabs(margin) < 1e-7) ok = exact_voxel_rare<DepthT, PINHOLE>(p, depth, x, y, z0 + j, cz);
+                if (fabs(margin) < 1e-7) ok = exact_voxel_rare<DepthT, PINHOLE>(p, depth, x, y, z0 + j * ZS, cz);
             }
             m = (float)((sd < p.tdist ? sd : p.tdist) * p.inv_scale);
         }
-        ok = ok & (z0 + j < p.Z);
+        ok = ok & (z0 + j * ZS < p.Z);
         ms[j] = m;
         upd[j] = ok;
         any = any | ok;
@@ -233,8 +238,14 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
 
     const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
     using P = Pack<float, VEC>;
-    P t = *reinterpret_cast<const P *>(tsdf + off);
-    P w = *reinterpret_cast<const P *>(tsdf_w + off);
+    P t, w;
+    if (STRIDED) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { t.v[j] = tsdf[off + j * ZS]; w.v[j] = tsdf_w[off + j * ZS]; }
+    } else {
+        t = *reinterpret_cast<const P *>(tsdf + off);
+        w = *reinterpret_cast<const P *>(tsdf_w + off);
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         // T <- (T*w + m/scale)/(1+w);  w <- min(1+w, wmax)          (fusion_dm.py:209-210)
@@ -247,8 +258,15 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
         t.v[j] = upd[j] ? q : t.v[j];
         w.v[j] = upd[j] ? fminf(d, p.wmax_f) : wt;
     }
-    *reinterpret_cast<P *>(tsdf + off) = t;
-    *reinterpret_cast<P *>(tsdf_w + off) = w;
+    if (STRIDED) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (upd[j]) { tsdf[off + j * ZS] = t.v[j]; tsdf_w[off + j * ZS] = w.v[j]; }
+        }
+    } else {
+        *reinterpret_cast<P *>(tsdf + off) = t;
+        *reinterpret_cast<P *>(tsdf_w + off) = w;
+    }
   }
 }
 
@@ -307,11 +325,23 @@ static int launch_integrate(void *tsdf, void *tsdf_w, const void *depth, Integra
     dim3 grid(gx, gy);
     dim3 block(256);
     if constexpr (FAST) {
-        if (pinhole) {
-            hipLaunchKernelGGL((integrate_depth_kernel<DepthT, VEC, true>), grid, block, 0, stream,
+        // strided lanes need whole 256-voxel runs per wave: 64 packs of one row
+        const bool strided = VEC == 4 && p.zpacks % 64 == 0 && getenv("DFH_STRIDED");   // opt-in: measured no faster
+        if (strided) {
+            if constexpr (VEC == 4) {
+                if (pinhole) {
+                    hipLaunchKernelGGL((integrate_depth_kernel<DepthT, 4, true, true>), grid, block, 0, stream,
+                                       (float *)tsdf, (float *)tsdf_w, (const DepthT *)depth, p);
+                } else {
+                    hipLaunchKernelGGL((integrate_depth_kernel<DepthT, 4, false, true>), grid, block, 0, stream,
+                                       (float *)tsdf, (float *)tsdf_w, (const DepthT *)depth, p);
+                }
+            }
+        } else if (pinhole) {
+            hipLaunchKernelGGL((integrate_depth_kernel<DepthT, VEC, true, false>), grid, block, 0, stream,
                                (float *)tsdf, (float *)tsdf_w, (const DepthT *)depth, p);
         } else {
-            hipLaunchKernelGGL((integrate_depth_kernel<DepthT, VEC, false>), grid, block, 0, stream,
+            hipLaunchKernelGGL((integrate_depth_kernel<DepthT, VEC, false, false>), grid, block, 0, stream,
                                (float *)tsdf, (float *)tsdf_w, (const DepthT *)depth, p);
         }
     } else {
@@ -381,7 +411,8 @@ extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, cons
     const bool pinhole = K[1] == 0.0 && K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0 && K[8] == 1.0 &&
                          Kinv[6] == 0.0 && Kinv[7] == 0.0 && Kinv[8] == 1.0;
     const size_t esz = vol_dtype == DFH_F32 ? 4 : 8;
-    const bool vec4 = (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) && ((uintptr_t)tsdf_w % (4 * esz) == 0);
+    const bool vec4 = (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) && ((uintptr_t)tsdf_w % (4 * esz) == 0) &&
+                      !getenv("DFH_FORCE_SCALAR");
     p.zpacks = vec4 ? res[2] / 4 : res[2];
     p.zp_shift = -1;
     for (int b = 0; b < 31; ++b) if (p.zpacks == (1 << b)) p.zp_shift = b;

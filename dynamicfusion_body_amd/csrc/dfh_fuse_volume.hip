@@ -8,6 +8,8 @@
 // once to the volume dtype.
 #include "dfh_dq.h"
 
+#include <cstdlib>
+
 namespace dfh {
 
 template <typename T, int N>
@@ -75,6 +77,135 @@ __global__ __launch_bounds__(256) void fuse_volume_rigid_kernel(VolT *__restrict
     }
     *reinterpret_cast<P *>(tsdf + off) = t;
     *reinterpret_cast<P *>(tsdf_w + off) = w;
+}
+
+// K2 fast path for fp32 volumes.  A rigid dual quaternion acts on a point as an affine map
+// q = M i + t (M = |r|^2 R(r), t = 2 vec(d r*), folded on the host in fp64), so the per-voxel DQ
+// chain collapses to three FMAs per voxel; the trilinear blend uses FMA lerps.  The two decisions
+// (inside the live volume, s > -tdist) are guarded: within 1e-9 of a boundary the voxel is
+// re-evaluated with the exact chain, so the masks are those of the fp64 path.
+struct RigidFastParams {
+    double M[9], t[3];
+};
+
+template <typename LiveT>
+__device__ __forceinline__ double sample_fast(const LiveT *__restrict__ vol, int RY, int RZ, double px, double py, double pz) {
+    const double fx = floor(px), fy = floor(py), fz = floor(pz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const int x1 = (int)ceil(px), y1 = (int)ceil(py), z1 = (int)ceil(pz);
+    const double xd = px - fx, yd = py - fy, zd = pz - fz;
+    const size_t sx = (size_t)RY * RZ, sy = (size_t)RZ;
+    const double c000 = (double)vol[x0 * sx + y0 * sy + z0], c100 = (double)vol[x1 * sx + y0 * sy + z0];
+    const double c001 = (double)vol[x0 * sx + y1 * sy + z0], c101 = (double)vol[x1 * sx + y1 * sy + z0];
+    const double c010 = (double)vol[x0 * sx + y0 * sy + z1], c110 = (double)vol[x1 * sx + y0 * sy + z1];
+    const double c011 = (double)vol[x0 * sx + y1 * sy + z1], c111 = (double)vol[x1 * sx + y1 * sy + z1];
+    const double c00 = __builtin_fma(xd, c100 - c000, c000), c01 = __builtin_fma(xd, c101 - c001, c001);
+    const double c10 = __builtin_fma(xd, c110 - c010, c010), c11 = __builtin_fma(xd, c111 - c011, c011);
+    const double c0 = __builtin_fma(yd, c10 - c00, c00);          // y fraction blends the z1 samples (util.py:135)
+    const double c1 = __builtin_fma(yd, c11 - c01, c01);
+    return __builtin_fma(zd, c1 - c0, c0);                        // z fraction blends the y1 samples (util.py:137)
+}
+
+// STRIDED: a lane's 4 voxels are z, z+64, z+128, z+192 of its wave's 256-voxel run, so that in every
+// one of the 32 corner gathers (and the T/w accesses) consecutive lanes touch consecutive voxels.
+template <typename LiveT, bool STRIDED>
+__global__ __launch_bounds__(256) void fuse_volume_rigid_fast_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                      const LiveT *__restrict__ live, const RigidParams p,
+                                                                      const RigidFastParams f) {
+    constexpr int VEC = 4;
+    int y, zp;
+    pack_coords2(p.zpacks, p.zp_shift, y, zp);
+    if (y >= p.Y) return;
+    const int xl = blockIdx.y;
+    const int x = p.x0 + xl;
+    const int lane = threadIdx.x & 63;
+    const int z0 = STRIDED ? (zp - lane) * VEC + lane : zp * VEC;
+    constexpr int ZS = STRIDED ? 64 : 1;
+    const double xf = (double)x, yf = (double)y, zf = (double)z0;
+    double q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        q[r] = __builtin_fma(f.M[3 * r + 2], zf, __builtin_fma(f.M[3 * r + 1], yf, __builtin_fma(f.M[3 * r], xf, f.t[r])));
+    const double hx = (double)(p.LX - 1), hy = (double)(p.LY - 1), hz = (double)(p.LZ - 1);
+    const float tdf = (float)p.tdist;
+    float mv[VEC];
+    bool upd[VEC];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const double jf = (double)(j * ZS);
+        const double qx = __builtin_fma(f.M[2], jf, q[0]), qy = __builtin_fma(f.M[5], jf, q[1]), qz = __builtin_fma(f.M[8], jf, q[2]);
+        const double lo = fmin(fmin(qx, qy), qz);
+        const double hi = fmin(fmin(hx - qx, hy - qy), hz - qz);
+        const double edge = fmin(fabs(lo), fabs(hi));              // distance to the nearest face of [0,R-1]^3 (or worse)
+        bool ok = (lo >= 0.0) & (hi >= 0.0);
+        bool redo = !(fmin(fmin(fabs(qx), fabs(qy)), fabs(qz)) > 1e-9) | !(fmin(fmin(fabs(hx - qx), fabs(hy - qy)), fabs(hz - qz)) > 1e-9);
+        (void)edge;
+        double sv = 0.0;
+        if (ok) {
+            sv = sample_fast(live, p.LY, p.LZ, qx, qy, qz);
+            const double margin = sv + p.tdist;
+            ok = margin > 0.0;
+            redo = redo | !(fabs(margin) > 1e-9 * (1.0 + fabs(sv)));
+        }
+        if (__builtin_expect(redo, 0)) {
+            int xx = x, yy = y, zz = z0 + j * ZS;
+            asm volatile("" : "+v"(xx), "+v"(yy), "+v"(zz));       // keep the exact chain out of the hot path
+            const D3 e = dqb_warp_exact(p.lw.q, (double)xx, (double)yy, (double)zz);
+            ok = interpolate_exact(live, p.LX, p.LY, p.LZ, e.x, e.y, e.z, sv) && (sv > -1.0 * p.tdist);
+        }
+        ok = ok & (z0 + j * ZS < p.Z);
+        mv[j] = (float)(sv < p.tdist ? sv : p.tdist);
+        upd[j] = ok;
+        any = any | ok;
+    }
+    (void)tdf;
+    if (!any) return;
+    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
+    using P = VPack<float, VEC>;
+    P t, w;
+    if (STRIDED) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { t.v[j] = tsdf[off + j * ZS]; w.v[j] = tsdf_w[off + j * ZS]; }
+    } else {
+        t = *reinterpret_cast<const P *>(tsdf + off);
+        w = *reinterpret_cast<const P *>(tsdf_w + off);
+    }
+    const float wmaxf = (float)p.wmax;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float wt = w.v[j];
+        const float d = wt + 1.0f;
+        const float n = fmaf(t.v[j], wt, mv[j]);                   // (T*w + min(tdist,s)) / (1 + w)
+        const float r = __builtin_amdgcn_rcpf(d);
+        float qn = n * r;
+        qn = fmaf(fmaf(-d, qn, n), r, qn);
+        t.v[j] = upd[j] ? qn : t.v[j];
+        w.v[j] = upd[j] ? fminf(d, wmaxf) : wt;
+    }
+    if (STRIDED) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (upd[j]) { tsdf[off + j * ZS] = t.v[j]; tsdf_w[off + j * ZS] = w.v[j]; }
+        }
+    } else {
+        *reinterpret_cast<P *>(tsdf + off) = t;
+        *reinterpret_cast<P *>(tsdf_w + off) = w;
+    }
+}
+
+// |r|^2 R(r) and 2 vec(d r*) of a (possibly non-unit) dual quaternion, host fp64
+static void fold_rigid(const double *q, RigidFastParams &f) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    // r P r* for pure P: rows of the (unnormalised) rotation matrix
+    f.M[0] = w * w + x * x - y * y - z * z; f.M[1] = 2 * (x * y - w * z);           f.M[2] = 2 * (x * z + w * y);
+    f.M[3] = 2 * (x * y + w * z);           f.M[4] = w * w - x * x + y * y - z * z; f.M[5] = 2 * (y * z - w * x);
+    f.M[6] = 2 * (x * z - w * y);           f.M[7] = 2 * (y * z + w * x);           f.M[8] = w * w - x * x - y * y + z * z;
+    const double d0 = q[4], d1 = q[5], d2 = q[6], d3 = q[7];
+    // d (x) r* , vector part, times 2
+    f.t[0] = 2 * (-d0 * x + d1 * w - d2 * z + d3 * y);
+    f.t[1] = 2 * (-d0 * y + d1 * z + d2 * w - d3 * x);
+    f.t[2] = 2 * (-d0 * z - d1 * y + d2 * x + d3 * w);
 }
 
 template <typename VolT, typename LiveT>
@@ -323,6 +454,22 @@ extern "C" int dfh_fuse_volume_rigid(void *tsdf, void *tsdf_w, int vol_dtype, co
     const size_t esz = vol_dtype == DFH_F32 ? 4 : 8;
     const bool vec4 = (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) && ((uintptr_t)tsdf_w % (4 * esz) == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vol_dtype == DFH_F32 && vec4 && !getenv("DFH_K2_EXACT")) {
+        RigidFastParams f;
+        fold_rigid(lw_dq, f);
+        p.zpacks = p.Z / 4;
+        p.zp_shift = -1;
+        for (int b = 0; b < 31; ++b) if (p.zpacks == (1 << b)) p.zp_shift = b;
+        dim3 grid((unsigned)(((long)p.Y * p.zpacks + 255) / 256), (unsigned)p.nx), block(256);
+        const bool strided = p.zpacks % 64 == 0 && !getenv("DFH_NO_STRIDED");
+#define DFH_K2(LT, ST) hipLaunchKernelGGL((fuse_volume_rigid_fast_kernel<LT, ST>), grid, block, 0, s, (float *)tsdf, \
+                                          (float *)tsdf_w, (const LT *)live, p, f)
+        if (live_dtype == DFH_F32) { if (strided) DFH_K2(float, true); else DFH_K2(float, false); }
+        else { if (strided) DFH_K2(double, true); else DFH_K2(double, false); }
+#undef DFH_K2
+        DFH_HIP_CHECK(hipGetLastError());
+        return DFH_OK;
+    }
     if (vol_dtype == DFH_F32) {
         if (live_dtype == DFH_F32) return launch_rigid<float, float>(tsdf, tsdf_w, live, p, vec4, s);
         return launch_rigid<float, double>(tsdf, tsdf_w, live, p, vec4, s);

@@ -239,23 +239,35 @@ def main():
         out["roofline"]["traffic_source"] = "profiles/" + tr[1]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle_np as O           # checker timed as the CPU baseline, never the product
+        # checker timed as the CPU baseline, never the product: the C restatement (OpenMP, all host
+        # threads) and, for reference, the single-threaded numpy restatement
+        from oracle import oracle_c as OC
+        from oracle import oracle_np as O
+        OC.build()
+        nthr = OC.threads()
         To = np.zeros((R, R, R)) + tdist
         Wo = np.zeros((R, R, R))
-        nviews = len(lws) if R <= 256 else 1
+        cycles = 5 if R <= 256 else 1
         t0 = time.perf_counter()
-        for v in range(nviews):
-            O.fuse_depths(depths_np[v], lws[v], K, Kinv, To, Wo, tdist, tsdf_res=tsdf_res, scale=scale,
-                          center=center, wmax=100.0)
+        for _ in range(cycles):
+            for v in range(len(lws)):
+                OC.fuse_depths(depths_np[v], lws[v], K, Kinv, To, Wo, tdist, tsdf_res=tsdf_res, scale=scale,
+                               center=center, wmax=100.0, n_threads=nthr)
         cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": R ** 3 * nviews / cdt / 1e6, "unit": "Mvoxels/s", "cores": 1,
+        Tn = np.zeros((R, R, R)) + tdist
+        Wn = np.zeros((R, R, R))
+        t0 = time.perf_counter()
+        O.fuse_depths(depths_np[0], lws[0], K, Kinv, Tn, Wn, tdist, tsdf_res=tsdf_res, scale=scale, center=center, wmax=100.0)
+        ndt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": R ** 3 * cycles * len(lws) / cdt / 1e6, "unit": "Mvoxels/s", "cores": nthr,
                                "kind": "port",
-                               "sample": "%d full %d^3 sweeps (views %s) with the vectorised fp64 numpy oracle, "
-                                         "single thread; the reference's interpreter loop itself: 0.0835 Mvox/s"
-                                         % (nviews, R, list(VIEW_ANGLES[:nviews]))}
-        # the bench doubles as a parity spot check: GPU state after warmup+steps of the same
-        # 4-view cycle has identical update masks to the oracle after one cycle
-        out["cpu_baseline"]["mask_match"] = bool(np.array_equal(Wo > 0, (Wt > 0).cpu().numpy())) if nviews == len(lws) else None
+                               "sample": "%d sweeps of %d^3 (the %d bench views x %d) with oracle/oracle_c.c, the C "
+                                         "restatement of fuseDepths' CPU path (OpenMP, %d threads, fp64); numpy "
+                                         "restatement on 1 core: %.1f Mvox/s; the reference's interpreter loop itself: "
+                                         "0.0835 Mvox/s (BASELINE.md)" % (cycles * len(lws), R, len(lws), cycles, nthr,
+                                                                          R ** 3 / ndt / 1e6),
+                               # parity spot check: same update mask as the GPU volume after the same views
+                               "mask_match": bool(np.array_equal(Wo > 0, (Wt > 0).cpu().numpy()))}
 
     if not args.no_gn:
         del T, Wt

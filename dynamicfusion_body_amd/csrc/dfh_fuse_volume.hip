@@ -230,7 +230,7 @@ static int launch_rigid(void *tsdf, void *tsdf_w, const void *live, RigidParams 
 // K3: node search + DQ blending
 // ------------------------------------------------------------------------------------------
 constexpr int kBX = 4, kBY = 4, kBZ = 16;      // brick = one 256-thread block, z fastest (64-B rows)
-constexpr int kCap = 64;                        // candidate nodes kept per brick
+constexpr int kCap = 128;                       // candidate nodes kept per brick
 constexpr int kKMax = 8;                        // knn <= 8
 // half diagonal of the voxel-centre span of a brick
 #define DFH_BRICK_RADIUS 7.7942286340599480     /* sqrt(1.5^2 + 1.5^2 + 7.5^2) */
@@ -245,10 +245,11 @@ struct DqbParams {
     int nbx, nby, nbz;      // bricks per axis (over the slab)
 };
 
-// sorted (ascending, stable) insertion into an 8-slot list held in registers
-__device__ __forceinline__ void top8_insert(double (&bd)[kKMax], int (&bi)[kKMax], double d2, int idx) {
+// sorted (ascending, stable) insertion into a KS-slot list held in registers
+template <int KS>
+__device__ __forceinline__ void topk_insert(double (&bd)[KS], int (&bi)[KS], double d2, int idx) {
 #pragma unroll
-    for (int i = 0; i < kKMax; ++i) {
+    for (int i = 0; i < KS; ++i) {
         const bool lt = d2 < bd[i];
         const double td = bd[i];
         const int ti = bi[i];
@@ -259,16 +260,18 @@ __device__ __forceinline__ void top8_insert(double (&bd)[kKMax], int (&bi)[kKMax
     }
 }
 
-__device__ __forceinline__ double select_k(const double (&bd)[kKMax], int k) {
+template <int KS>
+__device__ __forceinline__ double select_k(const double (&bd)[KS], int k) {
     double r = bd[0];
 #pragma unroll
-    for (int i = 1; i < kKMax; ++i) r = (k - 1 == i) ? bd[i] : r;
+    for (int i = 1; i < KS; ++i) r = (k - 1 == i) ? bd[i] : r;
     return r;
 }
 
 // Per brick: the nodes that can be among the k nearest of ANY voxel centre p of the brick.
-// With c the brick centre and r its radius: D_k(p) <= d_k(c) + r, hence every such node q has
-// |q - c| <= d_k(c) + 2r.  cand[brick*(kCap+1)] = count (or -1: too many -> scan all nodes).
+// With c the brick centre and r its radius, D_k(p) <= d_k(c) + r for every p in the brick, so a
+// node q can only matter if its distance to the brick's box of voxel centres is <= d_k(c) + r.
+// cand[brick*(kCap+1)] = count (or -1: too many -> scan all nodes).
 __global__ __launch_bounds__(256) void dqb_candidates_kernel(const double *__restrict__ node_pos, int *__restrict__ cand,
                                                               const DqbParams p) {
     const long brick = (long)blockIdx.x * 256 + threadIdx.x;
@@ -277,9 +280,9 @@ __global__ __launch_bounds__(256) void dqb_candidates_kernel(const double *__res
     const int bz = (int)(brick % p.nbz);
     const int by = (int)((brick / p.nbz) % p.nby);
     const int bx = (int)(brick / ((long)p.nbz * p.nby));
-    const double cx = (double)(p.x0 + bx * kBX) + 0.5 * (kBX - 1);
-    const double cy = (double)(by * kBY) + 0.5 * (kBY - 1);
-    const double cz = (double)(bz * kBZ) + 0.5 * (kBZ - 1);
+    const double lx = (double)(p.x0 + bx * kBX), ly = (double)(by * kBY), lz = (double)(bz * kBZ);   // box of voxel centres
+    const double hx = lx + (kBX - 1), hy = ly + (kBY - 1), hz = lz + (kBZ - 1);
+    const double cx = 0.5 * (lx + hx), cy = 0.5 * (ly + hy), cz = 0.5 * (lz + hz);
     double bd[kKMax];
     int bi[kKMax];
 #pragma unroll
@@ -287,14 +290,15 @@ __global__ __launch_bounds__(256) void dqb_candidates_kernel(const double *__res
     for (int n = 0; n < p.N; ++n) {
         const double dx = cx - node_pos[3 * n], dy = cy - node_pos[3 * n + 1], dz = cz - node_pos[3 * n + 2];
         const double d2 = (dx * dx + dy * dy) + dz * dz;
-        if (d2 < bd[kKMax - 1]) top8_insert(bd, bi, d2, n);
+        if (d2 < bd[kKMax - 1]) topk_insert<kKMax>(bd, bi, d2, n);
     }
-    const double R = sqrt(select_k(bd, p.k)) + 2.0 * DFH_BRICK_RADIUS + 1e-6;
+    const double R = sqrt(select_k<kKMax>(bd, p.k)) + DFH_BRICK_RADIUS + 1e-6;
     const double R2 = R * R;
     int *c = cand + brick * (kCap + 1);
     int cnt = 0;
     for (int n = 0; n < p.N; ++n) {
-        const double dx = cx - node_pos[3 * n], dy = cy - node_pos[3 * n + 1], dz = cz - node_pos[3 * n + 2];
+        const double qx = node_pos[3 * n], qy = node_pos[3 * n + 1], qz = node_pos[3 * n + 2];
+        const double dx = fmax(fmax(lx - qx, qx - hx), 0.0), dy = fmax(fmax(ly - qy, qy - hy), 0.0), dz = fmax(fmax(lz - qz, qz - hz), 0.0);
         const double d2 = (dx * dx + dy * dy) + dz * dz;
         if (d2 <= R2) {
             if (cnt < kCap) c[1 + cnt] = n;
@@ -307,15 +311,16 @@ __global__ __launch_bounds__(256) void dqb_candidates_kernel(const double *__res
 // k nearest nodes of `pos` (ascending distance, ties by node index = stable argsort of the
 // squared distances; what KDTree.query(pos, k+1)[1][:-1] yields, core/fusion.py:175-176).
 // All 256 threads of the block must call this (LDS staging + barriers).
+template <int KS>
 __device__ __forceinline__ void block_knn(const double *__restrict__ node_pos, const int *__restrict__ c, int N,
                                           double px, double py, double pz, bool active,
-                                          double (&bd)[kKMax], int (&bi)[kKMax]) {
+                                          double (&bd)[KS], int (&bi)[KS]) {
     __shared__ double spos[kCap * 3];
     __shared__ int sidx[kCap];
     const int cnt = c[0];
     const int total = cnt >= 0 ? cnt : N;
 #pragma unroll
-    for (int i = 0; i < kKMax; ++i) { bd[i] = __builtin_huge_val(); bi[i] = -1; }
+    for (int i = 0; i < KS; ++i) { bd[i] = __builtin_huge_val(); bi[i] = -1; }
     for (int base = 0; base < total; base += kCap) {
         const int n = min(kCap, total - base);
         if ((int)threadIdx.x < n) {
@@ -330,7 +335,7 @@ __device__ __forceinline__ void block_knn(const double *__restrict__ node_pos, c
             for (int i = 0; i < n; ++i) {
                 const double dx = px - spos[3 * i], dy = py - spos[3 * i + 1], dz = pz - spos[3 * i + 2];
                 const double d2 = (dx * dx + dy * dy) + dz * dz;
-                if (d2 < bd[kKMax - 1]) top8_insert(bd, bi, d2, sidx[i]);
+                if (d2 < bd[KS - 1]) topk_insert<KS>(bd, bi, d2, sidx[i]);
             }
         }
         __syncthreads();
@@ -340,14 +345,15 @@ __device__ __forceinline__ void block_knn(const double *__restrict__ node_pos, c
 // Fusion.dq_blend + warp (core/fusion.py:502-551) for one point whose k nearest nodes are
 // (bd, bi).  Returns the point warped by the blended DQ and then by m_lw (x1 is re-rounded to
 // float32 inside the second dqb_warp, core/util.py:69); *wi_out = mean node distance (:180-183).
+template <int KS>
 __device__ __forceinline__ D3 dqb_blend_warp(const double *__restrict__ node_dq, const double *__restrict__ node_w,
-                                             const double (&bd)[kKMax], const int (&bi)[kKMax], int k,
+                                             const double (&bd)[KS], const int (&bi)[KS], int k,
                                              const double *lw, double px, double py, double pz, double *wi_out,
                                              double *blended /* 8, optional */) {
     double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double wi = 0.0;
 #pragma unroll
-    for (int j = 0; j < kKMax; ++j) {
+    for (int j = 0; j < KS; ++j) {
         if (j < k) {
             const int gi = bi[j];
             const double dist = sqrt(bd[j]);
@@ -367,8 +373,9 @@ __device__ __forceinline__ D3 dqb_blend_warp(const double *__restrict__ node_dq,
 #pragma unroll
         for (int c = 1; c < 8; ++c) b[c] = 0.0;
     } else {
+        const double inv = 1.0 / n;                  // one division; each component within 1 ulp of b/n
 #pragma unroll
-        for (int c = 0; c < 8; ++c) b[c] = b[c] / n;
+        for (int c = 0; c < 8; ++c) b[c] = b[c] * inv;
     }
     if (blended) {
 #pragma unroll
@@ -379,7 +386,7 @@ __device__ __forceinline__ D3 dqb_blend_warp(const double *__restrict__ node_dq,
     return dqb_warp_exact(lw, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));   // :512
 }
 
-template <typename VolT, typename LiveT>
+template <typename VolT, typename LiveT, int KS>
 __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__ tsdf, VolT *__restrict__ tsdf_w,
                                                                const LiveT *__restrict__ live,
                                                                const double *__restrict__ node_pos,
@@ -396,12 +403,12 @@ __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__
     const int xl = bx * kBX + lx, y = by * kBY + ly, z = bz * kBZ + lz;
     const bool inb = (xl < p.nx) && (y < p.Y) && (z < p.Z);
     const double px = (double)(p.x0 + xl), py = (double)y, pz = (double)z;
-    double bd[kKMax];
-    int bi[kKMax];
-    block_knn(node_pos, cand + brick * (kCap + 1), p.N, px, py, pz, inb, bd, bi);
+    double bd[KS];
+    int bi[KS];
+    block_knn<KS>(node_pos, cand + brick * (kCap + 1), p.N, px, py, pz, inb, bd, bi);
     if (!inb) return;
     double wi;
-    const D3 q = dqb_blend_warp(node_dq, node_w, bd, bi, p.k, p.lw.q, px, py, pz, &wi, nullptr);   // fusion.py:178
+    const D3 q = dqb_blend_warp<KS>(node_dq, node_w, bd, bi, p.k, p.lw.q, px, py, pz, &wi, nullptr);   // fusion.py:178
     double s;
     if (!interpolate_exact(live, p.LX, p.LY, p.LZ, q.x, q.y, q.z, s)) return;
     if (!(s > -1.0 * p.tdist)) return;                                                              // :179
@@ -418,8 +425,13 @@ template <typename VolT, typename LiveT>
 static int launch_dqb(void *tsdf, void *tsdf_w, const void *live, const double *node_pos, const double *node_dq,
                       const double *node_w, int *cand, const DqbParams &p, hipStream_t s) {
     const long nbricks = (long)p.nbx * p.nby * p.nbz;
-    hipLaunchKernelGGL((fuse_volume_dqb_kernel<VolT, LiveT>), dim3((unsigned)nbricks), dim3(256), 0, s, (VolT *)tsdf,
-                       (VolT *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, p);
+    if (p.k <= 4) {                                   // 4 register slots suffice: half the insertion work
+        hipLaunchKernelGGL((fuse_volume_dqb_kernel<VolT, LiveT, 4>), dim3((unsigned)nbricks), dim3(256), 0, s, (VolT *)tsdf,
+                           (VolT *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, p);
+    } else {
+        hipLaunchKernelGGL((fuse_volume_dqb_kernel<VolT, LiveT, kKMax>), dim3((unsigned)nbricks), dim3(256), 0, s, (VolT *)tsdf,
+                           (VolT *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, p);
+    }
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }

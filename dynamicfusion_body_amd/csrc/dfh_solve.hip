@@ -175,7 +175,6 @@ __global__ __launch_bounds__(256) void gn_build_rigid_kernel(const double *__res
 }
 
 // ------------------------------------------------------------------------------- sample setup
-constexpr int kSBX = 4, kSBY = 4, kSBZ = 16, kSCap = 64;     // must match dfh_fuse_volume.hip bricks
 
 __device__ __forceinline__ void top8_insert_s(double (&bd)[kKMaxS], int (&bi)[kKMaxS], double d2, int idx) {
 #pragma unroll

@@ -89,13 +89,39 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
             fs.gn_iteration(depth, lw_cam, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0)
 
     one_solve()                                   # warm-up (also builds the block pattern)
-    c_first = None
     barrier()
+    # eager: every kernel launched from Python through the C ABI
     t0 = _t.perf_counter()
     for _ in range(args.gn_solves):
         one_solve()
+    t_issue = _t.perf_counter() - t0              # host time to enqueue (no sync yet)
     barrier()
-    dt = _t.perf_counter() - t0
+    dt_eager = _t.perf_counter() - t0
+    launch = "eager"
+    dt = dt_eager
+    # one solve captured as a HIP graph and replayed (single GPU only: no collective inside a capture)
+    if world == 1 and not os.environ.get("DFH_NO_GRAPH"):
+        try:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                one_solve()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=side):
+                    one_solve()
+            torch.cuda.current_stream().wait_stream(side)
+            g.replay()
+            barrier()
+            t0 = _t.perf_counter()
+            for _ in range(args.gn_solves):
+                g.replay()
+            barrier()
+            dt_graph = _t.perf_counter() - t0
+            if dt_graph < dt_eager:
+                dt, launch = dt_graph, "hipGraph replay of one 10-iteration solve"
+        except Exception as e:                    # capture is an optimisation; eager numbers stay valid
+            launch = "eager (graph capture failed: %s)" % str(e)[:80]
     dt = D.max_over_ranks([dt])[0]
     cost, cnt = sv.cost()
     tot = torch.tensor([float(S)], dtype=torch.float64, device="cuda")
@@ -110,7 +136,8 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
     alg = per_sample * A / world + 4 * H * W + 8 * (36 * B + 6 * N) * (2 + sv.pcg_iters) + 64 * N
     return {"gn_iters_per_s": n_it / dt, "ms_per_gn_iter": dt / n_it * 1e3, "gn_iters_per_solve": iters,
             "solves_timed": args.gn_solves, "active_samples": A, "nodes": N, "knn": k, "blocks_6x6": B,
-            "pcg_iters": sv.pcg_iters, "scaling": "strong" if world > 1 else "n/a",
+            "pcg_iters": sv.pcg_iters, "scaling": "strong" if world > 1 else "n/a", "launch": launch,
+            "eager_ms_per_gn_iter": dt_eager / n_it * 1e3, "host_issue_ms_per_gn_iter": t_issue / n_it * 1e3,
             "final_cost": cost, "valid_samples_rank0": cnt,
             "hbm_bytes_per_iter_algorithmic": alg, "hbm_GBps_algorithmic": alg / (dt / n_it) / 1e9,
             "workload": "%d^3 canonical volume, %d-node warp field, DQB warp + projective association + %d GN "

@@ -404,41 +404,44 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     const int tid = threadIdx.x;
     const int s = blockIdx.x * kTile + tid;
     const int tile_n = min(kTile, p.S - blockIdx.x * kTile);
-    double r = 0.0;
-    {
+    // ---- each valid sample computes its residual and Jacobian row and appends it to the tile's
+    // compacted list in LDS (order preserved): the reduction below only walks valid rows
+    const bool act = tid < tile_n && valid[s] != 0;
+    __shared__ int sWaveCnt[4];
+    const unsigned long long bal = __ballot(act);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) sWaveCnt[wv] = __popcll(bal);
+    __syncthreads();
+    int pos = __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w_ = 0; w_ < wv; ++w_) pos += sWaveCnt[w_];
+    const int n_valid = sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
+    if (n_valid == 0) return;                                        // tiles without a valid sample contribute nothing
+    if (tid == 0) atomicAdd(cost_count + 1, (double)n_valid);        // valid-sample count
+    if (act) {
         double Jrow[NJ];
         int idx[kKMaxS];
         double w[kKMaxS];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) Jrow[j] = 0.0;
-        if (tid < tile_n) {
-#pragma unroll
-            for (int j = 0; j < kKMaxS; ++j) {
-                idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
-                w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
-            }
-            if (valid[s]) {
-                r = data_row(node_dq, idx, w, K, p.lw.q, spos[3 * (size_t)s], spos[3 * (size_t)s + 1], spos[3 * (size_t)s + 2],
-                             snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], corr[3 * (size_t)s],
-                             corr[3 * (size_t)s + 1], corr[3 * (size_t)s + 2], Jrow);
-            }
-#pragma unroll
-            for (int j = 0; j < K; ++j) sIdx[tid * K + j] = idx[j];
+        for (int j = 0; j < kKMaxS; ++j) {
+            idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
+            w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
         }
+        const double r = data_row(node_dq, idx, w, K, p.lw.q, spos[3 * (size_t)s], spos[3 * (size_t)s + 1], spos[3 * (size_t)s + 2],
+                                  snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], corr[3 * (size_t)s],
+                                  corr[3 * (size_t)s + 1], corr[3 * (size_t)s + 2], Jrow);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) sJ[tid * LD + j] = Jrow[j];
-        sJ[tid * LD + NJ] = r;
+        for (int j = 0; j < K; ++j) sIdx[pos * K + j] = idx[j];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) sJ[pos * LD + j] = Jrow[j];
+        sJ[pos * LD + NJ] = r;
     }
-    // tiles without a single valid sample contribute nothing
-    const int n_valid = __syncthreads_count(tid < tile_n && valid[s] != 0);
-    if (n_valid == 0) return;
-    if (tid == 0) atomicAdd(cost_count + 1, (double)n_valid);      // valid-sample count
-    // run boundaries: sRun[0..n_runs] are the tile offsets where the node tuple changes
+    __syncthreads();
+    // run boundaries: sRun[0..n_runs] are the offsets in the compacted list where the node tuple changes
     __shared__ int sRun[kTile + 1];
     __shared__ int sNRuns;
     {
         bool head = false;
-        if (tid < tile_n) {
+        if (tid < n_valid) {
             head = tid == 0;
             if (!head) {
 #pragma unroll
@@ -449,13 +452,24 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         __syncthreads();
         if (tid == 0) {
             int n = 0;
-            for (int t = 0; t < tile_n; ++t) if (sHead[t]) sRun[n++] = t;
-            sRun[n] = tile_n;
+            for (int t = 0; t < n_valid; ++t) if (sHead[t]) sRun[n++] = t;
+            sRun[n] = n_valid;
             sNRuns = n;
         }
         __syncthreads();
     }
     const int n_runs = sNRuns;
+    // block index of every (slot a, slot b) node pair of every run, searched once, in parallel
+    constexpr bool kBlkTable = K <= 4;                     // 256 runs x K^2 ints must fit next to sJ
+    __shared__ int sBlk[kBlkTable ? kTile * K * K : 1];
+    if (kBlkTable) {
+        for (int q = tid; q < n_runs * K * K; q += 256) {
+            const int rn = q / (K * K), pr = q - rn * (K * K);
+            const int t0 = sRun[rn];
+            sBlk[q] = find_block(row_ptr, col, sIdx[t0 * K + pr / K], sIdx[t0 * K + pr % K]);
+        }
+        __syncthreads();
+    }
     // entries: upper triangle of the NJ x NJ Gram matrix, then NJ entries of J^T r, then cost
     constexpr int NUP = NJ * (NJ + 1) / 2;
     for (int e = tid; e < NUP + NJ + 1; e += 256) {
@@ -485,12 +499,13 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
             } else if (pb == NJ) {
                 atomicAdd(rhs + 6 * sIdx[t0 * K + pa / 6] + pa % 6, acc);
             } else {
-                const int na = sIdx[t0 * K + pa / 6], nbn = sIdx[t0 * K + pb / 6];
+                const int sa = pa / 6, sb = pb / 6;
+                const int na = sIdx[t0 * K + sa], nbn = sIdx[t0 * K + sb];
                 const int ia = pa % 6, ib = pb % 6;
-                const int blk = find_block(row_ptr, col, na, nbn);
+                const int blk = kBlkTable ? sBlk[rn * K * K + sa * K + sb] : find_block(row_ptr, col, na, nbn);
                 if (blk >= 0) atomicAdd(vals + 36 * (size_t)blk + 6 * ia + ib, acc);
                 if (!(na == nbn && ia == ib)) {
-                    const int blk2 = na == nbn ? blk : find_block(row_ptr, col, nbn, na);
+                    const int blk2 = na == nbn ? blk : (kBlkTable ? sBlk[rn * K * K + sb * K + sa] : find_block(row_ptr, col, nbn, na));
                     if (blk2 >= 0) atomicAdd(vals + 36 * (size_t)blk2 + 6 * ib + ia, acc);
                 }
             }
@@ -498,7 +513,9 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     }
 }
 
-// Regularisation rows rho_ij = c_ij (W(q_i,v_j) - W(q_j,v_j)): one thread per (i, slot).
+// Regularisation rows rho_ij = c_ij (W(q_i,v_j) - W(q_j,v_j)): one WAVE per (i, slot); lanes 0..35
+// own one entry (a,b) of the four 6x6 blocks (ii, jj, ij, ji), lanes 0..5 also the gradient, so the
+// ~150 fp64 atomics of a pair are issued side by side instead of one after the other.
 __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict__ node_nbr, int N, int k,
                                                             const double *__restrict__ node_dq,
                                                             const double *__restrict__ node_pos,
@@ -506,7 +523,8 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
                                                             const int *__restrict__ row_ptr, const int *__restrict__ col,
                                                             double *__restrict__ vals, double *__restrict__ rhs,
                                                             double *__restrict__ cost_count) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (t >= N * k) return;
     const int i = t / k;
     const int j = node_nbr[t];
@@ -520,38 +538,36 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
     const double rho[3] = {c * (yi.x - yj.x), c * (yi.y - yj.y), c * (yi.z - yj.z)};
     const double si = (qi[0] * qi[0] + qi[1] * qi[1]) + (qi[2] * qi[2] + qi[3] * qi[3]);
     const double sj = (qj[0] * qj[0] + qj[1] * qj[1]) + (qj[2] * qj[2] + qj[3] * qj[3]);
-    // J_i = c [ -[y_i]x | s_i I ],  J_j = -c [ -[y_j]x | s_j I ]   (3 x 6 each)
-    double Ji[3][6], Jj[3][6];
-    const double yiv[3] = {yi.x, yi.y, yi.z}, yjv[3] = {yj.x, yj.y, yj.z};
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 6; ++b) { Ji[a][b] = 0.0; Jj[a][b] = 0.0; }
-    // -[y]x = [[0, y2, -y1], [-y2, 0, y0], [y1, -y0, 0]]
-    Ji[0][1] = c * yiv[2];  Ji[0][2] = -c * yiv[1]; Ji[1][0] = -c * yiv[2]; Ji[1][2] = c * yiv[0];
-    Ji[2][0] = c * yiv[1];  Ji[2][1] = -c * yiv[0];
-    Jj[0][1] = -c * yjv[2]; Jj[0][2] = c * yjv[1];  Jj[1][0] = c * yjv[2];  Jj[1][2] = -c * yjv[0];
-    Jj[2][0] = -c * yjv[1]; Jj[2][1] = c * yjv[0];
-    for (int a = 0; a < 3; ++a) { Ji[a][3 + a] = c * si; Jj[a][3 + a] = -c * sj; }
-    const int bii = find_block(row_ptr, col, i, i), bjj = find_block(row_ptr, col, j, j);
-    const int bij = find_block(row_ptr, col, i, j), bji = find_block(row_ptr, col, j, i);
-    for (int a = 0; a < 6; ++a) {
-        double gi = 0.0, gj = 0.0;
-        for (int m = 0; m < 3; ++m) { gi += Ji[m][a] * rho[m]; gj += Jj[m][a] * rho[m]; }
-        atomicAdd(rhs + 6 * i + a, gi);
-        atomicAdd(rhs + 6 * j + a, gj);
-        for (int b = 0; b < 6; ++b) {
-            double vii = 0.0, vjj = 0.0, vij = 0.0;
-            for (int m = 0; m < 3; ++m) {
-                vii += Ji[m][a] * Ji[m][b];
-                vjj += Jj[m][a] * Jj[m][b];
-                vij += Ji[m][a] * Jj[m][b];
-            }
-            if (bii >= 0 && vii != 0.0) atomicAdd(vals + 36 * (size_t)bii + 6 * a + b, vii);
-            if (bjj >= 0 && vjj != 0.0) atomicAdd(vals + 36 * (size_t)bjj + 6 * a + b, vjj);
-            if (bij >= 0 && vij != 0.0) atomicAdd(vals + 36 * (size_t)bij + 6 * a + b, vij);
-            if (bji >= 0 && vij != 0.0) atomicAdd(vals + 36 * (size_t)bji + 6 * b + a, vij);
+    // J_i = c [ -[y_i]x | s_i I ],  J_j = -c [ -[y_j]x | s_j I ]   (3 x 6 each), column `col6` on demand
+    auto Jcol = [&](const D3 &y, double sgn, double sc, int col6, double (&out)[3]) {
+        // -[y]x = [[0, y2, -y1], [-y2, 0, y0], [y1, -y0, 0]]
+        const double m[3][3] = {{0.0, y.z, -y.y}, {-y.z, 0.0, y.x}, {y.y, -y.x, 0.0}};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) out[r] = col6 < 3 ? sgn * c * m[r][col6 % 3] : (r == col6 - 3 ? sgn * c * sc : 0.0);
+    };
+    if (lane < 36) {
+        const int a = lane / 6, b = lane - 6 * a;
+        double ia[3], ib[3], ja[3], jb[3];
+        Jcol(yi, 1.0, si, a, ia); Jcol(yi, 1.0, si, b, ib);
+        Jcol(yj, -1.0, sj, a, ja); Jcol(yj, -1.0, sj, b, jb);
+        const double vii = (ia[0] * ib[0] + ia[1] * ib[1]) + ia[2] * ib[2];
+        const double vjj = (ja[0] * jb[0] + ja[1] * jb[1]) + ja[2] * jb[2];
+        const double vij = (ia[0] * jb[0] + ia[1] * jb[1]) + ia[2] * jb[2];
+        const double vji = (ja[0] * ib[0] + ja[1] * ib[1]) + ja[2] * ib[2];
+        const int bii = find_block(row_ptr, col, i, i), bjj = find_block(row_ptr, col, j, j);
+        const int bij = find_block(row_ptr, col, i, j), bji = find_block(row_ptr, col, j, i);
+        if (bii >= 0 && vii != 0.0) atomicAdd(vals + 36 * (size_t)bii + lane, vii);
+        if (bjj >= 0 && vjj != 0.0) atomicAdd(vals + 36 * (size_t)bjj + lane, vjj);
+        if (bij >= 0 && vij != 0.0) atomicAdd(vals + 36 * (size_t)bij + lane, vij);
+        if (bji >= 0 && vji != 0.0) atomicAdd(vals + 36 * (size_t)bji + lane, vji);
+        if (lane < 6) {
+            double gi[3], gj[3];
+            Jcol(yi, 1.0, si, lane, gi); Jcol(yj, -1.0, sj, lane, gj);
+            atomicAdd(rhs + 6 * i + lane, (gi[0] * rho[0] + gi[1] * rho[1]) + gi[2] * rho[2]);
+            atomicAdd(rhs + 6 * j + lane, (gj[0] * rho[0] + gj[1] * rho[1]) + gj[2] * rho[2]);
         }
+        if (lane == 0) atomicAdd(cost_count, 0.5 * ((rho[0] * rho[0] + rho[1] * rho[1]) + rho[2] * rho[2]));
     }
-    atomicAdd(cost_count, 0.5 * ((rho[0] * rho[0] + rho[1] * rho[1]) + rho[2] * rho[2]));
 }
 
 // ------------------------------------------------------------------------------- PCG
@@ -634,7 +650,7 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(const int *__restrict__ r
         double z = 0.0;
         for (int j = 0; j < 6; ++j) z += Di[6 * i + j] * rl[j];
         zl[i] = z;
-        pv[6 * a + i] = z;
+        pv[6 * a + i] = z;                 // z0; the first SpMV takes p = z (beta = 0)
         rz += rl[i] * z;
     }
     atomicAdd(scal + 0, rz);
@@ -642,12 +658,24 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(const int *__restrict__ r
 
 // One 64-lane wave per node row: lane = (block slot b in 0..9) x (output component i in 0..5);
 // each lane multiplies row i of its block with the 6 entries of p at the block's column node, the
-// ten slots are folded with DPP-free shuffles, lanes 0..5 hold y and lane 0 adds p.Ap once.
+// ten slots are folded with shuffles, lanes 0..5 hold y and lane 0 adds p.Ap once.
+// The direction update p = z + beta p is folded in: every row forms its neighbours' new p on the
+// fly from (z, p_prev, beta) and publishes its own new p in p_cur (ping-pong), so CG needs two
+// launches per iteration.  scal_prev = {rz, pAp, rz_next} of the previous iteration (NULL: beta = 0).
 __global__ __launch_bounds__(256) void pcg_spmv_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col,
-                                                        const double *__restrict__ vals, int N, const double *__restrict__ pv,
-                                                        double *__restrict__ Ap, double *__restrict__ scal) {
+                                                        const double *__restrict__ vals, int N, const double *__restrict__ z,
+                                                        const double *__restrict__ p_prev, double *__restrict__ p_cur,
+                                                        double *__restrict__ Ap, const double *__restrict__ scal_prev,
+                                                        double *__restrict__ scal) {
     const int lane = threadIdx.x & 63;
     const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    double beta = 0.0, rz_now = 0.0;
+    if (scal_prev) {
+        const double rz = scal_prev[0];
+        rz_now = scal_prev[2];
+        beta = rz != 0.0 ? rz_now / rz : 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = rz_now;      // rz of this iteration for update_xr
+    }
     if (a >= N) return;
     const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63: slot 10 (idle)
     double acc = 0.0;
@@ -655,11 +683,13 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(const int *__restrict__ r
     if (slot < 10) {
         for (int b = beg + slot; b < end; b += 10) {
             const double *B = vals + 36 * (size_t)b + 6 * i;
-            const double *pj = pv + 6 * col[b];
-            acc += ((B[0] * pj[0] + B[1] * pj[1]) + (B[2] * pj[2] + B[3] * pj[3])) + (B[4] * pj[4] + B[5] * pj[5]);
+            const double *zj = z + 6 * col[b];
+            const double *pj = p_prev + 6 * col[b];
+            const double q0 = zj[0] + beta * pj[0], q1 = zj[1] + beta * pj[1], q2 = zj[2] + beta * pj[2];
+            const double q3 = zj[3] + beta * pj[3], q4 = zj[4] + beta * pj[4], q5 = zj[5] + beta * pj[5];
+            acc += ((B[0] * q0 + B[1] * q1) + (B[2] * q2 + B[3] * q3)) + (B[4] * q4 + B[5] * q5);
         }
     }
-    // fold slots: lane l accumulates lanes l+6k (k = 1..9)
     double y = acc;
 #pragma unroll
     for (int k = 1; k < 10; ++k) {
@@ -668,50 +698,48 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(const int *__restrict__ r
     }
     double contrib = 0.0;
     if (lane < 6) {
+        const double pn = z[6 * a + lane] + beta * p_prev[6 * a + lane];
+        p_cur[6 * a + lane] = pn;
         Ap[6 * a + lane] = y;
-        contrib = pv[6 * a + lane] * y;
+        contrib = pn * y;
     }
-    // p.Ap over the 6 components
     contrib += __shfl_down(contrib, 4, 64);
     contrib += __shfl_down(contrib, 2, 64);
     contrib += __shfl_down(contrib, 1, 64);
     if (lane == 0) atomicAdd(scal + 1, contrib);
 }
 
+// x += alpha p, r -= alpha Ap, z = Minv r, rz_next += r.z : one thread per unknown (6 per node; the
+// node's six new residual entries are exchanged with shuffles inside the 6-lane group).
 __global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double *__restrict__ Minv, double *__restrict__ x,
                                                              double *__restrict__ r, const double *__restrict__ pv,
                                                              const double *__restrict__ Ap, double *__restrict__ z,
                                                              double *__restrict__ scal) {
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= N) return;
+    // 60 of the 64 lanes of a wave are used: 10 nodes per wave, 40 per block
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / 6, i = lane - 6 * grp;
+    const int a = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 10 + grp;
+    const bool act = grp < 10 && a < N;
     const double rz = scal[0], pAp = scal[1];
     const double alpha = pAp != 0.0 ? rz / pAp : 0.0;
-    double rl[6];
-    for (int i = 0; i < 6; ++i) {
-        x[6 * a + i] += alpha * pv[6 * a + i];
-        rl[i] = r[6 * a + i] - alpha * Ap[6 * a + i];
-        r[6 * a + i] = rl[i];
+    double rn = 0.0;
+    if (act) {
+        const int u = 6 * a + i;
+        x[u] += alpha * pv[u];
+        rn = r[u] - alpha * Ap[u];
+        r[u] = rn;
     }
-    double rzn = 0.0;
-    for (int i = 0; i < 6; ++i) {
-        double zz = 0.0;
-        for (int j = 0; j < 6; ++j) zz += Minv[36 * (size_t)a + 6 * i + j] * rl[j];
-        z[6 * a + i] = zz;
-        rzn += rl[i] * zz;
+    double zz = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double rj = __shfl(rn, 6 * grp + j, 64);
+        if (act) zz += Minv[36 * (size_t)a + 6 * i + j] * rj;
     }
-    atomicAdd(scal + 2, rzn);
-}
-
-// p = z + beta p; also rotates the scalars for the next iteration (thread 0 of block 0, after
-// every thread has read them: the rotation happens in the NEXT iteration's slot).
-__global__ __launch_bounds__(256) void pcg_update_p_kernel(int N, double *__restrict__ pv, const double *__restrict__ z,
-                                                            const double *__restrict__ scal, double *__restrict__ scal_next) {
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    const double rz = scal[0], rzn = scal[2];
-    const double beta = rz != 0.0 ? rzn / rz : 0.0;
-    if (a == 0) { scal_next[0] = rzn; scal_next[1] = 0.0; scal_next[2] = 0.0; }
-    if (a >= N) return;
-    for (int i = 0; i < 6; ++i) pv[6 * a + i] = z[6 * a + i] + beta * pv[6 * a + i];
+    double contrib = 0.0;
+    if (act) { z[6 * a + i] = zz; contrib = rn * zz; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) contrib += __shfl_down(contrib, o, 64);
+    if (lane == 0 && contrib != 0.0) atomicAdd(scal + 2, contrib);
 }
 
 // dq_a <- exp(xi_a) (x) dq_a  (exp: rotation exp(omega), translation v; oracle/gn_np.py)
@@ -860,9 +888,14 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
     DFH_REQUIRE(knn >= 1 && knn <= kKMaxS, "dfh_gn_build: knn=%d outside [1,%d]", knn, kKMaxS);
     DFH_REQUIRE(node_dq && node_pos && node_w && lw_dq && row_ptr && col && vals && rhs && cost_count, "dfh_gn_build: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    DFH_HIP_CHECK(hipMemsetAsync(vals, 0, sizeof(double) * 36 * (size_t)n_blocks, s));
-    DFH_HIP_CHECK(hipMemsetAsync(rhs, 0, sizeof(double) * 6 * (size_t)n_nodes, s));
-    DFH_HIP_CHECK(hipMemsetAsync(cost_count, 0, sizeof(double) * 2, s));
+    if (rhs == vals + 36 * (size_t)n_blocks && cost_count == rhs + 6 * (size_t)n_nodes) {
+        // the flat {blocks | rhs | cost,count} layout of the host solver: one memset
+        DFH_HIP_CHECK(hipMemsetAsync(vals, 0, sizeof(double) * (36 * (size_t)n_blocks + 6 * (size_t)n_nodes + 2), s));
+    } else {
+        DFH_HIP_CHECK(hipMemsetAsync(vals, 0, sizeof(double) * 36 * (size_t)n_blocks, s));
+        DFH_HIP_CHECK(hipMemsetAsync(rhs, 0, sizeof(double) * 6 * (size_t)n_nodes, s));
+        DFH_HIP_CHECK(hipMemsetAsync(cost_count, 0, sizeof(double) * 2, s));
+    }
     if (n_samples > 0) {
         DFH_REQUIRE(sample_pos && sample_nrm && nbr && weights && corr && valid, "dfh_gn_build: null sample pointer");
         BuildParams p;
@@ -882,7 +915,7 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
     }
     if (node_nbr && rw != 0.0) {
         const int n = n_nodes * knn;
-        hipLaunchKernelGGL(gn_build_reg_kernel, dim3((n + 255) / 256), dim3(256), 0, s, node_nbr, n_nodes, knn, node_dq, node_pos,
+        hipLaunchKernelGGL(gn_build_reg_kernel, dim3((n + 3) / 4), dim3(256), 0, s, node_nbr, n_nodes, knn, node_dq, node_pos,
                            node_w, rw, row_ptr, col, vals, rhs, cost_count);
         DFH_HIP_CHECK(hipGetLastError());
     }
@@ -891,7 +924,7 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
 
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
     if (n_nodes <= 0 || iters < 0) return 0;
-    // Minv (36N) + x,r,p,Ap,z (5*6N) + scalars (3 per iteration + 3)
+    // Minv (36N) + r,pA,Ap,z,pB (5*6N) + scalars (3 per iteration + 6)
     return sizeof(double) * ((size_t)36 * n_nodes + (size_t)30 * n_nodes + 3 * ((size_t)iters + 2));
 }
 
@@ -906,19 +939,24 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
     const size_t N6 = 6 * (size_t)n_nodes;
     double *Minv = ws; ws += 36 * (size_t)n_nodes;
     double *r = ws; ws += N6;
-    double *pv = ws; ws += N6;
     double *Ap = ws; ws += N6;
     double *z = ws; ws += N6;
-    double *scal = ws + N6;               // ws..ws+N6 stays spare
-    DFH_HIP_CHECK(hipMemsetAsync(scal, 0, sizeof(double) * 3 * ((size_t)iters + 2), s));
+    double *pB = ws; ws += N6;
+    double *pA = ws; ws += N6;                    // pA and the scalars are adjacent: one memset zeroes both
+    double *scal = ws;                            // (beta = 0 in iteration 0 must not meet NaN garbage in pA)
+    DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + 3 * ((size_t)iters + 2)), s));
     PcgParams p{n_nodes, lm_abs, lm_rel};
     dim3 grid((n_nodes + 255) / 256), block(256);
-    hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, pv, scal);
+    // scal[0..2] belongs to the init (rz0 in scal[2] so that iteration 0 reads it as "rz_next")
+    hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, z, scal + 2);
+    double *p_prev = pA, *p_cur = pB;
     for (int it = 0; it < iters; ++it) {
-        double *sc = scal + 3 * (size_t)it;
-        hipLaunchKernelGGL(pcg_spmv_kernel, dim3((n_nodes + 3) / 4), block, 0, s, row_ptr, col, vals, n_nodes, pv, Ap, sc);
-        hipLaunchKernelGGL(pcg_update_xr_kernel, grid, block, 0, s, n_nodes, Minv, x_out, r, pv, Ap, z, sc);
-        hipLaunchKernelGGL(pcg_update_p_kernel, grid, block, 0, s, n_nodes, pv, z, sc, sc + 3);
+        double *sc = scal + 3 * ((size_t)it + 1);
+        // iteration 0: beta = 0 but rz must still be forwarded -> scal_prev with rz = 0 gives beta = 0
+        hipLaunchKernelGGL(pcg_spmv_kernel, dim3((n_nodes + 3) / 4), block, 0, s, row_ptr, col, vals, n_nodes, z, p_prev, p_cur,
+                           Ap, sc - 3, sc);
+        hipLaunchKernelGGL(pcg_update_xr_kernel, dim3((n_nodes + 39) / 40), block, 0, s, n_nodes, Minv, x_out, r, p_cur, Ap, z, sc);
+        double *t = p_prev; p_prev = p_cur; p_cur = t;
     }
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;

@@ -1,0 +1,181 @@
+// Surface-sample extraction from the canonical TSDF: the step in front of the warp solve.
+// The reference gets its samples from skimage's marching cubes (core/fusion.py:554-568,
+// core/fusion_dm.py:319-331: `_vertices`, `_normals`), which is outside this hot path
+// (SURVEY.md §8(f) rank 1).  The stand-in used by the solve: every band voxel (w > 0, |T| < band,
+// T in voxel units as fuseDepths stores it) yields one sample -- the voxel centre moved onto the
+// zero level set along the TSDF gradient, with the normalised gradient as normal.  Three launches:
+// per-block counts, a single-block exclusive scan, ordered emission (samples come out in voxel
+// order [x][y][z], deterministically, with no atomics).
+#include "dfh_common.h"
+
+namespace dfh {
+
+constexpr int kExVox = 1024;          // voxels per block (256 threads x 4 along z)
+
+struct ExtractParams {
+    int X, Y, Z;                      // slab dims (planes of this buffer)
+    int x0;                           // global index of plane 0
+    double band;
+    long nvox;
+};
+
+template <typename VolT>
+__device__ __forceinline__ bool band_sample(const VolT *__restrict__ T, const VolT *__restrict__ W, const ExtractParams &p,
+                                            long v, double *pos, double *nrm) {
+    if (v >= p.nvox) return false;
+    const double t = (double)T[v];
+    if (!((double)W[v] > 0.0) || !(fabs(t) < p.band)) return false;
+    const int z = (int)(v % p.Z);
+    const int y = (int)((v / p.Z) % p.Y);
+    const int x = (int)(v / ((long)p.Z * p.Y));
+    const long sx = (long)p.Y * p.Z, sy = p.Z;
+    // central differences inside the slab, one-sided at its faces
+    const int xl = x > 0 ? x - 1 : 0, xh = x < p.X - 1 ? x + 1 : p.X - 1;
+    const int yl = y > 0 ? y - 1 : 0, yh = y < p.Y - 1 ? y + 1 : p.Y - 1;
+    const int zl = z > 0 ? z - 1 : 0, zh = z < p.Z - 1 ? z + 1 : p.Z - 1;
+    const double gx = xh > xl ? ((double)T[xh * sx + y * sy + z] - (double)T[xl * sx + y * sy + z]) / (double)(xh - xl) : 0.0;
+    const double gy = yh > yl ? ((double)T[x * sx + yh * sy + z] - (double)T[x * sx + yl * sy + z]) / (double)(yh - yl) : 0.0;
+    const double gz = zh > zl ? ((double)T[x * sx + y * sy + zh] - (double)T[x * sx + y * sy + zl]) / (double)(zh - zl) : 0.0;
+    const double n = sqrt((gx * gx + gy * gy) + gz * gz);
+    if (!(n > 1e-6)) return false;
+    if (pos) {
+        const double nx = gx / n, ny = gy / n, nz = gz / n;
+        nrm[0] = nx; nrm[1] = ny; nrm[2] = nz;
+        pos[0] = (double)(x + p.x0) - t * nx;
+        pos[1] = (double)y - t * ny;
+        pos[2] = (double)z - t * nz;
+    }
+    return true;
+}
+
+template <typename VolT>
+__global__ __launch_bounds__(256) void surface_count_kernel(const VolT *__restrict__ T, const VolT *__restrict__ W,
+                                                             const ExtractParams p, int *__restrict__ block_count) {
+    __shared__ int red[4];
+    const long v0 = (long)blockIdx.x * kExVox + threadIdx.x * 4;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += band_sample<VolT>(T, W, p, v0 + j, nullptr, nullptr) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of the block counts in place (single block), total -> *total_out
+__global__ __launch_bounds__(1024) void surface_scan_kernel(int *__restrict__ block_count, int nblocks, long *__restrict__ total_out) {
+    __shared__ long part[1024];
+    const int t = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = t * per, b1 = min(nblocks, b0 + per);
+    long s = 0;
+    for (int b = b0; b < b1; ++b) s += block_count[b];
+    part[t] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int o = 1; o < 1024; o <<= 1) {
+        const long add = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    long run = t > 0 ? part[t - 1] : 0;
+    for (int b = b0; b < b1; ++b) {
+        const int c = block_count[b];
+        block_count[b] = (int)run;            // capacity is checked by the host against the total
+        run += c;
+    }
+    if (t == 1023) *total_out = part[1023];
+}
+
+template <typename VolT>
+__global__ __launch_bounds__(256) void surface_emit_kernel(const VolT *__restrict__ T, const VolT *__restrict__ W,
+                                                            const ExtractParams p, const int *__restrict__ block_offset,
+                                                            double *__restrict__ pos_out, double *__restrict__ nrm_out,
+                                                            long capacity) {
+    __shared__ int wave_cnt[4];
+    const long v0 = (long)blockIdx.x * kExVox + threadIdx.x * 4;
+    double pos[4][3], nrm[4][3];
+    bool ok[4];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ok[j] = band_sample<VolT>(T, W, p, v0 + j, pos[j], nrm[j]); c += ok[j] ? 1 : 0; }
+    // exclusive prefix of c over the block, in thread order (= voxel order)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wave_cnt[wv] = incl;
+    __syncthreads();
+    long at = (long)block_offset[blockIdx.x] + (incl - c);
+    for (int w_ = 0; w_ < wv; ++w_) at += wave_cnt[w_];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (ok[j]) {
+            if (at < capacity) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { pos_out[3 * at + a] = pos[j][a]; nrm_out[3 * at + a] = nrm[j][a]; }
+            }
+            ++at;
+        }
+    }
+}
+
+}  // namespace dfh
+
+extern "C" {
+
+size_t dfh_surface_workspace_bytes(const int res[3]) {
+    if (!res || res[0] <= 0 || res[1] <= 0 || res[2] <= 0) return 0;
+    const long nvox = (long)res[0] * res[1] * res[2];
+    return sizeof(int) * (size_t)((nvox + dfh::kExVox - 1) / dfh::kExVox) + sizeof(long);
+}
+
+int dfh_surface_count(const void *tsdf, const void *tsdf_w, int vol_dtype, const int res[3], double band, void *workspace,
+                      size_t workspace_bytes, long *total_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(tsdf && tsdf_w && res && workspace && total_out, "dfh_surface_count: null pointer");
+    DFH_REQUIRE(vol_dtype == DFH_F32 || vol_dtype == DFH_F64, "dfh_surface_count: bad vol_dtype %d", vol_dtype);
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0 && band > 0.0, "dfh_surface_count: bad grid / band");
+    DFH_REQUIRE(workspace_bytes >= dfh_surface_workspace_bytes(res), "dfh_surface_count: workspace too small");
+    ExtractParams p{res[0], res[1], res[2], 0, band, (long)res[0] * res[1] * res[2]};
+    const long nb = (p.nvox + kExVox - 1) / kExVox;
+    DFH_REQUIRE(nb < (1L << 31), "dfh_surface_count: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    int *bc = static_cast<int *>(workspace);
+    if (vol_dtype == DFH_F32) {
+        hipLaunchKernelGGL(surface_count_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float *)tsdf, (const float *)tsdf_w, p, bc);
+    } else {
+        hipLaunchKernelGGL(surface_count_kernel<double>, dim3((unsigned)nb), dim3(256), 0, s, (const double *)tsdf, (const double *)tsdf_w, p, bc);
+    }
+    hipLaunchKernelGGL(surface_scan_kernel, dim3(1), dim3(1024), 0, s, bc, (int)nb, total_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_surface_emit(const void *tsdf, const void *tsdf_w, int vol_dtype, const int res[3], int x0, double band,
+                     const void *workspace, double *pos_out, double *nrm_out, long capacity, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(tsdf && tsdf_w && res && workspace, "dfh_surface_emit: null pointer");
+    DFH_REQUIRE(vol_dtype == DFH_F32 || vol_dtype == DFH_F64, "dfh_surface_emit: bad vol_dtype %d", vol_dtype);
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0 && band > 0.0 && capacity >= 0, "dfh_surface_emit: bad arguments");
+    if (capacity == 0) return DFH_OK;
+    DFH_REQUIRE(pos_out && nrm_out, "dfh_surface_emit: null output");
+    ExtractParams p{res[0], res[1], res[2], x0, band, (long)res[0] * res[1] * res[2]};
+    const long nb = (p.nvox + kExVox - 1) / kExVox;
+    hipStream_t s = (hipStream_t)stream;
+    const int *bo = static_cast<const int *>(workspace);
+    if (vol_dtype == DFH_F32) {
+        hipLaunchKernelGGL(surface_emit_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float *)tsdf, (const float *)tsdf_w, p, bo, pos_out, nrm_out, capacity);
+    } else {
+        hipLaunchKernelGGL(surface_emit_kernel<double>, dim3((unsigned)nb), dim3(256), 0, s, (const double *)tsdf, (const double *)tsdf_w, p, bo, pos_out, nrm_out, capacity);
+    }
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+}  // extern "C"

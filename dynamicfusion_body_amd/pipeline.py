@@ -3,17 +3,44 @@ node neighbourhoods, then GN iterations (associate -> build -> all-reduce -> PCG
 the TSDF update.  Mirrors the reference's frame loop (test.py:116-131: setupCorrespondences ->
 solve -> updateTSDF) with projective association in place of marching cubes + KD-tree.
 
-`extract_surface_samples` is bookkeeping on torch ops (mask, nonzero, central differences); a
-HIP band-compaction kernel is the first "next" row of SURVEY.md §8(f)."""
+`extract_surface_samples` runs the HIP band-compaction kernels of csrc/dfh_extract.hip (the
+first "next" row of SURVEY.md §8(f)); `extract_surface_samples_torch` is the same computation on
+torch ops, kept for CPU-side tests of the sample definition."""
 import numpy as np
 import torch
 
-from . import kernels
+from . import _lib, kernels
+from .device import current_stream_ptr, dtype_code, require_gpu
 from .solve import WarpSolver, sample_knn
 
 
 def extract_surface_samples(T, Wt, band, x0=0, max_samples=None):
-    """Band voxels (w > 0, |T| < band; T in voxel units as fuseDepths stores it) of a slab
+    """Band voxels (w > 0, |T| < band; T in voxel units as fuseDepths stores it) of a slab starting
+    at global plane x0 -> (surface points (S,3) in global index space, unit normals), fp64 CUDA
+    tensors in voxel order.  Three HIP launches (count, scan, emit) and one 8-byte read-back of the
+    sample count."""
+    require_gpu()
+    lib = _lib.load()
+    if not (isinstance(T, torch.Tensor) and T.is_cuda and T.dim() == 3 and T.is_contiguous() and Wt.shape == T.shape
+            and Wt.is_cuda and Wt.is_contiguous() and Wt.dtype == T.dtype):
+        raise ValueError("T and Wt must be contiguous 3-D CUDA tensors of the same shape and dtype")
+    res = _lib.iarr(T.shape)
+    nbytes = lib.dfh_surface_workspace_bytes(res)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=T.device)
+    total = torch.zeros(1, dtype=torch.int64, device=T.device)
+    _lib.check(lib.dfh_surface_count(T.data_ptr(), Wt.data_ptr(), dtype_code(T), res, float(band), ws.data_ptr(),
+                                     ws.numel() * 8, total.data_ptr(), current_stream_ptr()), "dfh_surface_count")
+    n = int(total.item())
+    cap = n if max_samples is None else min(n, int(max_samples))
+    pos = torch.empty((cap, 3), dtype=torch.float64, device=T.device)
+    nrm = torch.empty((cap, 3), dtype=torch.float64, device=T.device)
+    _lib.check(lib.dfh_surface_emit(T.data_ptr(), Wt.data_ptr(), dtype_code(T), res, int(x0), float(band), ws.data_ptr(),
+                                    pos.data_ptr(), nrm.data_ptr(), cap, current_stream_ptr()), "dfh_surface_emit")
+    return pos, nrm
+
+
+def extract_surface_samples_torch(T, Wt, band, x0=0, max_samples=None):
+    """Same samples on torch ops (works on CPU tensors).  Band voxels of a slab
     starting at global plane x0 -> (surface points (S,3) in global index space, unit normals).
     Normals are central differences of T inside the slab (one-sided at its faces); points are the
     voxel centres projected onto the zero level set along the normal."""

@@ -167,6 +167,19 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
 /* node_dq[a] <- exp(step * xi[a]) (x) node_dq[a]; exp = rotation exp(omega), translation v. */
 int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream);
 
+/* ---- surface samples for the solve (stand-in for marching cubes, core/fusion.py:554-568) -----------
+ * Every band voxel (w > 0, |T| < band; T in voxel units as fuseDepths stores it) whose TSDF gradient
+ * (central differences inside the slab, one-sided at its faces) is non-zero yields one sample: position
+ * = voxel centre - T * n (global index space, plane 0 of the buffer is global plane x0), normal n =
+ * gradient / |gradient|.  Samples come out in voxel order, deterministically.
+ *   dfh_surface_count : per-block counts + exclusive scan into `workspace`, *total_out (device) = count
+ *   dfh_surface_emit  : writes min(total, capacity) samples (n x 3 fp64 each); uses the same workspace. */
+size_t dfh_surface_workspace_bytes(const int res[3]);
+int dfh_surface_count(const void *tsdf, const void *tsdf_w, int vol_dtype, const int res[3], double band, void *workspace,
+                      size_t workspace_bytes, long *total_out, void *stream);
+int dfh_surface_emit(const void *tsdf, const void *tsdf_w, int vol_dtype, const int res[3], int x0, double band,
+                     const void *workspace, double *pos_out, double *nrm_out, long capacity, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

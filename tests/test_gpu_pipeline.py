@@ -101,3 +101,29 @@ def test_frame_solve_converges_and_matches_oracle():
     dq = sv.node_dq.cpu().numpy()
     assert np.allclose(np.sum(dq[:, :4] ** 2, axis=1), 1.0, atol=1e-10)
     assert np.abs(dq - dqs).max() < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_device_extraction_matches_torch_definition(dtype):
+    """csrc/dfh_extract.hip (count / scan / emit) against the same sample definition on torch ops:
+    identical count and voxel order, positions and normals to fp64 rounding; ragged shapes, slab
+    offset, capacity truncation, empty result."""
+    from dynamicfusion_body_amd.pipeline import extract_surface_samples_torch
+    rng = np.random.default_rng(12)
+    for shape, x0 in (((40, 33, 37), 0), ((7, 64, 50), 13), ((64, 64, 64), 0)):
+        g = np.stack(np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij"), axis=-1)
+        T = np.linalg.norm(g - (np.array(shape) / 2.0 + 0.3), axis=-1) - min(shape) / 3.0 + 0.05 * rng.normal(size=shape)
+        W = (rng.random(shape) < 0.8).astype(np.float64)
+        Td = torch.from_numpy(T).to("cuda", dtype=dtype).contiguous()
+        Wd = torch.from_numpy(W).to("cuda", dtype=dtype).contiguous()
+        pos, nrm = extract_surface_samples(Td, Wd, 1.5, x0=x0)
+        pt, nt = extract_surface_samples_torch(Td, Wd, 1.5, x0=x0)
+        assert pos.shape == pt.shape and pos.shape[0] > 50
+        assert float((pos - pt).abs().max()) <= 1e-12 and float((nrm - nt).abs().max()) <= 1e-12
+        cap = pos.shape[0] // 3
+        p2, n2 = extract_surface_samples(Td, Wd, 1.5, x0=x0, max_samples=cap)
+        assert p2.shape[0] == cap and torch.equal(p2, pos[:cap]) and torch.equal(n2, nrm[:cap])
+        pe, ne = extract_surface_samples(Td, torch.zeros_like(Wd), 1.5)
+        assert pe.shape == (0, 3) and ne.shape == (0, 3)
+    with pytest.raises(ValueError):
+        extract_surface_samples(Td, Wd[:2], 1.5)

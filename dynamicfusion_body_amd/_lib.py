@@ -35,6 +35,8 @@ _SIGNATURES = {
     "dfh_gn_build_rigid": (_int, [_vp, _vp, _vp, _vp, _int, _c_double_p, _vp, _vp]),
     "dfh_residual_data": (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _int, _c_double_p, _vp, _vp]),
     "dfh_residual_reg": (_int, [_vp, _int, _int, _vp, _vp, _vp, _dbl, _vp, _vp]),
+    "dfh_warp_points": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _int, _c_double_p, _vp, _vp, _vp]),
+    "dfh_closest_correspondences": (_int, [_vp, _vp, _int, _vp, _int, _int, _dbl, _vp, _vp, _vp, _vp]),
     "dfh_sample_knn": (_int, [_vp, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "dfh_gn_associate": (_int, [_vp, _vp, _vp, _int, _int, _vp, _c_double_p, _vp, _int, _int, _int, _c_double_p,
                                 _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, _vp, _vp]),

@@ -174,8 +174,6 @@ __global__ __launch_bounds__(256) void gn_build_rigid_kernel(const double *__res
     }
 }
 
-// ------------------------------------------------------------------------------- sample setup
-
 __device__ __forceinline__ void top8_insert_s(double (&bd)[kKMaxS], int (&bi)[kKMaxS], double d2, int idx) {
 #pragma unroll
     for (int i = 0; i < kKMaxS; ++i) {
@@ -188,6 +186,92 @@ __device__ __forceinline__ void top8_insert_s(double (&bd)[kKMaxS], int (&bi)[kK
         idx = lt ? ti : idx;
     }
 }
+
+// ------------------------------------------------------------------------------- batch warp + correspondences
+// Fusion.warp for a batch (core/fusion.py:502-520): nbr == NULL -> only the global m_lw is applied
+// (the FusionDM case, dqb_warp(_lw, v) / dqb_warp_normal(_lw, n), fusion_dm.py:230-231).
+__global__ __launch_bounds__(256) void warp_points_kernel(const double *__restrict__ verts, const double *__restrict__ norms,
+                                                           const int *__restrict__ nbr, int V, int k,
+                                                           const double *__restrict__ node_dq,
+                                                           const double *__restrict__ node_pos,
+                                                           const double *__restrict__ node_w, DQ lw,
+                                                           double *__restrict__ out_pos, double *__restrict__ out_nrm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    double px = verts[3 * (size_t)i], py = verts[3 * (size_t)i + 1], pz = verts[3 * (size_t)i + 2];
+    double nx = norms ? norms[3 * (size_t)i] : 0.0, ny = norms ? norms[3 * (size_t)i + 1] : 0.0, nz = norms ? norms[3 * (size_t)i + 2] : 0.0;
+    if (nbr) {
+        int idx[kKMaxS];
+#pragma unroll
+        for (int j = 0; j < kKMaxS; ++j) idx[j] = j < k ? nbr[(size_t)i * k + j] : 0;
+        double bh[8];
+        blend_from_indices(node_dq, node_pos, node_w, idx, k, px, py, pz, bh, nullptr, nullptr);
+        const D3 x1 = dqb_warp_exact(bh, round_f32(px), round_f32(py), round_f32(pz));
+        const D3 n1 = dqb_warp_normal_exact(bh, round_f32(nx), round_f32(ny), round_f32(nz));
+        px = x1.x; py = x1.y; pz = x1.z; nx = n1.x; ny = n1.y; nz = n1.z;
+    }
+    const D3 xp = dqb_warp_exact(lw.q, round_f32(px), round_f32(py), round_f32(pz));
+    out_pos[3 * (size_t)i] = xp.x; out_pos[3 * (size_t)i + 1] = xp.y; out_pos[3 * (size_t)i + 2] = xp.z;
+    if (out_nrm) {
+        const D3 np_ = dqb_warp_normal_exact(lw.q, round_f32(nx), round_f32(ny), round_f32(nz));
+        out_nrm[3 * (size_t)i] = np_.x; out_nrm[3 * (size_t)i + 1] = np_.y; out_nrm[3 * (size_t)i + 2] = np_.z;
+    }
+}
+
+// The selection loop of setupCorrespondences (core/fusion_dm.py:229-244, core/fusion.py:258-276):
+// k nearest live vertices of every warped vertex (brute force through LDS tiles, nearest first as
+// KDTree.query returns them), best = first neighbour with the smallest cost |wn.(vp - p)| below the
+// initial best_cost = 1, kept iff best_cost <= tolerance.
+__global__ __launch_bounds__(256) void closest_corr_kernel(const double *__restrict__ wpos, const double *__restrict__ wnrm, int V,
+                                                            const double *__restrict__ live, int L, int k, double tolerance,
+                                                            double *__restrict__ corr, double *__restrict__ cost_out,
+                                                            unsigned char *__restrict__ keep) {
+    __shared__ double sp[256 * 3];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < V;
+    const double px = act ? wpos[3 * (size_t)i] : 0.0, py = act ? wpos[3 * (size_t)i + 1] : 0.0, pz = act ? wpos[3 * (size_t)i + 2] : 0.0;
+    double bd[kKMaxS];
+    int bi[kKMaxS];
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) { bd[j] = __builtin_huge_val(); bi[j] = -1; }
+    for (int base = 0; base < L; base += 256) {
+        const int n = min(256, L - base);
+        if ((int)threadIdx.x < n) {
+            sp[3 * threadIdx.x] = live[3 * (size_t)(base + threadIdx.x)];
+            sp[3 * threadIdx.x + 1] = live[3 * (size_t)(base + threadIdx.x) + 1];
+            sp[3 * threadIdx.x + 2] = live[3 * (size_t)(base + threadIdx.x) + 2];
+        }
+        __syncthreads();
+        if (act) {
+            for (int j = 0; j < n; ++j) {
+                const double dx = px - sp[3 * j], dy = py - sp[3 * j + 1], dz = pz - sp[3 * j + 2];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 < bd[kKMaxS - 1]) top8_insert_s(bd, bi, d2, base + j);
+            }
+        }
+        __syncthreads();
+    }
+    if (!act) return;
+    const double nx = wnrm[3 * (size_t)i], ny = wnrm[3 * (size_t)i + 1], nz = wnrm[3 * (size_t)i + 2];
+    double best_cost = 1.0;                                     // fusion_dm.py:234
+    int best = bi[0];                                           // lverts[nidxs[0]], :233
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) {
+        if (j < k) {
+            const int q = bi[j];
+            const double dx = px - live[3 * (size_t)q], dy = py - live[3 * (size_t)q + 1], dz = pz - live[3 * (size_t)q + 2];
+            const double c = fabs((nx * dx + ny * dy) + nz * dz);   // :238
+            if (c < best_cost) { best_cost = c; best = q; }
+        }
+    }
+    corr[3 * (size_t)i] = live[3 * (size_t)best];
+    corr[3 * (size_t)i + 1] = live[3 * (size_t)best + 1];
+    corr[3 * (size_t)i + 2] = live[3 * (size_t)best + 2];
+    if (cost_out) cost_out[i] = best_cost;
+    keep[i] = best_cost <= tolerance ? 1 : 0;                    // :242
+}
+
+// ------------------------------------------------------------------------------- sample setup
 
 // k nearest nodes + Gaussian blend weights of arbitrary sample points (brute force over all
 // nodes: runs once per frame, S*N distance evaluations).
@@ -822,6 +906,39 @@ int dfh_residual_reg(const int *node_nbr, int n_nodes, int knn, const double *no
     const int n = n_nodes * knn;
     hipLaunchKernelGGL(residual_reg_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, node_nbr, n_nodes, knn,
                        node_dq, node_pos, node_w, rw, out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_warp_points(const double *verts, const double *normals, const int *nbr, int n_verts, int knn, const double *node_dq,
+                    const double *node_pos, const double *node_w, int n_nodes, const double lw_dq[8], double *out_pos,
+                    double *out_nrm, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_verts >= 0, "dfh_warp_points: negative count");
+    if (n_verts == 0) return DFH_OK;
+    DFH_REQUIRE(verts && lw_dq && out_pos, "dfh_warp_points: null pointer");
+    DFH_REQUIRE((normals == nullptr) == (out_nrm == nullptr) || normals, "dfh_warp_points: out_nrm needs normals");
+    if (nbr) {
+        DFH_REQUIRE(knn >= 1 && knn <= kKMaxS && n_nodes >= 1 && node_dq && node_pos && node_w, "dfh_warp_points: bad graph arguments");
+    }
+    DQ q;
+    for (int i = 0; i < 8; ++i) q.q[i] = lw_dq[i];
+    hipLaunchKernelGGL(warp_points_kernel, dim3((n_verts + 255) / 256), dim3(256), 0, (hipStream_t)stream, verts, normals, nbr,
+                       n_verts, knn, node_dq, node_pos, node_w, q, out_pos, normals ? out_nrm : nullptr);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_closest_correspondences(const double *warped_pos, const double *warped_nrm, int n_verts, const double *live_verts,
+                                int n_live, int knn, double tolerance, double *corr_out, double *cost_out,
+                                unsigned char *keep_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_verts >= 0 && knn >= 1 && knn <= kKMaxS, "dfh_closest_correspondences: bad sizes");
+    DFH_REQUIRE(n_live >= knn, "dfh_closest_correspondences: %d live vertices < knn=%d", n_live, knn);
+    if (n_verts == 0) return DFH_OK;
+    DFH_REQUIRE(warped_pos && warped_nrm && live_verts && corr_out && keep_out, "dfh_closest_correspondences: null pointer");
+    hipLaunchKernelGGL(closest_corr_kernel, dim3((n_verts + 255) / 256), dim3(256), 0, (hipStream_t)stream, warped_pos, warped_nrm,
+                       n_verts, live_verts, n_live, knn, tolerance, corr_out, cost_out, keep_out);
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }

@@ -178,17 +178,54 @@ class FusionDM:
         V, Nn, C = self._corr_state()
         return _solve.residual_rigid(x, V, Nn, C).cpu().numpy()
 
+    # ------------------------------------------------------------------ surface + correspondences
+    def marching_cubes(self, tsdf=None, step_size=1, band=1.0):
+        """Stand-in for skimage's marching cubes (reference core/fusion_dm.py:319-331), which is
+        outside this hot path: band voxels moved onto the zero level set along the TSDF gradient
+        (csrc/dfh_extract.hip) play the role of the mesh vertices, the normalised gradient that of
+        the vertex normals; there are no faces.  Same call shapes: with `tsdf` returns
+        (verts, faces=None, normals, values=None); without, fills `_vertices` / `_normals` from the
+        canonical volume (voxels with w > 0)."""
+        from .pipeline import extract_surface_samples
+        if tsdf is not None:
+            live = self._live_to_device(tsdf)
+            pos, nrm = extract_surface_samples(live, torch.ones_like(live), band)
+            return pos.cpu().numpy(), None, nrm.cpu().numpy(), None
+        self._ensure_volumes()
+        pos, nrm = extract_surface_samples(self._T, self._Wt, band)
+        self._vertices, self._faces, self._normals = pos.cpu().numpy(), None, nrm.cpu().numpy()
+
+    def setupCorrespondences(self, curr_tsdf, prune_result=True, tolerance=1.0, live_vertices=None):
+        """Closest-point correspondences of the canonical vertices in the live surface; reference
+        core/fusion_dm.py:219-244 (warp by `_lw`, knn nearest live vertices, smallest point-to-plane
+        cost, keep if <= tolerance).  `live_vertices` replaces the marching-cubes call on curr_tsdf."""
+        if self._vertices is None or self._normals is None:
+            raise ValueError('canonical vertices / normals have not been set (call marching_cubes())')
+        lverts = self.marching_cubes(curr_tsdf, step_size=1)[0] if live_vertices is None else np.asarray(live_vertices, dtype=np.float64)
+        if len(lverts) < self._knn:
+            raise ValueError('fewer live vertices than knn')
+        lw = np.asarray(self._lw, dtype=np.float64)
+        vp, wn = _solve.warp_points(self._vertices, self._normals, lw)
+        corr, cost, keep = _solve.closest_correspondences(vp, wn, lverts, self._knn, tolerance)
+        keep = keep.cpu().numpy().astype(bool)
+        self._corridx = list(np.nonzero(keep)[0])
+        self._correspondences = list(corr.cpu().numpy()[keep])
+
     def solve(self, curr_tsdf=None, iterations=10):
-        """Rigid alignment `_lw` for the current correspondences; call surface of reference
-        core/fusion_dm.py:264-282.  The reference re-extracts correspondences with marching
-        cubes + KD-tree three times around scipy's least_squares; here `_corridx` /
-        `_correspondences` are the caller's (or the projective association's) and `_lw` is
-        found by Gauss-Newton on 0.5*|computef_lw|^2 (6-DoF left twist, HIP kernels)."""
+        """Rigid alignment `_lw`; call surface of reference core/fusion_dm.py:264-282: three rounds
+        of [setupCorrespondences(curr_tsdf) -> minimise 0.5*|computef_lw|^2 from the current `_lw`].
+        The reference minimises with scipy's least_squares (finite differences); here Gauss-Newton
+        on the 6-DoF left twist with analytic Jacobians (HIP kernels).  curr_tsdf=None keeps the
+        correspondences already stored in `_corridx` / `_correspondences` (one round)."""
         self._itercounter += 1
-        V, Nn, C = self._corr_state()
-        x, costs = _solve.solve_rigid_gn(np.asarray(self._lw, dtype=np.float64), V, Nn, C, iters=iterations)
-        self._lw = x
-        self.last_costs = costs
+        self.last_costs = []
+        for _ in range(3 if curr_tsdf is not None else 1):             # iteration = 3, :265
+            if curr_tsdf is not None:
+                self.setupCorrespondences(curr_tsdf)
+            V, Nn, C = self._corr_state()
+            x, costs = _solve.solve_rigid_gn(np.asarray(self._lw, dtype=np.float64), V, Nn, C, iters=iterations)
+            self._lw = x
+            self.last_costs.append(costs)
 
     # ------------------------------------------------------------------ driver
     def _auto_alignment(self, depths, lws):
@@ -215,9 +252,6 @@ class FusionDM:
         tensors instead of downloading them."""
         if len(depths) != len(lws):
             raise ValueError('length of camera matrix array Ks must equal that of depth maps')   # :96-97
-        if useICP:
-            raise NotImplementedError('useICP needs marching-cubes correspondences '
-                                      '(core/fusion_dm.py:219-244), outside this hot path')
         if outputMesh:
             raise NotImplementedError('outputMesh needs marching cubes (core/fusion_dm.py:339-354), '
                                       'outside this hot path')
@@ -234,11 +268,24 @@ class FusionDM:
         self._IND[0:3, 3] = avg - scale * res / 2
         self._INDinv = la.inv(self._IND)
 
-        T, Wt = self._new_volume_pair()
-        for idx in range(len(depths)):                              # :166-170
-            self._depthidx = idx
-            self.fuseDepths(depths[idx], lws[idx], T, Wt, scale=12 * std / res, center=avg)
-        self._T, self._Wt = T, Wt
+        if useICP:                                                  # :149-164
+            for idx in range(len(depths)):
+                T, Wt = self._new_volume_pair()
+                self.fuseDepths(depths[idx], lws[idx], T, Wt, scale=10 * std / res, center=avg)
+                if idx == 0:
+                    self._T, self._Wt = T, Wt
+                    self.marching_cubes()
+                else:
+                    self._lw = np.array([1, 0, 0, 0, 0, 0, 0, 0], dtype=np.float32)
+                    self.solve(T)
+                    self.updateTSDF(T)
+            T, Wt = self._T, self._Wt
+        else:
+            T, Wt = self._new_volume_pair()
+            for idx in range(len(depths)):                          # :166-170
+                self._depthidx = idx
+                self.fuseDepths(depths[idx], lws[idx], T, Wt, scale=12 * std / res, center=avg)
+            self._T, self._Wt = T, Wt
         if as_numpy:
             return (self._tsdf, self._tsdfw)
         return (T, Wt)

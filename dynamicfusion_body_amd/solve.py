@@ -82,6 +82,46 @@ def residual_reg(node_dq, node_nbr, node_pos, node_w, rw):
     return out
 
 
+def warp_points(verts, normals, lw_dq, nbr=None, node_dq=None, node_pos=None, node_w=None):
+    """Batch Fusion.warp (reference core/fusion.py:502-520): (warped points, warped normals) as CUDA
+    fp64 tensors.  nbr=None applies only the global `lw_dq` (the FusionDM case)."""
+    require_gpu()
+    lib = _lib.load()
+    V = _f64(verts, (3,))
+    Nn = None if normals is None else _f64(normals, (3,))
+    out_p = torch.empty_like(V)
+    out_n = None if Nn is None else torch.empty_like(V)
+    if nbr is not None:
+        nb = _i32(nbr)
+        Q, P, Wn = _f64(node_dq, (8,)), _f64(node_pos, (3,)), _f64(node_w, ())
+        if nb.dim() != 2 or nb.shape[0] != V.shape[0]:
+            raise ValueError("neighbour table must be (n_vertices, knn)")
+        args = (nb.data_ptr(), V.shape[0], nb.shape[1], Q.data_ptr(), P.data_ptr(), Wn.data_ptr(), Q.shape[0])
+    else:
+        args = (0, V.shape[0], 1, 0, 0, 0, 0)
+    _lib.check(lib.dfh_warp_points(V.data_ptr(), 0 if Nn is None else Nn.data_ptr(), *args, _lib.darr(lw_dq, 8),
+                                   out_p.data_ptr(), 0 if out_n is None else out_n.data_ptr(), current_stream_ptr()),
+               "dfh_warp_points")
+    return out_p, out_n
+
+
+def closest_correspondences(warped_pos, warped_nrm, live_verts, knn, tolerance):
+    """Selection loop of setupCorrespondences (reference core/fusion_dm.py:229-244): returns
+    (best live point (V,3), best cost (V,), keep (V,) uint8) as CUDA tensors."""
+    require_gpu()
+    lib = _lib.load()
+    P, Nn, Lv = _f64(warped_pos, (3,)), _f64(warped_nrm, (3,)), _f64(live_verts, (3,))
+    if P.shape[0] != Nn.shape[0]:
+        raise ValueError("warped positions and normals disagree in length")
+    corr = torch.empty_like(P)
+    cost = torch.empty(P.shape[0], dtype=torch.float64, device="cuda")
+    keep = torch.empty(P.shape[0], dtype=torch.uint8, device="cuda")
+    _lib.check(lib.dfh_closest_correspondences(P.data_ptr(), Nn.data_ptr(), P.shape[0], Lv.data_ptr(), Lv.shape[0], int(knn),
+                                               float(tolerance), corr.data_ptr(), cost.data_ptr(), keep.data_ptr(),
+                                               current_stream_ptr()), "dfh_closest_correspondences")
+    return corr, cost, keep
+
+
 def sample_knn(sample_pos, node_pos, node_w, knn):
     """(nbr (S,k) int32, weights (S,k) fp64) of arbitrary points: k nearest nodes, nearest first."""
     require_gpu()

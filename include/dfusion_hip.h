@@ -128,6 +128,21 @@ int dfh_residual_data(const double *verts, const double *normals, const double *
 int dfh_residual_reg(const int *node_nbr, int n_nodes, int knn, const double *node_dq, const double *node_pos,
                      const double *node_w, double rw, double *out, void *stream);
 
+/* A5 for a batch: Fusion.warp(v, dqs[nbr], nbr, normal=n, m_lw=lw_dq) (core/fusion.py:502-520) for every
+ * vertex; nbr == NULL applies only lw_dq (dqb_warp(_lw, v), dqb_warp_normal(_lw, n), fusion_dm.py:230-231).
+ * normals / out_nrm may both be NULL. */
+int dfh_warp_points(const double *verts, const double *normals, const int *nbr, int n_verts, int knn, const double *node_dq,
+                    const double *node_pos, const double *node_w, int n_nodes, const double lw_dq[8], double *out_pos,
+                    double *out_nrm, void *stream);
+
+/* The selection loop of setupCorrespondences (core/fusion_dm.py:229-244; core/fusion.py:258-276, 'clpts'):
+ * for every warped vertex the knn nearest live vertices (nearest first), best = the first with the smallest
+ * cost |wn . (vp - p)| below the initial best_cost 1 (else the nearest), keep = best_cost <= tolerance.
+ * corr_out n x 3, cost_out n (may be NULL), keep_out n uint8. */
+int dfh_closest_correspondences(const double *warped_pos, const double *warped_nrm, int n_verts, const double *live_verts,
+                                int n_live, int knn, double tolerance, double *corr_out, double *cost_out,
+                                unsigned char *keep_out, void *stream);
+
 /* k nearest nodes (nearest first; KDTree.query order, core/fusion.py:121-123) and the Gaussian DQB
  * weights exp(-(|p - v_j| / (2 w_j))^2) (:537) of arbitrary sample points.  Both are static while the
  * graph is unchanged.  nbr_out: n_samples x knn int32; weights_out: n_samples x knn. */

@@ -443,3 +443,30 @@ def computef(x, vertices, normals, correspondences, nbr, node_vidx, node_pos, no
     fd = computef_data(dqs, vertices, normals, correspondences, nbr, node_pos, node_w, lw_dq)
     fr = computef_reg(dqs, node_vidx, nbr, node_pos, node_w, rw)
     return np.concatenate([fd, fr])
+
+
+# --------------------------------------------------------------------------------------
+# correspondence search     core/fusion_dm.py:219-244, core/fusion.py:255-276
+# --------------------------------------------------------------------------------------
+
+def closest_correspondences(warped_pos, warped_nrm, live_verts, k, tolerance):
+    """The selection loop shared by FusionDM.setupCorrespondences (fusion_dm.py:229-244) and
+    Fusion.setupCorrespondences('clpts') (fusion.py:258-276): for every warped canonical vertex
+    vp with warped normal wn, the k nearest live vertices (KDTree.query order: nearest first);
+    best = the first one whose cost |wn.(vp - p)| is smallest AND < 1 (best_cost starts at 1,
+    best_pt at the nearest neighbour, :233-241); kept iff best_cost <= tolerance (:242).
+    Returns (best_pt (V,3), best_cost (V,), keep (V,) bool)."""
+    vp = np.asarray(warped_pos, dtype=np.float64)
+    wn = np.asarray(warped_nrm, dtype=np.float64)
+    lv = np.asarray(live_verts, dtype=np.float64)
+    nidx = knn_bruteforce(vp, lv, k)                      # (V,k)
+    P = lv[nidx]
+    d = vp[:, None, :] - P
+    cost = np.abs(wn[:, None, 0] * d[..., 0] + wn[:, None, 1] * d[..., 1] + wn[:, None, 2] * d[..., 2])
+    best_cost = np.ones(len(vp))
+    best = P[:, 0, :].copy()
+    for j in range(k):
+        better = cost[:, j] < best_cost
+        best_cost = np.where(better, cost[:, j], best_cost)
+        best = np.where(better[:, None], P[:, j, :], best)
+    return best, best_cost, best_cost <= tolerance

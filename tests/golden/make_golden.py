@@ -349,7 +349,45 @@ def g6():
     print("g6 ok: updated", out["updated"], "of", R ** 3, "ref time", dt)
 
 
+# ---------------------------------------------------------------------------- G7
+def g7():
+    """setupCorrespondences of both classes with marching cubes (skimage, absent) monkey-patched to
+    return a given live vertex set: everything after that call is the reference's own code."""
+    rng = np.random.default_rng(707)
+    V, L, k = 300, 420, 4
+    d = rng.normal(size=(V, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    verts = 16 + 8 * d
+    norms = d + 0.05 * rng.normal(size=(V, 3)); norms /= np.linalg.norm(norms, axis=1, keepdims=True)
+    dl = rng.normal(size=(L, 3)); dl /= np.linalg.norm(dl, axis=1, keepdims=True)
+    lverts = 16.3 + 8.2 * dl + 0.4 * rng.normal(size=(L, 3))
+    lw = small_dq(rng, rot=0.05, trans=0.4) * 1.01
+    out = dict(verts=verts, norms=norms, lverts=lverts, lw=lw, knn=k)
+    fd = FusionDM(1.0, np.eye(3), tsdf_res=4, knn=k)
+    fd._vertices, fd._normals, fd._lw = verts, norms, lw
+    fd.marching_cubes = lambda tsdf=None, step_size=1: (lverts, None, None, None)
+    for tol in (1.0, 0.35):
+        quiet(fd.setupCorrespondences, np.zeros((2, 2, 2)), tolerance=tol)
+        out["dm_corridx_%g" % tol] = np.array(fd._corridx)
+        out["dm_corr_%g" % tol] = np.array(fd._correspondences)
+    # non-rigid: Fusion.setupCorrespondences(method='clpts', prune_result=False)
+    N = 24
+    vidx = rng.choice(V, size=N, replace=False)
+    node_pos = verts[vidx].copy()
+    node_dq = np.array([small_dq(rng, rot=0.06, trans=0.3, scale_jitter=0.01) for _ in range(N)])
+    node_w = rng.uniform(5.0, 7.0, size=N)
+    fu = bare_fusion(1.0, k, node_pos, node_dq, node_w, lw, vert_idx=vidx)
+    fu._vertices, fu._normals = verts, norms
+    fu._neighbor_look_up = [fu._kdtree.query(v, k=k)[1] for v in verts]
+    fu._sess = None
+    fu.marching_cubes = lambda tsdf=None, step_size=0: (lverts, None, None, None)
+    quiet(fu.setupCorrespondences, np.zeros((2, 2, 2)), method='clpts', prune_result=False)
+    out.update(node_pos=node_pos, node_dq=node_dq, node_w=node_w, vidx=vidx, nbr=np.array(fu._neighbor_look_up),
+               nr_corr=np.array(fu._correspondences))
+    np.savez_compressed(os.path.join(HERE, "g7_correspondences.npz"), **out)
+    print("g7 ok: kept", len(out["dm_corridx_1"]), len(out["dm_corridx_0.35"]), "of", V)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for w in which:
         globals()[w]()

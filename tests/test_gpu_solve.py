@@ -244,4 +244,56 @@ def test_class_surface_matches_reference(golden):
     fd._lw = np.array([1, 0, 0, 0, 0, 0, 0, 0], dtype=np.float32)
     fd.solve(None)
     assert np.abs(O.DQTSE3(fd._lw) - O.DQTSE3(x_true)).max() < 1e-3
-    assert fd.last_costs[-1] < 1e-8
+    assert fd.last_costs[-1][-1] < 1e-8
+
+
+def test_setup_correspondences_matches_reference(golden):
+    """FusionDM.setupCorrespondences / the batch warp / the selection kernel against the reference's
+    outputs (golden g7: marching cubes patched to return given live vertices)."""
+    from dynamicfusion_body_amd import FusionDM
+    g = golden("g7_correspondences")
+    k = int(g["knn"])
+    fd = FusionDM(1.0, np.eye(3), tsdf_res=4, knn=k)
+    fd._vertices, fd._normals, fd._lw = g["verts"], g["norms"], g["lw"]
+    for tol in (1.0, 0.35):
+        fd.setupCorrespondences(None, tolerance=tol, live_vertices=g["lverts"])
+        assert np.array_equal(np.array(fd._corridx), g["dm_corridx_%g" % tol])
+        assert np.array_equal(np.array(fd._correspondences), g["dm_corr_%g" % tol])
+    # non-rigid: warp through the node graph, then the same selection (Fusion.setupCorrespondences 'clpts')
+    vp, wn = solve.warp_points(g["verts"], g["norms"], g["lw"], nbr=g["nbr"], node_dq=g["node_dq"], node_pos=g["node_pos"], node_w=g["node_w"])
+    vo, no = O.warp(g["verts"], g["node_dq"][g["nbr"]], g["node_pos"][g["nbr"]], g["node_w"][g["nbr"]], normal=g["norms"], m_lw=g["lw"])
+    assert np.abs(vp.cpu().numpy() - vo).max() <= 1e-12 and np.abs(wn.cpu().numpy() - no).max() <= 1e-12
+    corr, cost, keep = solve.closest_correspondences(vp, wn, g["lverts"], k, 0.2)
+    assert np.array_equal(corr.cpu().numpy(), g["nr_corr"])
+    bo, co, ko = O.closest_correspondences(vo, no, g["lverts"], k, 0.2)
+    assert np.abs(cost.cpu().numpy() - co).max() <= 1e-12 and np.array_equal(keep.cpu().numpy().astype(bool), ko)
+    with pytest.raises(ValueError):
+        solve.closest_correspondences(vp, wn, g["lverts"][:2], k, 0.2)
+
+
+def test_icp_compute_live_tsdf_recovers_rigid_motion():
+    """compute_live_tsdf(useICP=True) (reference core/fusion_dm.py:149-164): view 0 becomes the
+    canonical volume, the second (displaced scene) view is aligned by three rounds of
+    [setupCorrespondences -> GN on `_lw`] and fused with updateTSDF."""
+    from dynamicfusion_body_amd import FusionDM
+    R = 64
+    H, W, fx, cx, cy = scene.CAMERAS["C1"]
+    K = scene.intrinsics(fx, cx, cy)
+    f = FusionDM(0.6, K, tsdf_res=R)
+    avg = np.array([-0.03, -0.43, -5.6], dtype='float32'); c = avg.astype(np.float64)
+    lw = scene.view_extrinsic(0.0, centre=c)
+    scale = 10 * 1.3 / R
+    shift = np.array([1.2, -0.8, 0.6]) * scale                    # metres: about one voxel
+    d0 = scene.render_depth(K, lw, H, W, invalid_frac=0.0, sphere_c=c, sphere_r=2.5, wall_z=-1.0)
+    d1 = scene.render_depth(K, lw, H, W, invalid_frac=0.0, sphere_c=c + shift, sphere_r=2.5, wall_z=-1.0 + shift[2])
+    T, Wt = f.compute_live_tsdf([d0, d1], [lw, lw], useICP=True)
+    assert len(f.last_costs) == 3 and f.last_costs[-1][-1] < f.last_costs[0][0]
+    M = O.DQTSE3(f._lw)
+    # `_lw` maps canonical index space onto the live frame.  Point-to-plane on a sphere observes the
+    # motion along the viewing direction well (z) and tangential sliding only weakly (x, y): the
+    # right sign and part of the magnitude
+    t_true = shift / scale
+    assert np.abs(M[:3, :3] - np.eye(3)).max() < 0.05
+    assert abs(M[2, 3] - t_true[2]) < 0.15
+    assert M[0, 3] * t_true[0] > 0 and M[1, 3] * t_true[1] > 0 and np.abs(M[:2, 3]).max() < 1.5 * np.abs(t_true[:2]).max()
+    assert (Wt > 1).any()                                          # the second view was fused in

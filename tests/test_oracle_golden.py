@@ -199,3 +199,19 @@ def test_g6_config1(golden):
     assert abs(T.sum() - float(g["sumT"])) <= 1e-8
     assert np.abs(T.reshape(-1)[g["sample_idx"]] - g["sample_T"]).max() <= VAL_TOL
     assert np.array_equal(W.reshape(-1)[g["sample_idx"]], g["sample_W"])
+
+
+def test_g7_correspondences(golden):
+    """setupCorrespondences (both classes) with marching cubes patched out: the selection loop."""
+    g = golden("g7_correspondences")
+    k = int(g["knn"])
+    vp = O.dqb_warp(g["lw"], g["verts"]); wn = O.dqb_warp_normal(g["lw"], g["norms"])
+    for tol in (1.0, 0.35):
+        best, cost, keep = O.closest_correspondences(vp, wn, g["lverts"], k, tol)
+        assert np.array_equal(np.nonzero(keep)[0], g["dm_corridx_%g" % tol])
+        assert np.array_equal(best[keep], g["dm_corr_%g" % tol])
+    assert 0 < len(g["dm_corridx_0.35"]) < len(g["dm_corridx_1"])
+    nbr = g["nbr"]
+    vp2, wn2 = O.warp(g["verts"], g["node_dq"][nbr], g["node_pos"][nbr], g["node_w"][nbr], normal=g["norms"], m_lw=g["lw"])
+    best2, _, _ = O.closest_correspondences(vp2, wn2, g["lverts"], k, 0.2)
+    assert np.array_equal(best2, g["nr_corr"])          # prune_result=False keeps every row (fusion.py:276)

@@ -13,7 +13,7 @@ plain arrays the caller fills.
 import numpy as np
 import torch
 
-from . import kernels, solve as _solve
+from . import graph as _graph, io as _io, kernels, solve as _solve
 from .device import f32_exact, require_gpu, to_device, torch_dtype
 
 
@@ -284,3 +284,45 @@ class Fusion:
         x1 = (qmul(qmul(r, P), rc) + 2.0 * qmul(d, rc))[:, 1:]
         n1 = qmul(qmul(r, Nq), rc)[:, 1:]
         return x1, n1
+
+    # ------------------------------------------------------------------ graph maintenance (§8(f) rank 3)
+    def marching_cubes(self, tsdf=None, step_size=0, band=1.0):
+        """Stand-in for skimage's marching cubes (reference core/fusion.py:554-568): surface samples
+        of csrc/dfh_extract.hip as vertices, normalised TSDF gradient as normals, no faces."""
+        from .pipeline import extract_surface_samples
+        if tsdf is not None:
+            live = self._live_to_device(tsdf)
+            pos, nrm = extract_surface_samples(live, torch.ones_like(live), band)
+            return pos.cpu().numpy(), None, nrm.cpu().numpy(), None
+        self._ensure_volumes()
+        w = self._Wt if float(self._Wt.max()) > 0 else torch.ones_like(self._T)
+        pos, nrm = extract_surface_samples(self._T, w, band)
+        self._vertices, self._faces, self._normals = pos.cpu().numpy(), None, nrm.cpu().numpy()
+
+    def construct_graph(self):
+        """Reference core/fusion.py:101-123 (needs `_vertices` and `_radius`)."""
+        if self._vertices is None or getattr(self, '_radius', None) is None:
+            raise ValueError('construct_graph needs _vertices and _radius')
+        self._nodes, self._kdtree, self._neighbor_look_up = _graph.construct_graph(self._vertices, self._radius, self._knn)
+
+    def _dq_blend_kdtree(self, pos):
+        d, loc = self._kdtree.query(pos, k=self._knn)                       # core/fusion.py:529
+        return self.dq_blend(pos, [self._nodes[i][2] for i in np.atleast_1d(loc)], np.atleast_1d(loc))
+
+    def update_graph(self, refresh_surface=True):
+        """Reference core/fusion.py:201-239: refresh the surface, re-anchor the nodes, insert nodes
+        for unsupported vertices, rebuild the lookup, drop the live-frame data, write the warp field."""
+        if refresh_surface:
+            self.marching_cubes()
+        self._nodes, self._kdtree, self._neighbor_look_up, n_new = _graph.update_graph(
+            self._nodes, self._kdtree, self._vertices, self._radius, self._knn, self._dq_blend_kdtree)
+        self._curr_tsdf = None
+        self._correspondences = []
+        self._workspace_key = None
+        if self._write_warpfield:
+            self.write_warp_field(getattr(self, 'DATA_PATH', '.'), 'test')
+        return n_new
+
+    def write_warp_field(self, path, filename):
+        """Reference core/fusion.py:571-573."""
+        return _io.write_warp_field(self._nodes, path, filename, self._itercounter)

@@ -387,7 +387,68 @@ def g7():
     print("g7 ok: kept", len(out["dm_corridx_1"]), len(out["dm_corridx_0.35"]), "of", V)
 
 
+# ---------------------------------------------------------------------------- G8
+def g8():
+    """Graph maintenance (uniform_sample, construct_graph, update_graph with marching cubes patched
+    out) and the file readers (load_sdf on a file written by this package's writer, read_proj_matrix)."""
+    import tempfile
+    from core.sdf import load_sdf
+    rng = np.random.default_rng(808)
+    V, k = 260, 4
+    d = rng.normal(size=(V, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    verts = 16 + 8 * d
+    out = dict(verts=verts, knn=k)
+    us_v, us_i = util.uniform_sample(verts, 3.1)
+    out["us_v"], out["us_i"], out["radius"] = us_v, us_i, 3.1
+    fu = Fusion.__new__(Fusion)
+    fu._vertices, fu._radius, fu._knn, fu._verbose, fu._nodes = verts, 3.1, k, False, []
+    fu.construct_graph()
+    out["cg_idx"] = np.array([n[0] for n in fu._nodes])
+    out["cg_pos"] = np.array([n[1] for n in fu._nodes])
+    out["cg_dq"] = np.array([n[2] for n in fu._nodes])
+    out["cg_w"] = np.array([n[3] for n in fu._nodes])
+    out["cg_lookup"] = np.array(fu._neighbor_look_up)
+    # update_graph: new surface = old vertices + an extra patch no node supports
+    d2 = rng.normal(size=(60, 3)); d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    verts2 = np.concatenate([verts[:200] + 0.05 * rng.normal(size=(200, 3)), np.array([34.0, 16, 16]) + 5 * d2])
+    for i in range(len(fu._nodes)):
+        nd = fu._nodes[i]
+        fu._nodes[i] = (nd[0], nd[1], small_dq(rng, 0.05, 0.3), nd[3])
+    out["ug_dq_in"] = np.array([n[2] for n in fu._nodes])
+
+    def fake_mc(tsdf=None, step_size=0):
+        fu._vertices = verts2
+    fu.marching_cubes = fake_mc
+    fu._write_warpfield = False
+    quiet(fu.update_graph)
+    out["verts2"] = verts2
+    out["ug_idx"] = np.array([n[0] for n in fu._nodes])
+    out["ug_pos"] = np.array([n[1] for n in fu._nodes])
+    out["ug_dq"] = np.array([np.asarray(n[2], dtype=np.float64) for n in fu._nodes])
+    out["ug_w"] = np.array([n[3] for n in fu._nodes])
+    out["ug_lookup"] = np.array(fu._neighbor_look_up)
+    # file formats
+    _spec2 = importlib.util.spec_from_file_location("dfio", os.path.join(ROOT, "dynamicfusion_body_amd", "io.py"))
+    dfio = importlib.util.module_from_spec(_spec2); _spec2.loader.exec_module(dfio)
+    vol = rng.normal(size=(5, 6, 8)).astype(np.float32)
+    cp = rng.normal(size=(5, 6, 8, 3)).astype(np.float32)
+    bmin, bmax = np.array([4.9, 0.0, -1.5]), np.array([59.1, 64.0, 64.25])
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, "t.dist")
+        dfio.write_sdf(fn, bmin, bmax, vol, cp)
+        a, b, v, c = quiet(load_sdf, fn, read_closest_points=True)
+        out["sdf_bytes"] = np.frombuffer(open(fn, "rb").read(), dtype=np.uint8)
+        out["sdf_bmin"], out["sdf_bmax"], out["sdf_vol"], out["sdf_cp"] = a, b, np.ascontiguousarray(v), np.ascontiguousarray(c)
+        pn = os.path.join(td, "proj0.txt")
+        txt = "2000.5 0 800 12.25\n0 -2000.25 600 -3e-1\n0 0 1 5.5\n"
+        open(pn, "w").write(txt)
+        out["proj_txt"] = np.frombuffer(txt.encode(), dtype=np.uint8)
+        out["proj_out"] = util.read_proj_matrix(pn)
+    np.savez_compressed(os.path.join(HERE, "g8_graph_io.npz"), **out)
+    print("g8 ok: nodes", len(out["cg_idx"]), "->", len(out["ug_idx"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()

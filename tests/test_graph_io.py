@@ -1,0 +1,68 @@
+"""CPU: deformation-graph maintenance and file formats against the
+reference's outputs (golden g8: uniform_sample, construct_graph, update_graph with marching cubes
+patched out, load_sdf, read_proj_matrix)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from dynamicfusion_body_amd import Fusion, graph, io
+
+
+def test_uniform_sample_and_construct_graph(golden):
+    g = golden("g8_graph_io")
+    v, i = graph.uniform_sample(g["verts"], float(g["radius"]))
+    assert np.array_equal(i, g["us_i"]) and np.array_equal(v, g["us_v"])
+    e_v, e_i = graph.uniform_sample([], 1.0)
+    assert e_v.size == 0 and e_i.size == 0
+    nodes, kd, lookup = graph.construct_graph(g["verts"], float(g["radius"]), int(g["knn"]))
+    assert np.array_equal(np.array([n[0] for n in nodes]), g["cg_idx"])
+    assert np.array_equal(np.array([n[1] for n in nodes]), g["cg_pos"])
+    assert np.array_equal(np.array([n[2] for n in nodes]), g["cg_dq"]) and nodes[0][2].dtype == np.float32
+    assert np.array_equal(np.array([n[3] for n in nodes]), g["cg_w"])
+    assert np.array_equal(np.array(lookup), g["cg_lookup"])
+
+
+def test_update_graph_matches_reference(golden):
+    g = golden("g8_graph_io")
+    k = int(g["knn"])
+    fu = Fusion(np.zeros((4, 4, 4)), 1.0, knn=k, write_warpfield=False)
+    fu._vertices, fu._radius = g["verts"], float(g["radius"])
+    fu.construct_graph()
+    fu._nodes = [(n[0], n[1], g["ug_dq_in"][i], n[3]) for i, n in enumerate(fu._nodes)]
+    fu._vertices = g["verts2"]
+    n_new = fu.update_graph(refresh_surface=False)
+    assert n_new == len(g["ug_idx"]) - len(g["cg_idx"]) and n_new > 0
+    assert np.array_equal(np.array([n[0] for n in fu._nodes]), g["ug_idx"])
+    assert np.array_equal(np.array([n[1] for n in fu._nodes]), g["ug_pos"])
+    assert np.abs(np.array([np.asarray(n[2], dtype=np.float64) for n in fu._nodes]) - g["ug_dq"]).max() <= 1e-14
+    assert np.array_equal(np.array([n[3] for n in fu._nodes]), g["ug_w"])
+    assert np.array_equal(np.array(fu._neighbor_look_up), g["ug_lookup"])
+    assert fu._curr_tsdf is None and fu._correspondences == []
+
+
+def test_file_formats(golden, tmp_path):
+    g = golden("g8_graph_io")
+    fn = tmp_path / "t.dist"
+    fn.write_bytes(g["sdf_bytes"].tobytes())
+    bmin, bmax, vol, cp = io.load_sdf(str(fn), read_closest_points=True)
+    assert np.array_equal(bmin, g["sdf_bmin"]) and np.array_equal(bmax, g["sdf_bmax"])
+    assert vol.shape == (5, 6, 8) and np.array_equal(vol, g["sdf_vol"]) and np.array_equal(cp, g["sdf_cp"])
+    _, _, vol2, cp2 = io.load_sdf(str(fn))
+    assert np.array_equal(vol2, vol) and cp2 is None
+    io.write_sdf(str(tmp_path / "u.dist"), bmin, bmax, vol, cp)                  # writer is the reader's inverse
+    assert (tmp_path / "u.dist").read_bytes() == g["sdf_bytes"].tobytes()
+    (tmp_path / "bad.dist").write_bytes(g["sdf_bytes"].tobytes()[:100])
+    with pytest.raises(ValueError):
+        io.load_sdf(str(tmp_path / "bad.dist"))
+    pn = tmp_path / "proj0.txt"
+    pn.write_bytes(g["proj_txt"].tobytes())
+    assert np.array_equal(io.read_proj_matrix(str(pn)), g["proj_out"])
+    # warp-field pickle: the reference's layout (list of 4-tuples), file name <name>__<iter>.p
+    nodes = [(3, np.array([1.0, 2, 3]), np.arange(8.0), 6.2)]
+    f = io.write_warp_field(nodes, str(tmp_path), "test", 7)
+    assert os.path.basename(f) == "test__7.p"
+    back = pickle.load(open(f, "rb"))
+    assert back[0][0] == 3 and np.array_equal(back[0][2], np.arange(8.0)) and back[0][3] == 6.2
+    assert io.read_warp_field(f)[0][0] == 3

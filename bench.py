@@ -260,6 +260,21 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
 
+    # measured device-copy ceiling (float4 copy of 1 GiB, far beyond the 256 MiB Infinity Cache)
+    src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    c1.record()
+    torch.cuda.synchronize()
+    ceil_gbs = 5 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del src, dst
+    out["roofline"]["copy_ceiling_GBps"] = ceil_gbs
+    out["roofline"]["frac_of_copy_ceiling"] = achieved / ceil_gbs
     tr = pmc_traffic("integrate_depth_kernel", R)
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]

@@ -244,3 +244,39 @@ def test_config2_256_full_volume_vs_oracle(angle):
         kernels.integrate_depth(T2[a:b], W2[a:b], d, K, np.linalg.inv(K), lw, scale, center, tdist,
                                 tsdf_res=R, res=(R, R, R), x_range=(a, b))
     assert torch.equal(T2, T) and torch.equal(W2, W)
+
+
+def test_config4_512_size_independent_properties():
+    """BASELINE config 4 grid (512^3, 1280x720 depth) without an oracle run: (1) integrating the
+    same view again leaves T unchanged (the running average of equal values) and counts w up to
+    wmax; (2) eight axis-0 slabs reproduce the full sweep bit for bit; (3) the float64-volume exact
+    kernel and the float32 fast path agree on the update mask of every voxel."""
+    R = 512
+    H, W_, fx, cx, cy = scene.CAMERAS["C5"]
+    K = scene.intrinsics(fx, cx, cy); Kinv = np.linalg.inv(K)
+    scale, center, tdist = scene.grid_params(R)
+    lw = scene.view_extrinsic(-30.0)
+    d = torch.from_numpy(scene.render_depth(K, lw, H, W_, dtype=np.float32)).cuda()
+    T = torch.full((R, R, R), tdist, dtype=torch.float32, device="cuda"); Wt = torch.zeros_like(T)
+    kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist, 3.0)
+    T1, W1 = T.clone(), Wt.clone()
+    upd = W1 > 0
+    assert 0.3 < float(upd.float().mean()) < 0.8
+    for n in (2, 3, 4):
+        kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist, 3.0)
+        assert torch.equal(Wt > 0, upd)
+        assert float(Wt[upd].min()) == float(min(n, 3)) and float(Wt[upd].max()) == float(min(n, 3))
+        assert float((T - T1).abs().max()) <= 4 * n * F32_EPS * float(T1.abs().max())
+        assert torch.equal(T[~upd], T1[~upd])
+    # slabs
+    Ts = torch.full((R, R, R), tdist, dtype=torch.float32, device="cuda"); Ws = torch.zeros_like(Ts)
+    for r in range(8):
+        a, b = r * 64, (r + 1) * 64
+        kernels.integrate_depth(Ts[a:b], Ws[a:b], d, K, Kinv, lw, scale, center, tdist, 3.0, tsdf_res=R, res=(R, R, R), x_range=(a, b))
+    assert torch.equal(Ts, T1) and torch.equal(Ws, W1)
+    del Ts, Ws, T
+    # exact fp64 kernel vs filtered fast path: same mask on all 134 M voxels
+    T64 = torch.full((R, R, R), tdist, dtype=torch.float64, device="cuda"); W64 = torch.zeros_like(T64)
+    kernels.integrate_depth(T64, W64, d, K, Kinv, lw, scale, center, tdist, 3.0)
+    assert torch.equal(W64 > 0, upd)
+    assert float((T64.float() - T1).abs().max()) <= 4 * F32_EPS * float(T1.abs().max())

@@ -826,6 +826,208 @@ __global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double 
     if (lane == 0 && contrib != 0.0) atomicAdd(scal + 2, contrib);
 }
 
+// ---- persistent PCG: the whole iteration loop in one launch --------------------------------------
+// Same arithmetic as pcg_spmv_kernel + pcg_update_xr_kernel, but every wave owns ONE node row for
+// the whole solve: its 6x6 blocks (up to kRowCache per lane slot), its rows of Minv and its six
+// entries of x, r, z, p stay in registers; per iteration only the neighbours' (z, p_prev) are read
+// (agent-scope loads) and two grid-wide barriers replace the two kernel boundaries.  The grid is
+// sized so that all workgroups are co-resident (<= one per CU); the barrier spin is bounded and an
+// abort flag makes every wave leave if one ever times out (x is then NaN, never a hang).
+constexpr int kRowCache = 3;               // blocks per lane slot held in registers (rows <= 30 blocks)
+constexpr unsigned kSpinLimit = 1u << 22;  // ~seconds
+constexpr int kMaxPcgBlocks = 512;         // persistent path only for grids up to this many workgroups
+
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Grid-wide sum that doubles as the grid barrier.  `slots` = gridDim.x doubles, all-zero bits
+// before the launch (the host memsets them), used by exactly one reduction.  Every workgroup adds
+// its waves' values in LDS (fixed order) and publishes the partial with an agent-coherent store; a
+// partial whose bits are all zero is published as -0.0, so "bits != 0" is the arrival flag.  Wave 0
+// then polls all slots and adds them in a fixed order (same bits every run and on every rank).
+// Everything a wave published before (agent-coherent stores followed by s_waitcnt 0) is visible to
+// whoever has seen its workgroup's partial.  No cache-wide fences and no read-modify-write atomics:
+// per reduction the critical path is store -> poll.  The spin is bounded and an abort flag makes
+// every workgroup leave if one ever times out.  Returns false (block-uniform) on abort.
+struct BarrierLds {
+    double wave_part[16];
+    double total;
+    int ok;
+};
+
+__device__ __forceinline__ bool grid_sum(double *slots, unsigned *abort_flag, BarrierLds *lds, double wave_val /* lane 0 */,
+                                         double *sum_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    __builtin_amdgcn_s_waitcnt(0);                      // this wave's published z / p have reached the coherence point
+    if (lane == 0) lds->wave_part[wave] = wave_val;
+    __syncthreads();
+    if (wave == 0) {
+        if (lane == 0) {
+            double v = 0.0;
+            for (int w = 0; w < waves; ++w) v += lds->wave_part[w];
+            if (__double_as_longlong(v) == 0) v = -0.0;
+            st_agent(slots + blockIdx.x, v);
+        }
+        const int nb = (int)gridDim.x;
+        unsigned spins = 0;
+        int ok = 1;
+        double tot = 0.0;
+        if (nb <= 64) {
+            // one slot per lane; two polls in flight so that a new arrival is seen half a round trip sooner
+            const double *my = slots + (lane < nb ? lane : 0);
+            double t0 = ld_agent(my);
+            for (;;) {
+                const double t1 = ld_agent(my);
+                if (__all(lane >= nb || __double_as_longlong(t0) != 0)) break;
+                t0 = ld_agent(my);
+                if (__all(lane >= nb || __double_as_longlong(t1) != 0)) { t0 = t1; break; }
+                if (++spins > kSpinLimit || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+            double v = lane < nb ? t0 : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            tot = v;
+        } else {
+            for (;;) {
+                double v = 0.0;
+                bool all = true;
+                for (int b = lane; b < nb; b += 64) {
+                    const double t = ld_agent(slots + b);
+                    all = all && (__double_as_longlong(t) != 0);
+                    v += t;
+                }
+                if (__all(all)) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    tot = v;
+                    break;
+                }
+                if (++spins > kSpinLimit || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (lane == 0) { lds->total = tot; lds->ok = ok; }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    *sum_out = lds->total;
+    return lds->ok != 0;
+}
+
+__global__ __launch_bounds__(1024) void pcg_persistent_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col,
+                                                               const double *__restrict__ vals, int N, int iters,
+                                                               const double *__restrict__ Minv, double *__restrict__ x,
+                                                               const double *__restrict__ r0, double *z, double *pA, double *pB,
+                                                               double *scal, double *part, unsigned *abort_flag) {
+    __shared__ BarrierLds lds;
+    const int lane = threadIdx.x & 63;
+    const int waves = blockDim.x >> 6;
+    const int a = blockIdx.x * waves + (threadIdx.x >> 6);
+    const bool row = a < N;
+    const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63 idle in the SpMV
+    const int beg = row ? row_ptr[a] : 0, end = row ? row_ptr[a + 1] : 0;
+    // register cache of this row's blocks: lane (slot, i) holds row i of blocks beg+slot+10c
+    double Bc[kRowCache][6];
+    int cj[kRowCache];
+#pragma unroll
+    for (int c = 0; c < kRowCache; ++c) {
+        const int b = beg + slot + 10 * c;
+        const bool have = slot < 10 && b < end;
+        cj[c] = have ? col[b] : -1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Bc[c][j] = have ? vals[36 * (size_t)b + 6 * i + j] : 0.0;
+    }
+    const bool lead = row && lane < 6;
+    double Mi[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Mi[j] = lead ? Minv[36 * (size_t)a + 6 * lane + j] : 0.0;
+    double xi = 0.0, ri = lead ? r0[6 * a + lane] : 0.0, zi = lead ? z[6 * a + lane] : 0.0, pi = 0.0;
+    double rz_prev = 0.0, rz_cur = ld_agent(scal + 2);         // rz0 from pcg_init_kernel (previous launch)
+    double *p_prev = pA, *p_cur = pB;
+    const unsigned nblk = gridDim.x;
+    bool ok = true;
+    for (int it = 0; it < iters && ok; ++it) {
+        const double beta = rz_prev != 0.0 ? rz_cur / rz_prev : 0.0;
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < kRowCache; ++c) {
+            // lane (slot, i) fetches entry i of its neighbour's new direction; the six lanes of the slot trade them
+            const int j6 = 6 * (cj[c] >= 0 ? cj[c] : 0) + i;
+            const double qi = slot < 10 ? ld_agent(z + j6) + beta * ld_agent(p_prev + j6) : 0.0;
+            const int base = 6 * slot;
+            const double q0 = __shfl(qi, base + 0, 64), q1 = __shfl(qi, base + 1, 64), q2 = __shfl(qi, base + 2, 64);
+            const double q3 = __shfl(qi, base + 3, 64), q4 = __shfl(qi, base + 4, 64), q5 = __shfl(qi, base + 5, 64);
+            if (cj[c] >= 0)
+                acc += ((Bc[c][0] * q0 + Bc[c][1] * q1) + (Bc[c][2] * q2 + Bc[c][3] * q3)) + (Bc[c][4] * q4 + Bc[c][5] * q5);
+        }
+        if (slot < 10) {
+            for (int b = beg + slot + 10 * kRowCache; b < end; b += 10) {      // rows wider than the cache
+                const double *B = vals + 36 * (size_t)b + 6 * i;
+                const double *zj = z + 6 * col[b];
+                const double *pj = p_prev + 6 * col[b];
+                const double q0 = ld_agent(zj + 0) + beta * ld_agent(pj + 0), q1 = ld_agent(zj + 1) + beta * ld_agent(pj + 1);
+                const double q2 = ld_agent(zj + 2) + beta * ld_agent(pj + 2), q3 = ld_agent(zj + 3) + beta * ld_agent(pj + 3);
+                const double q4 = ld_agent(zj + 4) + beta * ld_agent(pj + 4), q5 = ld_agent(zj + 5) + beta * ld_agent(pj + 5);
+                acc += ((B[0] * q0 + B[1] * q1) + (B[2] * q2 + B[3] * q3)) + (B[4] * q4 + B[5] * q5);
+            }
+        }
+        double y = acc;
+#pragma unroll
+        for (int k = 1; k < 10; ++k) {
+            const double o = __shfl(acc, lane + 6 * k, 64);
+            y += (lane + 6 * k < 60) ? o : 0.0;
+        }
+        double contrib = 0.0;
+        if (lead) {
+            pi = zi + beta * pi;
+            st_agent(p_cur + 6 * a + lane, pi);
+            contrib = pi * y;
+        }
+        contrib += __shfl_down(contrib, 4, 64);
+        contrib += __shfl_down(contrib, 2, 64);
+        contrib += __shfl_down(contrib, 1, 64);
+        double pAp;
+        ok = grid_sum(part + (size_t)(2 * it) * nblk, abort_flag, &lds, contrib, &pAp);
+        if (!ok) break;
+        const double alpha = pAp != 0.0 ? rz_cur / pAp : 0.0;
+        if (lead) {
+            xi += alpha * pi;
+            ri = ri - alpha * y;
+        }
+        double zz = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) zz += Mi[j] * __shfl(ri, j, 64);
+        contrib = 0.0;
+        if (lead) {
+            zi = zz;
+            st_agent(z + 6 * a + lane, zi);
+            contrib = ri * zi;
+        }
+        contrib += __shfl_down(contrib, 4, 64);
+        contrib += __shfl_down(contrib, 2, 64);
+        contrib += __shfl_down(contrib, 1, 64);
+        double rz_next;
+        ok = grid_sum(part + (size_t)(2 * it + 1) * nblk, abort_flag, &lds, contrib, &rz_next);
+        if (!ok) break;
+        rz_prev = rz_cur;
+        rz_cur = rz_next;
+        double *t = p_prev; p_prev = p_cur; p_cur = t;
+    }
+    if (lead) x[6 * a + lane] = ok ? xi : __builtin_nan("");
+}
+
 // dq_a <- exp(xi_a) (x) dq_a  (exp: rotation exp(omega), translation v; oracle/gn_np.py)
 __global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ node_dq, const double *__restrict__ xi, int N,
                                                            double step) {
@@ -1041,8 +1243,9 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
 
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
     if (n_nodes <= 0 || iters < 0) return 0;
-    // Minv (36N) + r,pA,Ap,z,pB (5*6N) + scalars (3 per iteration + 6)
-    return sizeof(double) * ((size_t)36 * n_nodes + (size_t)30 * n_nodes + 3 * ((size_t)iters + 2));
+    // Minv (36N) + r,pA,Ap,z,pB (5*6N) + scalars (3 per iteration + 6) + per-workgroup partial sums
+    return sizeof(double) * ((size_t)36 * n_nodes + (size_t)30 * n_nodes + 3 * ((size_t)iters + 2) +
+                             2 * (size_t)iters * (((size_t)n_nodes + 3) / 4));
 }
 
 int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
@@ -1061,11 +1264,29 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
     double *pB = ws; ws += N6;
     double *pA = ws; ws += N6;                    // pA and the scalars are adjacent: one memset zeroes both
     double *scal = ws;                            // (beta = 0 in iteration 0 must not meet NaN garbage in pA)
-    DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + 3 * ((size_t)iters + 2)), s));
+    DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + 3 * ((size_t)iters + 2) + 2 * (size_t)iters * (((size_t)n_nodes + 3) / 4)), s));
     PcgParams p{n_nodes, lm_abs, lm_rel};
     dim3 grid((n_nodes + 255) / 256), block(256);
     // scal[0..2] belongs to the init (rz0 in scal[2] so that iteration 0 reads it as "rz_next")
     hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, z, scal + 2);
+    // One persistent launch when every row can have its own co-resident wave (N <= 16 waves x #CUs)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        DFH_HIP_CHECK(hipGetDevice(&dev));
+        DFH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    int wpb = n_nodes <= 8 * 64 ? 8 : 16;             // fat workgroups: <= 64 partial sums per reduction where possible
+    if (const char *e = getenv("DFH_PCG_WPB")) { const int v = atoi(e); if (v == 4 || v == 8) wpb = v; }
+    const int nblk = (n_nodes + wpb - 1) / wpb;
+    if (nblk <= n_cu && nblk <= kMaxPcgBlocks && !getenv("DFH_PCG_MULTILAUNCH")) {
+        unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
+        double *part = scal + 3 * ((size_t)iters + 2);                                    // 2 reductions per iteration x nblk slots
+        hipLaunchKernelGGL(pcg_persistent_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, n_nodes, iters, Minv, x_out,
+                           r, z, pA, pB, scal, part, flag);
+        DFH_HIP_CHECK(hipGetLastError());
+        return DFH_OK;
+    }
     double *p_prev = pA, *p_cur = pB;
     for (int it = 0; it < iters; ++it) {
         double *sc = scal + 3 * ((size_t)it + 1);

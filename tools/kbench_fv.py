@@ -11,7 +11,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--nodes", type=int, default=512)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--lib", default=None, help="alternative libdfusion_hip.so (kernel experiments)")
 a = ap.parse_args()
+if a.lib:
+    from dynamicfusion_body_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 R, N, k = a.res, a.nodes, 4
 tdist = 4.0
 g = torch.arange(R, device="cuda", dtype=torch.float32)

@@ -927,17 +927,37 @@ __device__ __forceinline__ bool grid_sum(double *slots, unsigned *abort_flag, Ba
 }
 
 __global__ __launch_bounds__(1024) void pcg_persistent_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col,
-                                                               const double *__restrict__ vals, int N, int iters,
-                                                               const double *__restrict__ Minv, double *__restrict__ x,
-                                                               const double *__restrict__ r0, double *z, double *pA, double *pB,
-                                                               double *scal, double *part, unsigned *abort_flag) {
+                                                               double *vals, const double *__restrict__ rhs, const PcgParams prm,
+                                                               int iters, double *__restrict__ x, double *z, double *pA, double *pB,
+                                                               double *part, unsigned *abort_flag) {
     __shared__ BarrierLds lds;
+    const int N = prm.N;
     const int lane = threadIdx.x & 63;
     const int waves = blockDim.x >> 6;
     const int a = blockIdx.x * waves + (threadIdx.x >> 6);
     const bool row = a < N;
     const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63 idle in the SpMV
     const int beg = row ? row_ptr[a] : 0, end = row ? row_ptr[a + 1] : 0;
+    const bool lead = row && lane < 6;
+    // -- what pcg_init_kernel does, per row: damp the diagonal block (the damping lives in the
+    //    matrix), invert it (block-Jacobi preconditioner), r0 = -rhs, z0 = Minv r0 -------------
+    const int dblk = lead ? find_block(row_ptr, col, a, a) : -1;
+    double Mi[6];
+    {
+        double D[36], Di[36];
+#pragma unroll
+        for (int t = 0; t < 36; ++t) D[t] = dblk >= 0 ? vals[36 * (size_t)dblk + t] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) D[7 * t] = D[7 * t] + prm.lm_abs + prm.lm_rel * D[7 * t];
+        inv6(D, Di);                                            // lanes 0..5 redundantly: same cost as one lane
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double v = Di[j];
+#pragma unroll
+            for (int rr = 1; rr < 6; ++rr) v = lane == rr ? Di[6 * rr + j] : v;
+            Mi[j] = lead ? v : 0.0;
+        }
+    }
     // register cache of this row's blocks: lane (slot, i) holds row i of blocks beg+slot+10c
     double Bc[kRowCache][6];
     int cj[kRowCache];
@@ -948,16 +968,34 @@ __global__ __launch_bounds__(1024) void pcg_persistent_kernel(const int *__restr
         cj[c] = have ? col[b] : -1;
 #pragma unroll
         for (int j = 0; j < 6; ++j) Bc[c][j] = have ? vals[36 * (size_t)b + 6 * i + j] : 0.0;
+        if (have && cj[c] == a) Bc[c][i] = Bc[c][i] + prm.lm_abs + prm.lm_rel * Bc[c][i];     // same expression as D above
     }
-    const bool lead = row && lane < 6;
-    double Mi[6];
+    __builtin_amdgcn_s_waitcnt(0);                              // every read of the undamped diagonal has returned
+    if (dblk >= 0) {
+        double dv = 0.0;
+        {
+            const double d0 = vals[36 * (size_t)dblk + 7 * lane];
+            dv = d0 + prm.lm_abs + prm.lm_rel * d0;
+        }
+        vals[36 * (size_t)dblk + 7 * lane] = dv;
+    }
+    double xi = 0.0, ri = lead ? -rhs[6 * a + lane] : 0.0, pi = 0.0;
+    double zi = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) Mi[j] = lead ? Minv[36 * (size_t)a + 6 * lane + j] : 0.0;
-    double xi = 0.0, ri = lead ? r0[6 * a + lane] : 0.0, zi = lead ? z[6 * a + lane] : 0.0, pi = 0.0;
-    double rz_prev = 0.0, rz_cur = ld_agent(scal + 2);         // rz0 from pcg_init_kernel (previous launch)
+    for (int j = 0; j < 6; ++j) zi += Mi[j] * __shfl(ri, j, 64);
+    double contrib = 0.0;
+    if (lead) {
+        st_agent(z + 6 * a + lane, zi);
+        contrib = ri * zi;
+    }
+    contrib += __shfl_down(contrib, 4, 64);
+    contrib += __shfl_down(contrib, 2, 64);
+    contrib += __shfl_down(contrib, 1, 64);
+    double rz_prev = 0.0, rz_cur = 0.0;
+    bool ok = grid_sum(part, abort_flag, &lds, contrib, &rz_cur);
+    part += gridDim.x;
     double *p_prev = pA, *p_cur = pB;
     const unsigned nblk = gridDim.x;
-    bool ok = true;
     for (int it = 0; it < iters && ok; ++it) {
         const double beta = rz_prev != 0.0 ? rz_cur / rz_prev : 0.0;
         double acc = 0.0;
@@ -989,7 +1027,7 @@ __global__ __launch_bounds__(1024) void pcg_persistent_kernel(const int *__restr
             const double o = __shfl(acc, lane + 6 * k, 64);
             y += (lane + 6 * k < 60) ? o : 0.0;
         }
-        double contrib = 0.0;
+        contrib = 0.0;
         if (lead) {
             pi = zi + beta * pi;
             st_agent(p_cur + 6 * a + lane, pi);
@@ -1245,7 +1283,7 @@ size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
     if (n_nodes <= 0 || iters < 0) return 0;
     // Minv (36N) + r,pA,Ap,z,pB (5*6N) + scalars (3 per iteration + 6) + per-workgroup partial sums
     return sizeof(double) * ((size_t)36 * n_nodes + (size_t)30 * n_nodes + 3 * ((size_t)iters + 2) +
-                             2 * (size_t)iters * (((size_t)n_nodes + 3) / 4));
+                             2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4));
 }
 
 int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
@@ -1264,11 +1302,9 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
     double *pB = ws; ws += N6;
     double *pA = ws; ws += N6;                    // pA and the scalars are adjacent: one memset zeroes both
     double *scal = ws;                            // (beta = 0 in iteration 0 must not meet NaN garbage in pA)
-    DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + 3 * ((size_t)iters + 2) + 2 * (size_t)iters * (((size_t)n_nodes + 3) / 4)), s));
+    DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + 3 * ((size_t)iters + 2) + 2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4)), s));
     PcgParams p{n_nodes, lm_abs, lm_rel};
     dim3 grid((n_nodes + 255) / 256), block(256);
-    // scal[0..2] belongs to the init (rz0 in scal[2] so that iteration 0 reads it as "rz_next")
-    hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, z, scal + 2);
     // One persistent launch when every row can have its own co-resident wave (N <= 16 waves x #CUs)
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -1281,12 +1317,14 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
     const int nblk = (n_nodes + wpb - 1) / wpb;
     if (nblk <= n_cu && nblk <= kMaxPcgBlocks && !getenv("DFH_PCG_MULTILAUNCH")) {
         unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
-        double *part = scal + 3 * ((size_t)iters + 2);                                    // 2 reductions per iteration x nblk slots
-        hipLaunchKernelGGL(pcg_persistent_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, n_nodes, iters, Minv, x_out,
-                           r, z, pA, pB, scal, part, flag);
+        double *part = scal + 3 * ((size_t)iters + 2);                                    // (2 per iteration + 1) reductions x nblk slots
+        hipLaunchKernelGGL(pcg_persistent_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, z, pA, pB,
+                           part, flag);
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }
+    // scal[0..2] belongs to the init (rz0 in scal[2] so that iteration 0 reads it as "rz_next")
+    hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, z, scal + 2);
     double *p_prev = pA, *p_cur = pB;
     for (int it = 0; it < iters; ++it) {
         double *sc = scal + 3 * ((size_t)it + 1);

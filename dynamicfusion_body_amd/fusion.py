@@ -10,10 +10,12 @@ on this hot path: the deformation graph is supplied as the re
 core/fusion.py:107-116), and `_vertices/_normals/_correspondences/_neighbor_look_up` are
 plain arrays the caller fills.
 """
+import os
+
 import numpy as np
 import torch
 
-from . import graph as _graph, io as _io, kernels, solve as _solve
+from . import graph as _graph, io as _io, kernels, mesh as _mesh, solve as _solve
 from .device import f32_exact, require_gpu, to_device, torch_dtype
 
 
@@ -286,9 +288,21 @@ class Fusion:
         return x1, n1
 
     # ------------------------------------------------------------------ graph maintenance (§8(f) rank 3)
-    def marching_cubes(self, tsdf=None, step_size=0, band=1.0):
-        """Stand-in for skimage's marching cubes (reference core/fusion.py:554-568): surface samples
-        of csrc/dfh_extract.hip as vertices, normalised TSDF gradient as normals, no faces."""
+    def marching_cubes(self, tsdf=None, step_size=0):
+        """Reference core/fusion.py:554-568: `measure.marching_cubes_lewiner(volume, step_size=...,
+        allow_degenerate=False)` with skimage's default level (min + max) / 2; step_size < 1 means
+        `_marching_cubes_step_size`.  GPU mesh extraction of csrc/dfh_mesh.hip (see mesh.py)."""
+        if step_size < 1:
+            step_size = self._marching_cubes_step_size
+        if tsdf is not None:
+            return _mesh.marching_cubes(self._live_to_device(tsdf), None, step_size, as_numpy=True)
+        self._ensure_volumes()
+        self._vertices, self._faces, self._normals, values = _mesh.marching_cubes(self._T, None, step_size, as_numpy=True)
+        if self._verbose:
+            print("Marching Cubes result: number of extracted vertices is %d" % (len(self._vertices)))
+
+    def surface_samples(self, tsdf=None, band=1.0):
+        """Dense band-voxel samples (csrc/dfh_extract.hip) in place of mesh vertices; not in the reference."""
         from .pipeline import extract_surface_samples
         if tsdf is not None:
             live = self._live_to_device(tsdf)
@@ -298,6 +312,35 @@ class Fusion:
         w = self._Wt if float(self._Wt.max()) > 0 else torch.ones_like(self._T)
         pos, nrm = extract_surface_samples(self._T, w, band)
         self._vertices, self._faces, self._normals = pos.cpu().numpy(), None, nrm.cpu().numpy()
+
+    def write_canonical_mesh(self, path, filename):
+        """Reference core/fusion.py:577-587: index-space OBJ, `v` / `vn` / `f a b c` (1-based)."""
+        self._ensure_volumes()
+        verts, faces, normals, values = _mesh.marching_cubes(self._T, None, 1, as_numpy=True)
+        with open(os.path.join(path, filename), 'w') as f:
+            f.write("".join('v %f %f %f\n' % (v[0], v[1], v[2]) for v in verts))
+            f.write("".join('vn %f %f %f\n' % (n[0], n[1], n[2]) for n in normals))
+            f.write("".join('f %d %d %d\n' % (t[0] + 1, t[1] + 1, t[2] + 1) for t in faces))
+
+    def average_edge_dist_in_face(self, f):
+        """Reference core/fusion.py:593-597."""
+        v1, v2, v3 = (np.asarray(self._vertices[i], dtype=np.float64) for i in f[:3])
+        d = lambda a, b: float(np.sqrt(np.sum((a - b) ** 2)))
+        return (d(v1, v2) + d(v1, v3) + d(v2, v3)) / 3
+
+    def initialize_canonical(self):
+        """What the reference's constructor does after storing the volume (core/fusion.py:86-96): initial
+        marching cubes, `_radius` = subsample_rate x mean edge length of the faces, deformation graph.
+        Separate from __init__ here so that constructing the object does not need a GPU."""
+        self.marching_cubes()
+        V = np.asarray(self._vertices)                                           # fp32, as skimage returns them
+        F = np.asarray(self._faces)
+        if len(F) == 0:
+            raise ValueError('marching cubes found no surface in the canonical volume')
+        e = (np.linalg.norm(V[F[:, 0]] - V[F[:, 1]], axis=1) + np.linalg.norm(V[F[:, 0]] - V[F[:, 2]], axis=1) +
+             np.linalg.norm(V[F[:, 1]] - V[F[:, 2]], axis=1)) / 3                 # average_edge_dist_in_face, :592-596
+        self._radius = self._subsample_rate * np.average(e)                      # :92
+        self.construct_graph()
 
     def construct_graph(self):
         """Reference core/fusion.py:101-123 (needs `_vertices` and `_radius`)."""

@@ -17,11 +17,13 @@ What differs, on purpose:
     (:600-737), which computes something else (SURVEY.md §8(a) row A2);
   * no CPU fallback: without the HIP library / a GPU the hot methods raise.
 """
+import os
+
 import numpy as np
 import torch
 from numpy import linalg as la
 
-from . import kernels, solve as _solve
+from . import kernels, mesh as _mesh, solve as _solve
 from .device import f32_exact, require_gpu, to_device, torch_dtype
 
 
@@ -179,13 +181,25 @@ class FusionDM:
         return _solve.residual_rigid(x, V, Nn, C).cpu().numpy()
 
     # ------------------------------------------------------------------ surface + correspondences
-    def marching_cubes(self, tsdf=None, step_size=1, band=1.0):
-        """Stand-in for skimage's marching cubes (reference core/fusion_dm.py:319-331), which is
-        outside this hot path: band voxels moved onto the zero level set along the TSDF gradient
-        (csrc/dfh_extract.hip) play the role of the mesh vertices, the normalised gradient that of
-        the vertex normals; there are no faces.  Same call shapes: with `tsdf` returns
-        (verts, faces=None, normals, values=None); without, fills `_vertices` / `_normals` from the
-        canonical volume (voxels with w > 0)."""
+    def marching_cubes(self, tsdf=None, step_size=1):
+        """Mesh vertices / faces / normals of the level set; reference core/fusion_dm.py:319-331
+        (`measure.marching_cubes_lewiner(volume, step_size=step_size)`: no level is passed, so skimage's
+        default (min + max) / 2 applies -- reproduced).  With `tsdf` returns (verts, faces, normals,
+        values) as numpy arrays; without, fills `_vertices` / `_faces` / `_normals` from the canonical
+        volume.  Runs on the GPU (csrc/dfh_mesh.hip); conventions and what is pinned: mesh.py."""
+        if step_size < 1:
+            step_size = self._marching_cubes_step_size
+        if tsdf is not None:
+            return _mesh.marching_cubes(self._live_to_device(tsdf), None, step_size, as_numpy=True)
+        self._ensure_volumes()
+        self._vertices, self._faces, self._normals, values = _mesh.marching_cubes(self._T, None, step_size, as_numpy=True)
+        if self._verbose:
+            print("Marching Cubes result: number of extracted vertices is %d" % (len(self._vertices)))
+
+    def surface_samples(self, tsdf=None, band=1.0):
+        """Dense alternative to the mesh vertices for the solve (not in the reference): every band
+        voxel moved onto the zero level set along the TSDF gradient (csrc/dfh_extract.hip), with the
+        normalised gradient as normal.  Same shapes as marching_cubes, faces / values = None."""
         from .pipeline import extract_surface_samples
         if tsdf is not None:
             live = self._live_to_device(tsdf)
@@ -194,6 +208,13 @@ class FusionDM:
         self._ensure_volumes()
         pos, nrm = extract_surface_samples(self._T, self._Wt, band)
         self._vertices, self._faces, self._normals = pos.cpu().numpy(), None, nrm.cpu().numpy()
+
+    def write_canonical_mesh(self, path, filename):
+        """OBJ file of the canonical surface in world coordinates; reference core/fusion_dm.py:339-354
+        (level 0, step 1, degenerate faces dropped; `v` / `vn` / `f a//a b//b c//c`, 1-based)."""
+        self._ensure_volumes()
+        verts, faces, normals, values = _mesh.marching_cubes(self._T, 0.0, 1, as_numpy=True)
+        _mesh.write_obj(os.path.join(path, filename), verts, faces, normals, ind=self._IND)
 
     def setupCorrespondences(self, curr_tsdf, prune_result=True, tolerance=1.0, live_vertices=None):
         """Closest-point correspondences of the canonical vertices in the live surface; reference
@@ -246,15 +267,12 @@ class FusionDM:
         return np.average(np.array(avgs), axis=0), float(np.average(np.array(stds)))
 
     def compute_live_tsdf(self, depths, lws, UseAutoAlignment=False, useICP=False, outputMesh=False,
-                          as_numpy=True):
+                          as_numpy=True, mesh_path='.'):
         """Fuse a set of depth maps into a fresh volume; reference core/fusion_dm.py:95-178.
         The volume stays on the GPU across views; `as_numpy=False` returns the CUDA
         tensors instead of downloading them."""
         if len(depths) != len(lws):
             raise ValueError('length of camera matrix array Ks must equal that of depth maps')   # :96-97
-        if outputMesh:
-            raise NotImplementedError('outputMesh needs marching cubes (core/fusion_dm.py:339-354), '
-                                      'outside this hot path')
         avg = np.array([-0.03, -0.43, -5.6], dtype='float32')       # :106-107
         std = 1.3
         if UseAutoAlignment:
@@ -286,6 +304,8 @@ class FusionDM:
                 self._depthidx = idx
                 self.fuseDepths(depths[idx], lws[idx], T, Wt, scale=12 * std / res, center=avg)
             self._T, self._Wt = T, Wt
+        if outputMesh:                                              # :174-176 (the reference also dumps tsdf_temp.npy; not done)
+            self.write_canonical_mesh(mesh_path, 'test.obj')
         if as_numpy:
             return (self._tsdf, self._tsdfw)
         return (T, Wt)

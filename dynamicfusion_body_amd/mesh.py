@@ -1,0 +1,101 @@
+"""Mesh extraction and the canonical-mesh file: the reference's `marching_cubes` /
+`write_canonical_mesh` (core/fusion_dm.py:319-331,339-354, core/fusion.py:554-568).
+
+`marching_cubes` runs the HIP kernels of csrc/dfh_mesh.hip (count -> scan -> vertices -> faces) and
+has skimage's call shape: (verts, faces, normals, values), with `level=None` meaning
+(min + max) / 2 (skimage's documented default, which is what the reference's `marching_cubes()`
+gets since it passes no level)."""
+import numpy as np
+import torch
+
+from . import _lib
+from .device import current_stream_ptr, dtype_code, require_gpu
+
+
+def marching_cubes(volume, level=None, step_size=1, as_numpy=False, order="reference"):
+    """volume: 3-D CUDA tensor (fp32 / fp64, contiguous).  Returns verts (V,3) fp32 in array-index
+    coordinates, faces (F,3) int32, unit normals (V,3) fp32 pointing down the gradient, values (V,)
+    fp32 -- CUDA tensors, or numpy arrays with as_numpy=True.  Zero-area faces are not emitted
+    (allow_degenerate=False, the only mode the reference uses for its outputs).
+    order="reference": skimage's numbering (faces cube by cube, vertices by first use, unused vertices
+    dropped); order="lattice": vertices by owning lattice point (skips the renumbering pass)."""
+    if order not in ("reference", "lattice"):
+        raise ValueError("order must be 'reference' or 'lattice'")
+    require_gpu()
+    lib = _lib.load()
+    if not (isinstance(volume, torch.Tensor) and volume.is_cuda and volume.dim() == 3 and volume.is_contiguous()):
+        raise ValueError("volume must be a contiguous 3-D CUDA tensor")
+    step = int(step_size)
+    if step < 1:
+        raise ValueError("step_size must be at least 1")                         # skimage raises ValueError too
+    if min(volume.shape) < 2:
+        raise ValueError("Input array must be at least 2x2x2.")
+    if level is None:
+        level = 0.5 * (float(volume.min()) + float(volume.max()))
+    level = float(level)
+    res = _lib.iarr(volume.shape)
+    nbytes = lib.dfh_mc_workspace_bytes(res, step)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=volume.device)
+    totals = torch.zeros(2, dtype=torch.int64, device=volume.device)
+    _lib.check(lib.dfh_mc_count(volume.data_ptr(), dtype_code(volume), res, step, level, ws.data_ptr(), ws.numel() * 8,
+                                totals.data_ptr(), current_stream_ptr()), "dfh_mc_count")
+    nv, nf = (int(v) for v in totals.tolist())
+    if nv >= (1 << 29) or nf >= (1 << 31) // 3:
+        raise ValueError("surface too large for 32-bit mesh indices (%d vertices, %d faces)" % (nv, nf))
+    dev = volume.device
+    verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+    normals = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+    values = torch.empty((nv,), dtype=torch.float32, device=dev)
+    faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
+    _lib.check(lib.dfh_mc_emit(volume.data_ptr(), dtype_code(volume), res, step, level, ws.data_ptr(), ws.numel() * 8,
+                               verts.data_ptr(), normals.data_ptr(), values.data_ptr(), faces.data_ptr(), nv, nf,
+                               current_stream_ptr()), "dfh_mc_emit")
+    if order == "reference":
+        nbytes = lib.dfh_mc_reorder_workspace_bytes(nv, nf)
+        ws2 = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        v2, n2, val2 = torch.empty_like(verts), torch.empty_like(normals), torch.empty_like(values)
+        used = torch.zeros(1, dtype=torch.int64, device=dev)
+        _lib.check(lib.dfh_mc_reorder(verts.data_ptr(), normals.data_ptr(), values.data_ptr(), faces.data_ptr(), nv, nf,
+                                      v2.data_ptr(), n2.data_ptr(), val2.data_ptr(), used.data_ptr(), ws2.data_ptr(),
+                                      ws2.numel() * 8, current_stream_ptr()), "dfh_mc_reorder")
+        nu = int(used.item())
+        verts, normals, values = v2[:nu], n2[:nu], val2[:nu]
+    if as_numpy:
+        return verts.cpu().numpy(), faces.cpu().numpy(), normals.cpu().numpy(), values.cpu().numpy()
+    return verts, faces, normals, values
+
+
+def write_obj(fpath, verts, faces, normals, ind=None):
+    """The reference's OBJ layout (core/fusion_dm.py:339-354): `v x y z` rows, then `vn`, then
+    `f a//a b//b c//c` with 1-based indices, `%f` formatting; `ind` (4x4) maps index space to world
+    (`self._IND`: rotation applied to normals, rotation + translation to vertices)."""
+    verts = np.asarray(verts, dtype=np.float64)
+    normals = np.asarray(normals, dtype=np.float64)
+    faces = np.asarray(faces)
+    if ind is not None:
+        ind = np.asarray(ind, dtype=np.float64)
+        rot, trans = ind[:3, :3], ind[:3, 3]
+        verts = verts @ rot.T + trans
+        normals = normals @ rot.T
+    with open(fpath, "w") as f:
+        f.write("".join("v %f %f %f\n" % (v[0], v[1], v[2]) for v in verts))
+        f.write("".join("vn %f %f %f\n" % (n[0], n[1], n[2]) for n in normals))
+        f.write("".join("f %d//%d %d//%d %d//%d\n" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1) for a, b, c in faces))
+
+
+def read_obj(fpath):
+    """v / vn / f rows of an OBJ file -> (verts, faces as stored, normals); text parsing only."""
+    V, N, F = [], [], []
+    with open(fpath) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                V.append([float(x) for x in t[1:4]])
+            elif t[0] == "vn":
+                N.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                F.append([int(x.split("/")[0]) for x in t[1:4]])
+    return (np.array(V, dtype=np.float64).reshape(-1, 3), np.array(F, dtype=np.int64).reshape(-1, 3),
+            np.array(N, dtype=np.float64).reshape(-1, 3))

@@ -195,6 +195,33 @@ int dfh_surface_count(const void *tsdf, const void *tsdf_w, int vol_dtype, const
 int dfh_surface_emit(const void *tsdf, const void *tsdf_w, int vol_dtype, const int res[3], int x0, double band,
                      const void *workspace, double *pos_out, double *nrm_out, long capacity, void *stream);
 
+/* ---- marching cubes: `_vertices` / `_faces` / `_normals` from a TSDF volume --------------------------
+ * Replaces measure.marching_cubes_lewiner(volume, level, step_size, allow_degenerate=False) as called at
+ * core/fusion_dm.py:319-331,342 and core/fusion.py:554-568 (skimage 0.13.1, a third-party dependency
+ * that is not vendored).  Vertices sit on the edges of the step-subsampled lattice at the linearly
+ * interpolated crossing of `level` (array-index coordinates, fp32 like skimage's), unit normals point
+ * down the gradient (central differences on the lattice), faces are wound with their right-hand normal
+ * up the gradient, zero-area faces are dropped -- the conventions of the reference's own output
+ * meshes/original.obj.  Triangle choice inside a cube and the output order are this library's
+ * (deterministic: vertices by owning lattice point then axis, faces by cube then table order).
+ *   dfh_mc_count : totals_out[0] = vertices, totals_out[1] = faces (device longs); fills `workspace`
+ *   dfh_mc_emit  : writes min(total, capacity) vertices (x3 fp32), normals (x3 fp32), values (max of the
+ *                  edge's two samples, may be NULL) and faces (x3 int32); same workspace, after dfh_mc_count. */
+size_t dfh_mc_workspace_bytes(const int res[3], int step);
+int dfh_mc_count(const void *vol, int vol_dtype, const int res[3], int step, double level, void *workspace,
+                 size_t workspace_bytes, long *totals_out, void *stream);
+int dfh_mc_emit(const void *vol, int vol_dtype, const int res[3], int step, double level, void *workspace,
+                size_t workspace_bytes, float *verts, float *normals, float *values, int *faces, long cap_verts, long cap_faces,
+                void *stream);
+/* The reference's vertex order on top of dfh_mc_emit's output: skimage numbers vertices as its faces create
+ * them and flips the face rows afterwards, i.e. ids increase with first use when rows are read right-to-left
+ * (meshes/original.obj).  Renumbers accordingly (faces rewritten in place, vertex arrays copied to *_out in
+ * the new order), drops vertices no face uses; *used_out (device) = vertices kept. */
+size_t dfh_mc_reorder_workspace_bytes(long n_verts, long n_faces);
+int dfh_mc_reorder(const float *verts_in, const float *normals_in, const float *values_in, int *faces, long n_verts, long n_faces,
+                   float *verts_out, float *normals_out, float *values_out, long *used_out, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,7 +51,7 @@ _SIGNATURES = {
     "dfh_mc_workspace_bytes": (ctypes.c_size_t, [_c_int_p, _int]),
     "dfh_mc_count": (_int, [_vp, _int, _c_int_p, _int, _dbl, _vp, ctypes.c_size_t, _vp, _vp]),
     "dfh_mc_emit": (_int, [_vp, _int, _c_int_p, _int, _dbl, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp, ctypes.c_long, ctypes.c_long,
-                           _vp]),
+                           ctypes.c_long, _vp]),
     "dfh_mc_reorder_workspace_bytes": (ctypes.c_size_t, [ctypes.c_long, ctypes.c_long]),
     "dfh_mc_reorder": (_int, [_vp, _vp, _vp, _vp, ctypes.c_long, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
 }

@@ -1,76 +1,111 @@
 // Marching cubes on the device: `_vertices`, `_faces`, `_normals` from a TSDF volume, the call the
 // reference makes through skimage (measure.marching_cubes_lewiner at core/fusion_dm.py:319-331,342
 // and core/fusion.py:554-568).  skimage's Lewiner tables are a third-party
-// dependency that is absent here, so the triangle table is derived by tools/gen_mc_table.py (same
-// topology rules for every cube, watertight, consistently oriented); what IS pinned by the
-// reference's own output mesh (meshes/original.obj -> tests/golden/g9_mesh.npz): vertices on lattice
-// edges at the linearly interpolated crossing in array-index coordinates, unit normals pointing down
-// the gradient, faces wound with their right-hand normal up the gradient, zero-area faces dropped
-// (allow_degenerate=False).  oracle/mc_np.py states the same computation in numpy.
+// dependency that is absent here, so the triangle table is derived by tools/gen_mc_table.py
+// (watertight, consistently oriented, and for the 88 configurations that occur in the reference's own
+// output mesh meshes/original.obj triangulated exactly as there).  Pinned by that mesh
+// (tests/golden/g9_mesh.npz): vertices on lattice edges at the linearly interpolated crossing in
+// array-index coordinates, unit normals pointing down the gradient, faces wound with their
+// right-hand normal up the gradient, zero-area faces dropped (allow_degenerate=False), face order by
+// cube, vertex order by first use (dfh_mc_reorder); its face array is reproduced bit for bit.
+// oracle/mc_np.py states the same computation in numpy.
 //
-// Layout: one thread per lattice point p = (x, y, z) of the (step-subsampled) volume, z fastest,
-// 256 consecutive points per workgroup.  Point p owns the three edges leaving it along +axis 0/1/2
-// and the cube whose corner 0 it is.  Four launches, no atomics, deterministic output order
-// (vertices by owner point then axis; faces by cube then table order):
-//   mc_count_kernel   per-workgroup {vertices, faces}
-//   mc_scan_kernel    exclusive scan of those pairs (one workgroup), totals
-//   mc_vertex_kernel  code[p] = crossing mask << 29 | index of p's first vertex; positions, normals
-//   mc_face_kernel    faces, looking up the owners' codes
+// Work decomposition: lattice point p = (x, y, z) of the (step-subsampled) volume owns the three
+// edges leaving it along +axis 0/1/2 and the cube whose corner 0 it is.  A tile = one z row (x, y, all z),
+// tiles numbered in C order of the points (the count pass covers 4 rows per workgroup, the emit passes
+// one active row per workgroup: they are latency-bound, so many short workgroups).  No atomics,
+// deterministic output order (vertices by owner point then axis; faces by cube then table order):
+//   mc_count_kernel        per-tile {vertices, faces, active}; signs compared in the volume's own type
+//   mc_scan_chunk_kernel   exclusive scan inside chunks of 2048 tiles   } hierarchical scan
+//   mc_scan_top_kernel     scan of the chunk totals, grand totals       }
+//   mc_active_kernel       compacted list of tiles that emit anything (the emit passes launch only those)
+//   mc_vertex_kernel       code[p] = crossing mask << 29 | index of p's first vertex; positions, normals
+//   mc_face_kernel         faces, looking up the owners' codes
 #include "dfh_common.h"
 #include "dfh_mc_table.h"
 
 namespace dfh {
 
 constexpr int kMcBlock = 256;
+constexpr int kMcRows = 4;                  // z rows (tiles) per workgroup of the count pass
+constexpr int kMcChunk = 2048;              // tiles per scan chunk (256 threads x 8)
 constexpr unsigned kMcBaseMask = (1u << 29) - 1u;
 
 struct McParams {
     int Y, Z;                 // strides of the full volume (elements): x*Y*Z + y*Z + z
     int s;                    // step_size
     int NX, NY, NZ;           // lattice dims = ceil(dim / s)
+    int nseg;                 // 256-point segments per z row
+    int nty;                  // count-pass workgroups along y
     double level;
-    long npts;
+    float lo_f, eq_f;         // fp32 volumes: (double)v > level <=> v > lo_f (largest float <= level);
+                              //               (double)v == level <=> v == eq_f (NaN when level is no float)
+    long ntiles;
 };
 
 template <typename VolT>
-__device__ __forceinline__ double mc_val(const VolT *__restrict__ vol, const McParams &p, int x, int y, int z) {
-    return (double)vol[((size_t)(x * p.s) * p.Y + (size_t)(y * p.s)) * p.Z + (size_t)(z * p.s)];
+__device__ __forceinline__ size_t mc_off(const McParams &p, int x, int y, int z) {
+    return ((size_t)(x * p.s) * p.Y + (size_t)(y * p.s)) * p.Z + (size_t)(z * p.s);
 }
+template <typename VolT>
+__device__ __forceinline__ double mc_val(const VolT *__restrict__ vol, const McParams &p, int x, int y, int z) {
+    return (double)vol[mc_off<VolT>(p, x, y, z)];
+}
+__device__ __forceinline__ bool mc_above(float v, const McParams &p) { return v > p.lo_f; }
+__device__ __forceinline__ bool mc_above(double v, const McParams &p) { return v > p.level; }
+__device__ __forceinline__ bool mc_equal(float v, const McParams &p) { return v == p.eq_f; }
+__device__ __forceinline__ bool mc_equal(double v, const McParams &p) { return v == p.level; }
 
-struct McPoint {
-    int x, y, z;
-    bool inside;              // p < npts
-    double f[8];              // corner values (only those inside the lattice are meaningful)
+struct McSigns {
     unsigned above;           // bit c: corner c exists and value > level
     unsigned eq;              // bit c: corner c exists and value == level
     unsigned cross;           // bit a: owned edge along axis a exists and is crossed
     bool cell;                // the cube with corner 0 = p exists
 };
 
+// The four z rows a point's cube touches: (x,y), (x,y+1), (x+1,y), (x+1,y+1).  Workgroup-uniform, so the
+// address arithmetic is scalar; rows outside the lattice alias row (x,y) and are masked out by hx / hy.
 template <typename VolT>
-__device__ __forceinline__ void mc_load(const VolT *__restrict__ vol, const McParams &p, long idx, McPoint &q) {
-    q.inside = idx < p.npts;
+struct McRows {
+    const VolT *r[4];         // index = ox + 2*oy  (bit 0: +x, bit 1: +y)
+    bool hx, hy;
+};
+
+template <typename VolT>
+__device__ __forceinline__ McRows<VolT> mc_rows(const VolT *__restrict__ vol, const McParams &p, int x, int y) {
+    McRows<VolT> w;
+    w.hx = x + 1 < p.NX;
+    w.hy = y + 1 < p.NY;
+    const size_t sx = (size_t)p.s * p.Y * p.Z, sy = (size_t)p.s * p.Z;
+    const VolT *b = vol + (size_t)x * sx + (size_t)y * sy;
+    w.r[0] = b;
+    w.r[1] = w.hx ? b + sx : b;
+    w.r[2] = w.hy ? b + sy : b;
+    w.r[3] = (w.hx && w.hy) ? b + sx + sy : b;
+    return w;
+}
+
+// corner c of point (x,y,z): offset ((c>>0)&1, (c>>1)&1, (c>>2)&1) along axes (0,1,2)
+template <typename VolT>
+__device__ __forceinline__ McSigns mc_signs(const McRows<VolT> &w, const McParams &p, int z) {
+    McSigns q;
     q.above = q.eq = q.cross = 0u;
-    q.cell = false;
-    q.x = q.y = q.z = 0;
-    if (!q.inside) return;
-    q.z = (int)(idx % p.NZ);
-    q.y = (int)((idx / p.NZ) % p.NY);
-    q.x = (int)(idx / ((long)p.NZ * p.NY));
-    const bool hx = q.x + 1 < p.NX, hy = q.y + 1 < p.NY, hz = q.z + 1 < p.NZ;
+    const bool hz = z + 1 < p.NZ;
+    const int z0 = z * p.s, z1 = hz ? z0 + p.s : z0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int ox = c & 1, oy = (c >> 1) & 1, oz = (c >> 2) & 1;
-        const bool have = (!ox || hx) && (!oy || hy) && (!oz || hz);
-        q.f[c] = have ? mc_val(vol, p, q.x + ox, q.y + oy, q.z + oz) : 0.0;
-        if (have && q.f[c] > p.level) q.above |= 1u << c;
-        if (have && q.f[c] == p.level) q.eq |= 1u << c;
+        const bool have = (!ox || w.hx) && (!oy || w.hy) && (!oz || hz);
+        const VolT v = w.r[ox + 2 * oy][oz ? z1 : z0];
+        if (have && mc_above(v, p)) q.above |= 1u << c;
+        if (have && mc_equal(v, p)) q.eq |= 1u << c;
     }
     const unsigned a0 = q.above & 1u;
-    if (hx && (((q.above >> 1) & 1u) != a0)) q.cross |= 1u;
-    if (hy && (((q.above >> 2) & 1u) != a0)) q.cross |= 2u;
+    if (w.hx && (((q.above >> 1) & 1u) != a0)) q.cross |= 1u;
+    if (w.hy && (((q.above >> 2) & 1u) != a0)) q.cross |= 2u;
     if (hz && (((q.above >> 4) & 1u) != a0)) q.cross |= 4u;
-    q.cell = hx && hy && hz;
+    q.cell = w.hx && w.hy && hz;
+    return q;
 }
 
 // edge e = 4*a + o1 + 2*o2  ->  axis a and the corner (offset bits) where the edge starts
@@ -96,7 +131,7 @@ __device__ __forceinline__ bool mc_keep(const signed char *row, int t, unsigned 
     return col[0] != col[1] && col[1] != col[2] && col[0] != col[2];
 }
 
-__device__ __forceinline__ int mc_tri_count(const McPoint &q) {
+__device__ __forceinline__ int mc_tri_count(const McSigns &q) {
     if (!q.cell || q.above == 0u || q.above == 255u) return 0;
     const signed char *row = kMcTable + kMcRow * (int)q.above;
     const int n = row[0];
@@ -129,59 +164,84 @@ __device__ __forceinline__ int mc_block_scan(int v, int *lds /* 4 ints */, int *
     return before + inc - v;
 }
 
+// 256-point segment `seg` of a row in the row's activity mask; segments beyond the 31st share bit 31.
+__device__ __forceinline__ unsigned mc_chunk_bit(int seg) { return 1u << (seg < 31 ? seg : 31); }
+
+// tile of this workgroup: blockIdx = (ty, x) in the count pass
 template <typename VolT>
 __global__ __launch_bounds__(kMcBlock) void mc_count_kernel(const VolT *__restrict__ vol, const McParams p,
-                                                             unsigned *__restrict__ counts) {
+                                                             uint4 *__restrict__ entries) {
     __shared__ int lds[4];
-    McPoint q;
-    mc_load(vol, p, (long)blockIdx.x * kMcBlock + threadIdx.x, q);
-    int tv, tf;
-    mc_block_scan(__popc(q.cross), lds, &tv);
-    mc_block_scan(mc_tri_count(q), lds, &tf);
-    if (threadIdx.x == 0) { counts[2 * blockIdx.x] = (unsigned)tv; counts[2 * blockIdx.x + 1] = (unsigned)tf; }
+    __shared__ unsigned chunk_mask[kMcRows];            // bit seg: that 256-point segment of the row emits something
+    const int x = (int)blockIdx.y, y0 = (int)blockIdx.x * kMcRows;
+    if (threadIdx.x < kMcRows) chunk_mask[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int r = 0; r < kMcRows; ++r) {
+        const int y = y0 + r;
+        if (y >= p.NY) break;
+        const McRows<VolT> rows = mc_rows(vol, p, x, y);
+        int cv = 0, cf = 0;
+        for (int seg = 0; seg < p.nseg; ++seg) {
+            const int z = seg * kMcBlock + (int)threadIdx.x;
+            int v = 0, f = 0;
+            if (z < p.NZ) {
+                const McSigns q = mc_signs(rows, p, z);
+                v = __popc(q.cross);
+                f = mc_tri_count(q);
+            }
+            cv += v;
+            cf += f;
+            if (__any((v | f) != 0) && (threadIdx.x & 63) == 0) atomicOr(&chunk_mask[r], mc_chunk_bit(seg));
+        }
+        int tv, tf;
+        mc_block_scan(cv, lds, &tv);                    // (its barriers also order the atomicOr's before the read below)
+        mc_block_scan(cf, lds, &tf);
+        if (threadIdx.x == 0)
+            entries[(long)x * p.NY + y] = make_uint4((unsigned)tv, (unsigned)tf, (tv | tf) != 0 ? 1u : 0u, chunk_mask[r]);
+    }
 }
 
-// counts[2b], counts[2b+1] -> exclusive prefix sums (in place); totals[0..1] = sums
-__global__ __launch_bounds__(1024) void mc_scan_kernel(unsigned *__restrict__ counts, long nblocks, long *__restrict__ totals) {
-    __shared__ unsigned long long wsum[2][16];
-    __shared__ unsigned long long carry[2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 2) carry[threadIdx.x] = 0ull;
-    __syncthreads();
-    for (long base = 0; base < nblocks; base += 1024) {
-        const long b = base + threadIdx.x;
-        unsigned long long v[2], inc[2];
+// entries[t] = {vertices, faces, active, -} -> exclusive prefixes inside the chunk; chunk sums to chunk_tot
+__global__ __launch_bounds__(kMcBlock) void mc_scan_chunk_kernel(uint4 *__restrict__ entries, long ntiles, uint4 *__restrict__ chunk_tot) {
+    __shared__ int lds[4];
+    const long t0 = (long)blockIdx.x * kMcChunk + (long)threadIdx.x * 8;
+    uint4 e[8];
+    unsigned sv = 0, sf = 0, sa = 0;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            v[k] = b < nblocks ? counts[2 * b + k] : 0u;
-            inc[k] = v[k];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned long long t = __shfl_up(inc[k], o, 64);
-                if (lane >= o) inc[k] += t;
-            }
-            if (lane == 63) wsum[k][wave] = inc[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            unsigned long long before = carry[k];
-            for (int w = 0; w < wave; ++w) before += wsum[k][w];
-            // exclusive prefixes must fit the 29-bit vertex index / 31-bit face index (checked on the host from the totals)
-            if (b < nblocks) counts[2 * b + k] = (unsigned)(before + inc[k] - v[k]);
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                unsigned long long tot = carry[k];
-                for (int w = 0; w < 16; ++w) tot += wsum[k][w];
-                carry[k] = tot;
-            }
-        }
-        __syncthreads();
+    for (int j = 0; j < 8; ++j) {
+        e[j] = t0 + j < ntiles ? entries[t0 + j] : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 pre = make_uint4(sv, sf, sa, e[j].w);             // .w keeps the activity mask (non-zero = active)
+        sv += e[j].x; sf += e[j].y; sa += e[j].z;
+        e[j] = pre;
     }
-    if (threadIdx.x == 0) { totals[0] = (long)carry[0]; totals[1] = (long)carry[1]; }
+    int tv, tf, ta;
+    const unsigned bv = (unsigned)mc_block_scan((int)sv, lds, &tv);
+    const unsigned bf = (unsigned)mc_block_scan((int)sf, lds, &tf);
+    const unsigned ba = (unsigned)mc_block_scan((int)sa, lds, &ta);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (t0 + j < ntiles) entries[t0 + j] = make_uint4(e[j].x + bv, e[j].y + bf, e[j].z + ba, e[j].w);
+    if (threadIdx.x == 0) chunk_tot[blockIdx.x] = make_uint4((unsigned)tv, (unsigned)tf, (unsigned)ta, 0u);
+}
+
+// chunk totals -> exclusive prefixes (few hundred at most: one thread), grand totals {vertices, faces, active tiles}
+__global__ void mc_scan_top_kernel(uint4 *__restrict__ chunk_tot, long nchunks, long *__restrict__ totals) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long v = 0, f = 0, a = 0;
+    for (long c = 0; c < nchunks; ++c) {
+        const uint4 t = chunk_tot[c];
+        chunk_tot[c] = make_uint4((unsigned)v, (unsigned)f, (unsigned)a, 0u);
+        v += t.x; f += t.y; a += t.z;
+    }
+    totals[0] = (long)v; totals[1] = (long)f; totals[2] = (long)a;
+}
+
+__global__ __launch_bounds__(kMcBlock) void mc_active_kernel(const uint4 *__restrict__ entries, const uint4 *__restrict__ chunk_tot,
+                                                             long ntiles, unsigned *__restrict__ list) {
+    const long t = (long)blockIdx.x * kMcBlock + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint4 e = entries[t];
+    if (e.w) list[chunk_tot[t / kMcChunk].z + e.z] = (unsigned)t;
 }
 
 // gradient of the lattice function at lattice point (x,y,z): central differences, one-sided on the faces
@@ -210,79 +270,119 @@ __device__ __forceinline__ void mc_grad(const VolT *__restrict__ vol, const McPa
     }
 }
 
+// the emit passes run on the active tiles only: blockIdx.x indexes `list` (or is the tile itself when list == NULL)
+__device__ __forceinline__ long mc_tile(const unsigned *__restrict__ list) { return list ? (long)list[blockIdx.x] : (long)blockIdx.x; }
+
+// One vertex: interpolated crossing of the edge leaving (x,y,z) along axis a, normal from the lattice gradient.
+template <typename VolT>
+__device__ __forceinline__ void mc_emit_vertex(const VolT *__restrict__ vol, const McParams &p, int x, int y, int z, int a, long vi,
+                                               float *__restrict__ verts, float *__restrict__ normals, float *__restrict__ values) {
+    const int x1 = x + (a == 0), y1 = y + (a == 1), z1 = z + (a == 2);
+    const double f0 = mc_val(vol, p, x, y, z), f1 = mc_val(vol, p, x1, y1, z1);
+    const double tt = (p.level - f0) / (f1 - f0);
+    double pos[3] = {(double)x, (double)y, (double)z};
+    pos[a] = pos[a] + tt;
+    double g0[3], g1[3];
+    mc_grad(vol, p, x, y, z, g0);
+    mc_grad(vol, p, x1, y1, z1, g1);
+    const double gx = g0[0] + tt * (g1[0] - g0[0]), gy = g0[1] + tt * (g1[1] - g0[1]), gz = g0[2] + tt * (g1[2] - g0[2]);
+    const double n2 = (gx * gx + gy * gy) + gz * gz;
+    const double nrm = sqrt(n2);
+    const double inv = nrm > 0.0 ? -1.0 / nrm : 0.0;
+    verts[3 * vi + 0] = (float)(pos[0] * (double)p.s);
+    verts[3 * vi + 1] = (float)(pos[1] * (double)p.s);
+    verts[3 * vi + 2] = (float)(pos[2] * (double)p.s);
+    normals[3 * vi + 0] = (float)(gx * inv);
+    normals[3 * vi + 1] = (float)(gy * inv);
+    normals[3 * vi + 2] = (float)(gz * inv);
+    if (values) values[vi] = (float)(f0 > f1 ? f0 : f1);
+}
+
 template <typename VolT>
 __global__ __launch_bounds__(kMcBlock) void mc_vertex_kernel(const VolT *__restrict__ vol, const McParams p,
-                                                              const unsigned *__restrict__ offsets, unsigned *__restrict__ code,
+                                                              const uint4 *__restrict__ entries, const uint4 *__restrict__ chunk_tot,
+                                                              const unsigned *__restrict__ list, unsigned *__restrict__ code,
                                                               float *__restrict__ verts, float *__restrict__ normals,
                                                               float *__restrict__ values, long cap) {
     __shared__ int lds[4];
-    const long idx = (long)blockIdx.x * kMcBlock + threadIdx.x;
-    McPoint q;
-    mc_load(vol, p, idx, q);
-    int tot;
-    const int rank = mc_block_scan(__popc(q.cross), lds, &tot);
-    if (!q.inside) return;
-    const unsigned base = offsets[2 * blockIdx.x] + (unsigned)rank;
-    code[idx] = (q.cross << 29) | (base & kMcBaseMask);
-    if (q.cross == 0u) return;
-    double g0[3];
-    mc_grad(vol, p, q.x, q.y, q.z, g0);
-    unsigned k = 0;
+    __shared__ unsigned queue[3 * kMcBlock];            // crossed edges of one 256-point segment: z << 2 | axis
+    const long t = mc_tile(list);
+    const int x = (int)(t / p.NY), y = (int)(t - (long)x * p.NY);
+    const uint4 ent = entries[t];
+    unsigned carry = ent.x + chunk_tot[t / kMcChunk].x;
+    {
+        const McRows<VolT> rows = mc_rows(vol, p, x, y);
+        for (int seg = 0; seg < p.nseg; ++seg) {
+            if (list && !(ent.w & mc_chunk_bit(seg))) continue;            // nothing emitted here, nobody reads these codes
+            const int z = seg * kMcBlock + (int)threadIdx.x;
+            McSigns q;
+            q.cross = 0u;
+            if (z < p.NZ) q = mc_signs(rows, p, z);
+            int tot;
+            const int rank = mc_block_scan(__popc(q.cross), lds, &tot);
+            if (z < p.NZ) code[((long)x * p.NY + y) * p.NZ + z] = (q.cross << 29) | ((carry + (unsigned)rank) & kMcBaseMask);
+            if (tot > 0) {
+                // light lanes enqueue, then all lanes emit: the fp64 interpolation / gradient work runs on full waves
+                int k = rank;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        if (!((q.cross >> a) & 1u)) continue;
-        const long vi = (long)base + k;
-        ++k;
-        if (vi >= cap) continue;
-        const double f0 = q.f[0], f1 = q.f[1 << a];
-        const double t = (p.level - f0) / (f1 - f0);
-        double pos[3] = {(double)q.x, (double)q.y, (double)q.z};
-        pos[a] = pos[a] + t;
-        double g1[3];
-        mc_grad(vol, p, q.x + (a == 0), q.y + (a == 1), q.z + (a == 2), g1);
-        const double gx = g0[0] + t * (g1[0] - g0[0]), gy = g0[1] + t * (g1[1] - g0[1]), gz = g0[2] + t * (g1[2] - g0[2]);
-        const double n2 = (gx * gx + gy * gy) + gz * gz;
-        const double nrm = sqrt(n2);
-        const double inv = nrm > 0.0 ? -1.0 / nrm : 0.0;
-        verts[3 * vi + 0] = (float)(pos[0] * (double)p.s);
-        verts[3 * vi + 1] = (float)(pos[1] * (double)p.s);
-        verts[3 * vi + 2] = (float)(pos[2] * (double)p.s);
-        normals[3 * vi + 0] = (float)(gx * inv);
-        normals[3 * vi + 1] = (float)(gy * inv);
-        normals[3 * vi + 2] = (float)(gz * inv);
-        if (values) values[vi] = (float)(f0 > f1 ? f0 : f1);
+                for (int a = 0; a < 3; ++a)
+                    if ((q.cross >> a) & 1u) queue[k++] = ((unsigned)z << 2) | (unsigned)a;
+                __syncthreads();
+                for (int i = (int)threadIdx.x; i < tot; i += kMcBlock) {
+                    const long vi = (long)carry + i;
+                    if (vi < cap) mc_emit_vertex(vol, p, x, y, (int)(queue[i] >> 2), (int)(queue[i] & 3u), vi, verts, normals, values);
+                }
+                __syncthreads();
+            }
+            carry += (unsigned)tot;
+        }
     }
 }
 
 template <typename VolT>
 __global__ __launch_bounds__(kMcBlock) void mc_face_kernel(const VolT *__restrict__ vol, const McParams p,
-                                                            const unsigned *__restrict__ offsets, const unsigned *__restrict__ code,
+                                                            const uint4 *__restrict__ entries, const uint4 *__restrict__ chunk_tot,
+                                                            const unsigned *__restrict__ list, const unsigned *__restrict__ code,
                                                             int *__restrict__ faces, long cap) {
     __shared__ int lds[4];
-    const long idx = (long)blockIdx.x * kMcBlock + threadIdx.x;
-    McPoint q;
-    mc_load(vol, p, idx, q);
-    const int nt = mc_tri_count(q);
-    int tot;
-    const int rank = mc_block_scan(nt, lds, &tot);
-    if (nt == 0) return;
-    long fi = (long)offsets[2 * blockIdx.x + 1] + rank;
-    const signed char *row = kMcTable + kMcRow * (int)q.above;
-    const int n = row[0];
-    for (int t = 0; t < n; ++t) {
-        if (!mc_keep(row, t, q.eq)) continue;
-        if (fi < cap) {
+    const long t = mc_tile(list);
+    const int x = (int)(t / p.NY), y = (int)(t - (long)x * p.NY);
+    const uint4 ent = entries[t];
+    long carry = (long)ent.y + chunk_tot[t / kMcChunk].y;
+    {
+        const McRows<VolT> rows = mc_rows(vol, p, x, y);
+        for (int seg = 0; seg < p.nseg; ++seg) {
+            if (list && !(ent.w & mc_chunk_bit(seg))) continue;
+            const int z = seg * kMcBlock + (int)threadIdx.x;
+            McSigns q;
+            q.above = q.eq = q.cross = 0u;
+            q.cell = false;
+            if (z < p.NZ) q = mc_signs(rows, p, z);
+            const int nt = mc_tri_count(q);
+            int tot;
+            const int rank = mc_block_scan(nt, lds, &tot);
+            long fi = carry + rank;
+            carry += tot;
+            if (nt == 0) continue;
+            const long idx = ((long)x * p.NY + y) * p.NZ + z;
+            const signed char *row = kMcTable + kMcRow * (int)q.above;
+            const int n = row[0];
+            for (int tr = 0; tr < n; ++tr) {
+                if (!mc_keep(row, tr, q.eq)) continue;
+                if (fi < cap) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                int a, c0;
-                mc_edge(row[1 + 3 * t + k], a, c0);
-                const long owner = idx + (long)(c0 & 1) * p.NY * p.NZ + (long)((c0 >> 1) & 1) * p.NZ + (long)((c0 >> 2) & 1);
-                const unsigned cd = code[owner];
-                const unsigned mask = cd >> 29;
-                faces[3 * fi + k] = (int)((cd & kMcBaseMask) + (unsigned)__popc(mask & ((1u << a) - 1u)));
+                    for (int k = 0; k < 3; ++k) {
+                        int a, c0;
+                        mc_edge(row[1 + 3 * tr + k], a, c0);
+                        const long owner = idx + (long)(c0 & 1) * p.NY * p.NZ + (long)((c0 >> 1) & 1) * p.NZ + (long)((c0 >> 2) & 1);
+                        const unsigned cd = code[owner];
+                        const unsigned mask = cd >> 29;
+                        faces[3 * fi + k] = (int)((cd & kMcBaseMask) + (unsigned)__popc(mask & ((1u << a) - 1u)));
+                    }
+                }
+                ++fi;
             }
         }
-        ++fi;
     }
 }
 
@@ -401,14 +501,37 @@ __global__ __launch_bounds__(256) void mc_relabel_kernel(int *__restrict__ faces
 static bool mc_params(const int res[3], int step, double level, McParams &p) {
     p.Y = res[1]; p.Z = res[2]; p.s = step; p.level = level;
     p.NX = (res[0] + step - 1) / step; p.NY = (res[1] + step - 1) / step; p.NZ = (res[2] + step - 1) / step;
-    p.npts = (long)p.NX * p.NY * p.NZ;
-    return true;
+    p.nseg = (p.NZ + kMcBlock - 1) / kMcBlock;
+    p.nty = (p.NY + kMcRows - 1) / kMcRows;
+    p.ntiles = (long)p.NX * p.NY;
+    float lo = (float)level;                                // round to nearest, then step down if above
+    if ((double)lo > level) lo = nextafterf(lo, -HUGE_VALF);
+    p.lo_f = lo;
+    p.eq_f = (double)(float)level == level ? (float)level : NAN;
+    return p.nty <= 0x7fffffff && p.NX <= 65535;            // grid.x / grid.y limits of the count pass
 }
 
-static void mc_workspace_layout(const McParams &p, size_t &code_bytes, size_t &counts_bytes, long &nblocks) {
-    nblocks = (p.npts + kMcBlock - 1) / kMcBlock;
-    code_bytes = ((size_t)p.npts * sizeof(unsigned) + 15) & ~(size_t)15;
-    counts_bytes = ((size_t)nblocks * 2 * sizeof(unsigned) + 15) & ~(size_t)15;
+struct McWorkspace {
+    unsigned *code;
+    uint4 *entries, *chunk_tot;
+    unsigned *list;
+    long nchunks;
+    size_t bytes;
+};
+
+static McWorkspace mc_workspace(const McParams &p, void *base) {
+    McWorkspace w;
+    const size_t npts = (size_t)p.NX * p.NY * p.NZ;
+    w.nchunks = (p.ntiles + kMcChunk - 1) / kMcChunk;
+    size_t off = 0;
+    char *b = static_cast<char *>(base);
+    auto take = [&](size_t n) { char *r = b ? b + off : nullptr; off += (n + 15) & ~(size_t)15; return r; };
+    w.code = reinterpret_cast<unsigned *>(take(npts * sizeof(unsigned)));
+    w.entries = reinterpret_cast<uint4 *>(take((size_t)p.ntiles * sizeof(uint4)));
+    w.chunk_tot = reinterpret_cast<uint4 *>(take((size_t)w.nchunks * sizeof(uint4)));
+    w.list = reinterpret_cast<unsigned *>(take((size_t)p.ntiles * sizeof(unsigned)));
+    w.bytes = off;
+    return w;
 }
 
 }  // namespace dfh
@@ -420,10 +543,7 @@ size_t dfh_mc_workspace_bytes(const int res[3], int step) {
     if (!res || res[0] <= 0 || res[1] <= 0 || res[2] <= 0 || step < 1) return 0;
     McParams p;
     mc_params(res, step, 0.0, p);
-    size_t cb, nb;
-    long nblocks;
-    mc_workspace_layout(p, cb, nb, nblocks);
-    return cb + nb;
+    return mc_workspace(p, nullptr).bytes;
 }
 
 int dfh_mc_count(const void *vol, int vol_dtype, const int res[3], int step, double level, void *workspace,
@@ -435,25 +555,25 @@ int dfh_mc_count(const void *vol, int vol_dtype, const int res[3], int step, dou
     DFH_REQUIRE(level == level, "dfh_mc_count: level is NaN");
     DFH_REQUIRE(workspace_bytes >= dfh_mc_workspace_bytes(res, step), "dfh_mc_count: workspace too small");
     McParams p;
-    mc_params(res, step, level, p);
-    DFH_REQUIRE(p.npts < (1L << 31) * (long)kMcBlock, "dfh_mc_count: grid too large");
-    size_t cb, nb;
-    long nblocks;
-    mc_workspace_layout(p, cb, nb, nblocks);
-    unsigned *counts = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + cb);
+    DFH_REQUIRE(mc_params(res, step, level, p), "dfh_mc_count: more than 65535 lattice planes");
+    const McWorkspace w = mc_workspace(p, workspace);
     hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)p.nty, (unsigned)p.NX);
     if (vol_dtype == DFH_F32)
-        hipLaunchKernelGGL(mc_count_kernel<float>, dim3((unsigned)nblocks), dim3(kMcBlock), 0, s, (const float *)vol, p, counts);
+        hipLaunchKernelGGL(mc_count_kernel<float>, grid, dim3(kMcBlock), 0, s, (const float *)vol, p, w.entries);
     else
-        hipLaunchKernelGGL(mc_count_kernel<double>, dim3((unsigned)nblocks), dim3(kMcBlock), 0, s, (const double *)vol, p, counts);
-    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, counts, nblocks, totals_out);
+        hipLaunchKernelGGL(mc_count_kernel<double>, grid, dim3(kMcBlock), 0, s, (const double *)vol, p, w.entries);
+    hipLaunchKernelGGL(mc_scan_chunk_kernel, dim3((unsigned)w.nchunks), dim3(kMcBlock), 0, s, w.entries, p.ntiles, w.chunk_tot);
+    hipLaunchKernelGGL(mc_scan_top_kernel, dim3(1), dim3(64), 0, s, w.chunk_tot, w.nchunks, totals_out);
+    hipLaunchKernelGGL(mc_active_kernel, dim3((unsigned)((p.ntiles + kMcBlock - 1) / kMcBlock)), dim3(kMcBlock), 0, s, w.entries,
+                       w.chunk_tot, p.ntiles, w.list);
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }
 
 int dfh_mc_emit(const void *vol, int vol_dtype, const int res[3], int step, double level, void *workspace,
                 size_t workspace_bytes, float *verts, float *normals, float *values, int *faces, long cap_verts, long cap_faces,
-                void *stream) {
+                long n_active_tiles, void *stream) {
     using namespace dfh;
     DFH_REQUIRE(vol && res && workspace, "dfh_mc_emit: null pointer");
     DFH_REQUIRE(vol_dtype == DFH_F32 || vol_dtype == DFH_F64, "dfh_mc_emit: bad vol_dtype %d", vol_dtype);
@@ -463,22 +583,24 @@ int dfh_mc_emit(const void *vol, int vol_dtype, const int res[3], int step, doub
     DFH_REQUIRE(cap_verts <= (long)kMcBaseMask, "dfh_mc_emit: more than 2^29-1 vertices");
     DFH_REQUIRE((cap_verts == 0 || (verts && normals)) && (cap_faces == 0 || faces), "dfh_mc_emit: null output");
     McParams p;
-    mc_params(res, step, level, p);
-    size_t cb, nb;
-    long nblocks;
-    mc_workspace_layout(p, cb, nb, nblocks);
-    unsigned *code = static_cast<unsigned *>(workspace);
-    unsigned *counts = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + cb);
+    DFH_REQUIRE(mc_params(res, step, level, p), "dfh_mc_emit: more than 65535 lattice planes");
+    DFH_REQUIRE(n_active_tiles <= p.ntiles, "dfh_mc_emit: n_active_tiles exceeds the tile count");
+    const McWorkspace w = mc_workspace(p, workspace);
+    const long nlaunch = n_active_tiles >= 0 ? n_active_tiles : p.ntiles;        // < 0: visit every tile, no list
+    const unsigned *list = n_active_tiles >= 0 ? w.list : nullptr;
+    if (nlaunch == 0) return DFH_OK;
+    DFH_REQUIRE(nlaunch < (1L << 31), "dfh_mc_emit: too many tiles");
     hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)nlaunch);
     if (vol_dtype == DFH_F32) {
-        hipLaunchKernelGGL(mc_vertex_kernel<float>, dim3((unsigned)nblocks), dim3(kMcBlock), 0, s, (const float *)vol, p, counts, code,
+        hipLaunchKernelGGL(mc_vertex_kernel<float>, grid, dim3(kMcBlock), 0, s, (const float *)vol, p, w.entries, w.chunk_tot, list, w.code,
                            verts, normals, values, cap_verts);
-        hipLaunchKernelGGL(mc_face_kernel<float>, dim3((unsigned)nblocks), dim3(kMcBlock), 0, s, (const float *)vol, p, counts, code,
+        hipLaunchKernelGGL(mc_face_kernel<float>, grid, dim3(kMcBlock), 0, s, (const float *)vol, p, w.entries, w.chunk_tot, list, w.code,
                            faces, cap_faces);
     } else {
-        hipLaunchKernelGGL(mc_vertex_kernel<double>, dim3((unsigned)nblocks), dim3(kMcBlock), 0, s, (const double *)vol, p, counts,
-                           code, verts, normals, values, cap_verts);
-        hipLaunchKernelGGL(mc_face_kernel<double>, dim3((unsigned)nblocks), dim3(kMcBlock), 0, s, (const double *)vol, p, counts, code,
+        hipLaunchKernelGGL(mc_vertex_kernel<double>, grid, dim3(kMcBlock), 0, s, (const double *)vol, p, w.entries, w.chunk_tot, list,
+                           w.code, verts, normals, values, cap_verts);
+        hipLaunchKernelGGL(mc_face_kernel<double>, grid, dim3(kMcBlock), 0, s, (const double *)vol, p, w.entries, w.chunk_tot, list, w.code,
                            faces, cap_faces);
     }
     DFH_HIP_CHECK(hipGetLastError());

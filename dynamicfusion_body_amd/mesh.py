@@ -12,13 +12,14 @@ from . import _lib
 from .device import current_stream_ptr, dtype_code, require_gpu
 
 
-def marching_cubes(volume, level=None, step_size=1, as_numpy=False, order="reference"):
+def marching_cubes(volume, level=None, step_size=1, as_numpy=False, order="reference", visit_all_tiles=False):
     """volume: 3-D CUDA tensor (fp32 / fp64, contiguous).  Returns verts (V,3) fp32 in array-index
     coordinates, faces (F,3) int32, unit normals (V,3) fp32 pointing down the gradient, values (V,)
     fp32 -- CUDA tensors, or numpy arrays with as_numpy=True.  Zero-area faces are not emitted
     (allow_degenerate=False, the only mode the reference uses for its outputs).
     order="reference": skimage's numbering (faces cube by cube, vertices by first use, unused vertices
-    dropped); order="lattice": vertices by owning lattice point (skips the renumbering pass)."""
+    dropped); order="lattice": vertices by owning lattice point (skips the renumbering pass).
+    visit_all_tiles: emit passes over every tile instead of the compacted list (same result; for tests)."""
     if order not in ("reference", "lattice"):
         raise ValueError("order must be 'reference' or 'lattice'")
     require_gpu()
@@ -36,10 +37,10 @@ def marching_cubes(volume, level=None, step_size=1, as_numpy=False, order="refer
     res = _lib.iarr(volume.shape)
     nbytes = lib.dfh_mc_workspace_bytes(res, step)
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=volume.device)
-    totals = torch.zeros(2, dtype=torch.int64, device=volume.device)
+    totals = torch.zeros(3, dtype=torch.int64, device=volume.device)
     _lib.check(lib.dfh_mc_count(volume.data_ptr(), dtype_code(volume), res, step, level, ws.data_ptr(), ws.numel() * 8,
                                 totals.data_ptr(), current_stream_ptr()), "dfh_mc_count")
-    nv, nf = (int(v) for v in totals.tolist())
+    nv, nf, nactive = (int(v) for v in totals.tolist())
     if nv >= (1 << 29) or nf >= (1 << 31) // 3:
         raise ValueError("surface too large for 32-bit mesh indices (%d vertices, %d faces)" % (nv, nf))
     dev = volume.device
@@ -48,7 +49,7 @@ def marching_cubes(volume, level=None, step_size=1, as_numpy=False, order="refer
     values = torch.empty((nv,), dtype=torch.float32, device=dev)
     faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
     _lib.check(lib.dfh_mc_emit(volume.data_ptr(), dtype_code(volume), res, step, level, ws.data_ptr(), ws.numel() * 8,
-                               verts.data_ptr(), normals.data_ptr(), values.data_ptr(), faces.data_ptr(), nv, nf,
+                               verts.data_ptr(), normals.data_ptr(), values.data_ptr(), faces.data_ptr(), nv, nf, -1 if visit_all_tiles else nactive,
                                current_stream_ptr()), "dfh_mc_emit")
     if order == "reference":
         nbytes = lib.dfh_mc_reorder_workspace_bytes(nv, nf)

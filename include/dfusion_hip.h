@@ -204,15 +204,17 @@ int dfh_surface_emit(const void *tsdf, const void *tsdf_w, int vol_dtype, const 
  * up the gradient, zero-area faces are dropped -- the conventions of the reference's own output
  * meshes/original.obj.  Triangle choice inside a cube and the output order are this library's
  * (deterministic: vertices by owning lattice point then axis, faces by cube then table order).
- *   dfh_mc_count : totals_out[0] = vertices, totals_out[1] = faces (device longs); fills `workspace`
+ *   dfh_mc_count : totals_out[0] = vertices, [1] = faces, [2] = z rows (tiles) that emit anything
+ *                  (3 device longs); fills `workspace`
  *   dfh_mc_emit  : writes min(total, capacity) vertices (x3 fp32), normals (x3 fp32), values (max of the
- *                  edge's two samples, may be NULL) and faces (x3 int32); same workspace, after dfh_mc_count. */
+ *                  edge's two samples, may be NULL) and faces (x3 int32); same workspace, after dfh_mc_count.
+ *                  n_active_tiles = totals_out[2] launches only those tiles; < 0 visits every tile. */
 size_t dfh_mc_workspace_bytes(const int res[3], int step);
 int dfh_mc_count(const void *vol, int vol_dtype, const int res[3], int step, double level, void *workspace,
                  size_t workspace_bytes, long *totals_out, void *stream);
 int dfh_mc_emit(const void *vol, int vol_dtype, const int res[3], int step, double level, void *workspace,
                 size_t workspace_bytes, float *verts, float *normals, float *values, int *faces, long cap_verts, long cap_faces,
-                void *stream);
+                long n_active_tiles, void *stream);
 /* The reference's vertex order on top of dfh_mc_emit's output: skimage numbers vertices as its faces create
  * them and flips the face rows afterwards, i.e. ids increase with first use when rows are read right-to-left
  * (meshes/original.obj).  Renumbers accordingly (faces rewritten in place, vertex arrays copied to *_out in

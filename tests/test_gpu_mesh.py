@@ -66,6 +66,20 @@ def test_sphere_step_and_default_level(step):
     assert rep["euler"] == 2 and rep["boundary_edges"] == 0 and rep["nonmanifold_edges"] == 0 and rep["misoriented_edges"] == 0
 
 
+def test_emit_over_all_tiles_is_the_same():
+    vol = np.random.default_rng(11).normal(size=(9, 14, 300)).astype(np.float32)       # two z segments per row
+    t = torch.from_numpy(vol).cuda()
+    a = mesh.marching_cubes(t, 0.0, as_numpy=True)
+    b = mesh.marching_cubes(t, 0.0, as_numpy=True, visit_all_tiles=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    check_equal(a, mc_np.marching_cubes(vol, 0.0))
+    lvl = 0.1234567                                                                    # not an fp32 number: native-type thresholds
+    check_equal(run(vol, lvl), mc_np.marching_cubes(vol, lvl))
+    lvl = float(vol[3, 4, 5])                                                          # exactly a sample: equality path
+    check_equal(run(vol, lvl), mc_np.marching_cubes(vol, lvl))
+
+
 def test_degenerate_faces_and_unused_vertices():
     vol = (np.round(np.random.default_rng(5).normal(size=(12, 11, 13)) * 2) / 2).astype(np.float32)
     got = run(vol, 0.0)

@@ -29,6 +29,10 @@ def timeit(fn, n):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
+v, f, n, val = mesh.marching_cubes(T, 0.0, 1, order="lattice")
+own = torch.floor(v[:, :2] + 1e-4).to(torch.int64)
+rows = torch.unique(own[:, 0] * R + own[:, 1]).numel()
+print("z rows owning a vertex: %d of %d (%.1f%%)" % (rows, R * R, 100.0 * rows / (R * R)))
 for order in ("lattice", "reference"):
     v, f, n, val = mesh.marching_cubes(T, 0.0, 1, order=order)
     ms = timeit(lambda: mesh.marching_cubes(T, 0.0, 1, order=order), a.reps)

@@ -56,19 +56,14 @@ __device__ __forceinline__ bool mc_above(double v, const McParams &p) { return v
 __device__ __forceinline__ bool mc_equal(float v, const McParams &p) { return v == p.eq_f; }
 __device__ __forceinline__ bool mc_equal(double v, const McParams &p) { return v == p.level; }
 
-struct McSigns {
-    unsigned above;           // bit c: corner c exists and value > level
-    unsigned eq;              // bit c: corner c exists and value == level
-    unsigned cross;           // bit a: owned edge along axis a exists and is crossed
-    bool cell;                // the cube with corner 0 = p exists
-};
-
-// The four z rows a point's cube touches: (x,y), (x,y+1), (x+1,y), (x+1,y+1).  Workgroup-uniform, so the
-// address arithmetic is scalar; rows outside the lattice alias row (x,y) and are masked out by hx / hy.
+// ---- sign classification: one wave per z row, four consecutive points per lane ----------------------
+// The four z rows a point's cube touches: (x,y), (x+1,y), (x,y+1), (x+1,y+1).  Wave-uniform, so the address
+// arithmetic is scalar; rows outside the lattice alias row (x,y) and are masked out.
 template <typename VolT>
 struct McRows {
     const VolT *r[4];         // index = ox + 2*oy  (bit 0: +x, bit 1: +y)
     bool hx, hy;
+    bool vec;                 // 4 consecutive samples can be fetched with one 16-byte (fp32) / two (fp64) loads
 };
 
 template <typename VolT>
@@ -82,30 +77,94 @@ __device__ __forceinline__ McRows<VolT> mc_rows(const VolT *__restrict__ vol, co
     w.r[1] = w.hx ? b + sx : b;
     w.r[2] = w.hy ? b + sy : b;
     w.r[3] = (w.hx && w.hy) ? b + sx + sy : b;
+    w.vec = p.s == 1 && (p.Z & 3) == 0 && ((uintptr_t)vol & 15) == 0;
     return w;
 }
 
-// corner c of point (x,y,z): offset ((c>>0)&1, (c>>1)&1, (c>>2)&1) along axes (0,1,2)
+// bit j (0..4) of the result: sample z0+j of the row is above the level / equals it (0 beyond the row's end)
 template <typename VolT>
-__device__ __forceinline__ McSigns mc_signs(const McRows<VolT> &w, const McParams &p, int z) {
-    McSigns q;
-    q.above = q.eq = q.cross = 0u;
-    const bool hz = z + 1 < p.NZ;
-    const int z0 = z * p.s, z1 = hz ? z0 + p.s : z0;
+__device__ __forceinline__ void mc_row_bits(const VolT *__restrict__ rp, const McParams &p, bool vec, int z0, unsigned &ab, unsigned &eb) {
+    VolT v[5];
+    if (vec && z0 + 3 < p.NZ) {
+        if constexpr (sizeof(VolT) == 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(rp + z0);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            const double2 q0 = *reinterpret_cast<const double2 *>(rp + z0), q1 = *reinterpret_cast<const double2 *>(rp + z0 + 2);
+            v[0] = q0.x; v[1] = q0.y; v[2] = q1.x; v[3] = q1.y;
+        }
+    } else {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int ox = c & 1, oy = (c >> 1) & 1, oz = (c >> 2) & 1;
-        const bool have = (!ox || w.hx) && (!oy || w.hy) && (!oz || hz);
-        const VolT v = w.r[ox + 2 * oy][oz ? z1 : z0];
-        if (have && mc_above(v, p)) q.above |= 1u << c;
-        if (have && mc_equal(v, p)) q.eq |= 1u << c;
+        for (int j = 0; j < 4; ++j) v[j] = rp[(size_t)min(z0 + j, p.NZ - 1) * p.s];
     }
-    const unsigned a0 = q.above & 1u;
-    if (w.hx && (((q.above >> 1) & 1u) != a0)) q.cross |= 1u;
-    if (w.hy && (((q.above >> 2) & 1u) != a0)) q.cross |= 2u;
-    if (hz && (((q.above >> 4) & 1u) != a0)) q.cross |= 4u;
-    q.cell = w.hx && w.hy && hz;
-    return q;
+    // sample z0+4 is the next lane's first sample (lanes hold consecutive groups of four); lane 63 fetches it
+    {
+        const VolT nxt = __shfl_down(v[0], 1, 64);
+        v[4] = (threadIdx.x & 63) == 63 ? rp[(size_t)min(z0 + 4, p.NZ - 1) * p.s] : nxt;
+    }
+    ab = eb = 0u;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const bool in = z0 + j < p.NZ;
+        if (in && mc_above(v[j], p)) ab |= 1u << j;
+        if (in && mc_equal(v[j], p)) eb |= 1u << j;
+    }
+}
+
+struct McSigns {
+    unsigned above;           // bit c: corner c exists and value > level   (corner c: offset (c&1, (c>>1)&1, (c>>2)&1))
+    unsigned eq;              // bit c: corner c exists and value == level
+    unsigned cross;           // bit a: owned edge along axis a exists and is crossed
+    bool cell;                // the cube with corner 0 = p exists
+};
+
+// signs of the four points z0..z0+3 of a row from the 5-bit sample masks of its four cube rows
+// (index ox + 2*oy; rows outside the lattice: zero masks)
+__device__ __forceinline__ void mc_assemble4(const unsigned (&ab)[4], const unsigned (&eb)[4], bool hx, bool hy, const McParams &p, int z0,
+                                             McSigns (&q)[4]) {
+    // all twenty samples on one side of the level (the bulk of the volume): nothing is crossed, no cube is cut
+    const unsigned any = ab[0] | ab[1] | ab[2] | ab[3], all = ab[0] & ab[1] & ab[2] & ab[3];
+    if (any == 0u || (all == 31u && hx && hy && z0 + 4 < p.NZ)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { q[j].above = q[j].eq = q[j].cross = 0u; q[j].cell = false; }
+        return;
+    }
+    // bit j of the four rows -> one nibble (row ri at bit ri): bytes packed, bit picked, gathered by a multiply
+    const unsigned pa = ab[0] | (ab[1] << 8) | (ab[2] << 16) | (ab[3] << 24);
+    const unsigned pe = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (eb[3] << 24);
+    unsigned na[5], ne[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        na[j] = ((((pa >> j) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
+        ne[j] = pe ? ((((pe >> j) & 0x01010101u) * 0x01020408u) >> 24) & 15u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool inside = z0 + j < p.NZ, hz = z0 + j + 1 < p.NZ;
+        const unsigned above = na[j] | (na[j + 1] << 4);
+        const unsigned diff = above ^ ((above & 1u) ? 255u : 0u);          // corners on the other side than corner 0
+        unsigned cross = 0u;
+        if (hx) cross |= (diff >> 1) & 1u;
+        if (hy) cross |= ((diff >> 2) & 1u) << 1;
+        if (hz) cross |= ((diff >> 4) & 1u) << 2;
+        q[j].above = inside ? above : 0u;
+        q[j].eq = inside ? (ne[j] | (ne[j + 1] << 4)) : 0u;
+        q[j].cross = inside ? cross : 0u;
+        q[j].cell = inside && hx && hy && hz;
+    }
+}
+
+// signs of the four points z0..z0+3 of row (x,y)
+template <typename VolT>
+__device__ __forceinline__ void mc_signs4(const McRows<VolT> &w, const McParams &p, int z0, McSigns (&q)[4]) {
+    unsigned ab[4], eb[4];
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+        const bool have = (!(ri & 1) || w.hx) && (!(ri & 2) || w.hy);
+        ab[ri] = eb[ri] = 0u;
+        if (have) mc_row_bits(w.r[ri], p, w.vec, z0, ab[ri], eb[ri]);
+    }
+    mc_assemble4(ab, eb, w.hx, w.hy, p, z0, q);
 }
 
 // edge e = 4*a + o1 + 2*o2  ->  axis a and the corner (offset bits) where the edge starts
@@ -164,40 +223,100 @@ __device__ __forceinline__ int mc_block_scan(int v, int *lds /* 4 ints */, int *
     return before + inc - v;
 }
 
+// exclusive scan over the 64 lanes of a wave (no barrier); *total = wave sum
+__device__ __forceinline__ int mc_wave_scan(int v, int *total) {
+    const int lane = threadIdx.x & 63;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    *total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+
 // 256-point segment `seg` of a row in the row's activity mask; segments beyond the 31st share bit 31.
 __device__ __forceinline__ unsigned mc_chunk_bit(int seg) { return 1u << (seg < 31 ? seg : 31); }
 
-// tile of this workgroup: blockIdx = (ty, x) in the count pass
+// count pass: one wave per kMcRows consecutive rows (x, y0..y0+3): the ten sample rows they touch are fetched
+// back to back, then the four rows are classified; no barriers.  Workgroup = 4 waves = 16 rows.
+// Plane x+1 is read again by the workgroups of plane x+1: workgroups are dealt round-robin to the 8 XCDs
+// (separate L2s), so each XCD gets a contiguous slab of x planes and finds that re-read in its own L2.
 template <typename VolT>
 __global__ __launch_bounds__(kMcBlock) void mc_count_kernel(const VolT *__restrict__ vol, const McParams p,
                                                              uint4 *__restrict__ entries) {
-    __shared__ int lds[4];
-    __shared__ unsigned chunk_mask[kMcRows];            // bit seg: that 256-point segment of the row emits something
-    const int x = (int)blockIdx.y, y0 = (int)blockIdx.x * kMcRows;
-    if (threadIdx.x < kMcRows) chunk_mask[threadIdx.x] = 0u;
-    __syncthreads();
-    for (int r = 0; r < kMcRows; ++r) {
-        const int y = y0 + r;
-        if (y >= p.NY) break;
-        const McRows<VolT> rows = mc_rows(vol, p, x, y);
-        int cv = 0, cf = 0;
-        for (int seg = 0; seg < p.nseg; ++seg) {
-            const int z = seg * kMcBlock + (int)threadIdx.x;
-            int v = 0, f = 0;
-            if (z < p.NZ) {
-                const McSigns q = mc_signs(rows, p, z);
-                v = __popc(q.cross);
-                f = mc_tri_count(q);
+    const int lane = threadIdx.x & 63;
+    const int yg = (p.nty + kMcBlock / 64 - 1) / (kMcBlock / 64);      // workgroups per x plane
+    int x, g;
+    if ((p.NX & 7) == 0) {
+        const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+        x = xcd * (p.NX >> 3) + j / yg;
+        g = j % yg;
+    } else {
+        x = (int)blockIdx.x / yg;
+        g = (int)blockIdx.x % yg;
+    }
+    const int y0 = (g * (kMcBlock / 64) + (int)(threadIdx.x >> 6)) * kMcRows;
+    if (y0 >= p.NY) return;
+    const bool hx = x + 1 < p.NX;
+    const size_t sx = (size_t)p.s * p.Y * p.Z, sy = (size_t)p.s * p.Z;
+    const VolT *base = vol + (size_t)x * sx + (size_t)y0 * sy;
+    const bool vec = p.s == 1 && (p.Z & 3) == 0 && ((uintptr_t)vol & 15) == 0;
+    int cnt[kMcRows];                                   // vertices | faces << 16 per row (<= 768 and <= 1280 per segment and lane group)
+    unsigned mask[kMcRows];
+#pragma unroll
+    for (int r = 0; r < kMcRows; ++r) { cnt[r] = 0; mask[r] = 0u; }
+    for (int seg = 0; seg < p.nseg; ++seg) {
+        const int z0 = seg * kMcBlock + 4 * lane;
+        unsigned A[2][kMcRows + 1], E[2][kMcRows + 1];
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+            for (int yy = 0; yy <= kMcRows; ++yy) {
+                A[ox][yy] = E[ox][yy] = 0u;
+                if (z0 < p.NZ && y0 + yy < p.NY && (ox == 0 || hx)) mc_row_bits(base + ox * sx + yy * sy, p, vec, z0, A[ox][yy], E[ox][yy]);
             }
-            cv += v;
-            cf += f;
-            if (__any((v | f) != 0) && (threadIdx.x & 63) == 0) atomicOr(&chunk_mask[r], mc_chunk_bit(seg));
+#pragma unroll
+        for (int r = 0; r < kMcRows; ++r) {
+            int c = 0;
+            if (z0 < p.NZ && y0 + r < p.NY) {
+                const unsigned ab[4] = {A[0][r], A[1][r], A[0][r + 1], A[1][r + 1]};
+                const unsigned eb[4] = {E[0][r], E[1][r], E[0][r + 1], E[1][r + 1]};
+                McSigns q[4];
+                mc_assemble4(ab, eb, hx, y0 + r + 1 < p.NY, p, z0, q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c += __popc(q[j].cross) | (mc_tri_count(q[j]) << 16);
+            }
+            // per-row totals can exceed 16 bits over many segments: fold into 64-bit lanes later; here per segment only
+            if (__any(c != 0)) mask[r] |= mc_chunk_bit(seg);
+            cnt[r] += c;
         }
-        int tv, tf;
-        mc_block_scan(cv, lds, &tv);                    // (its barriers also order the atomicOr's before the read below)
-        mc_block_scan(cf, lds, &tf);
-        if (threadIdx.x == 0)
-            entries[(long)x * p.NY + y] = make_uint4((unsigned)tv, (unsigned)tf, (tv | tf) != 0 ? 1u : 0u, chunk_mask[r]);
+        // flush the packed counters before they can overflow (every 16 segments: 16 * 20 triangles per lane < 2^16)
+        if ((seg & 15) == 15 || seg == p.nseg - 1) {
+#pragma unroll
+            for (int r = 0; r < kMcRows; ++r) {
+                int c = cnt[r];                          // low half <= 64 * 192, no carry into the high half
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+                cnt[r] = 0;
+                if (lane == 0 && y0 + r < p.NY) {
+                    uint4 *e = entries + (long)x * p.NY + y0 + r;
+                    const unsigned v = (unsigned)(c & 0xffff), f = (unsigned)(c >> 16) & 0xffffu;
+                    if (seg < 16) *e = make_uint4(v, f, 0u, 0u);
+                    else { e->x += v; e->y += f; }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < kMcRows; ++r)
+            if (y0 + r < p.NY) {
+                uint4 *e = entries + (long)x * p.NY + y0 + r;
+                e->z = (e->x | e->y) != 0u ? 1u : 0u;
+                e->w = mask[r];
+            }
     }
 }
 
@@ -270,8 +389,13 @@ __device__ __forceinline__ void mc_grad(const VolT *__restrict__ vol, const McPa
     }
 }
 
-// the emit passes run on the active tiles only: blockIdx.x indexes `list` (or is the tile itself when list == NULL)
-__device__ __forceinline__ long mc_tile(const unsigned *__restrict__ list) { return list ? (long)list[blockIdx.x] : (long)blockIdx.x; }
+// The emit passes run on the active rows only, one wave per row: wave w of workgroup b takes entry 4 b + w of
+// `list` (or row 4 b + w itself when list == NULL).  Everything inside a row is wave-synchronous: no barriers.
+__device__ __forceinline__ long mc_tile(const unsigned *__restrict__ list, long nrows) {
+    const long i = (long)blockIdx.x * (kMcBlock / 64) + (threadIdx.x >> 6);
+    if (i >= nrows) return -1;
+    return list ? (long)list[i] : i;
+}
 
 // One vertex: interpolated crossing of the edge leaving (x,y,z) along axis a, normal from the lattice gradient.
 template <typename VolT>
@@ -280,8 +404,7 @@ __device__ __forceinline__ void mc_emit_vertex(const VolT *__restrict__ vol, con
     const int x1 = x + (a == 0), y1 = y + (a == 1), z1 = z + (a == 2);
     const double f0 = mc_val(vol, p, x, y, z), f1 = mc_val(vol, p, x1, y1, z1);
     const double tt = (p.level - f0) / (f1 - f0);
-    double pos[3] = {(double)x, (double)y, (double)z};
-    pos[a] = pos[a] + tt;
+    const double px = (double)x + (a == 0 ? tt : 0.0), py = (double)y + (a == 1 ? tt : 0.0), pz = (double)z + (a == 2 ? tt : 0.0);
     double g0[3], g1[3];
     mc_grad(vol, p, x, y, z, g0);
     mc_grad(vol, p, x1, y1, z1, g1);
@@ -289,9 +412,9 @@ __device__ __forceinline__ void mc_emit_vertex(const VolT *__restrict__ vol, con
     const double n2 = (gx * gx + gy * gy) + gz * gz;
     const double nrm = sqrt(n2);
     const double inv = nrm > 0.0 ? -1.0 / nrm : 0.0;
-    verts[3 * vi + 0] = (float)(pos[0] * (double)p.s);
-    verts[3 * vi + 1] = (float)(pos[1] * (double)p.s);
-    verts[3 * vi + 2] = (float)(pos[2] * (double)p.s);
+    verts[3 * vi + 0] = (float)(px * (double)p.s);
+    verts[3 * vi + 1] = (float)(py * (double)p.s);
+    verts[3 * vi + 2] = (float)(pz * (double)p.s);
     normals[3 * vi + 0] = (float)(gx * inv);
     normals[3 * vi + 1] = (float)(gy * inv);
     normals[3 * vi + 2] = (float)(gz * inv);
@@ -301,88 +424,112 @@ __device__ __forceinline__ void mc_emit_vertex(const VolT *__restrict__ vol, con
 template <typename VolT>
 __global__ __launch_bounds__(kMcBlock) void mc_vertex_kernel(const VolT *__restrict__ vol, const McParams p,
                                                               const uint4 *__restrict__ entries, const uint4 *__restrict__ chunk_tot,
-                                                              const unsigned *__restrict__ list, unsigned *__restrict__ code,
+                                                              const unsigned *__restrict__ list, long nrows, unsigned *__restrict__ code,
                                                               float *__restrict__ verts, float *__restrict__ normals,
                                                               float *__restrict__ values, long cap) {
-    __shared__ int lds[4];
-    __shared__ unsigned queue[3 * kMcBlock];            // crossed edges of one 256-point segment: z << 2 | axis
-    const long t = mc_tile(list);
+    __shared__ unsigned queue_all[kMcBlock / 64][3 * kMcBlock];   // per wave: crossed edges of one segment, z << 2 | axis
+    const long t = mc_tile(list, nrows);
+    if (t < 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned *queue = queue_all[threadIdx.x >> 6];
     const int x = (int)(t / p.NY), y = (int)(t - (long)x * p.NY);
     const uint4 ent = entries[t];
     unsigned carry = ent.x + chunk_tot[t / kMcChunk].x;
-    {
-        const McRows<VolT> rows = mc_rows(vol, p, x, y);
-        for (int seg = 0; seg < p.nseg; ++seg) {
-            if (list && !(ent.w & mc_chunk_bit(seg))) continue;            // nothing emitted here, nobody reads these codes
-            const int z = seg * kMcBlock + (int)threadIdx.x;
-            McSigns q;
-            q.cross = 0u;
-            if (z < p.NZ) q = mc_signs(rows, p, z);
-            int tot;
-            const int rank = mc_block_scan(__popc(q.cross), lds, &tot);
-            if (z < p.NZ) code[((long)x * p.NY + y) * p.NZ + z] = (q.cross << 29) | ((carry + (unsigned)rank) & kMcBaseMask);
-            if (tot > 0) {
-                // light lanes enqueue, then all lanes emit: the fp64 interpolation / gradient work runs on full waves
-                int k = rank;
+    const McRows<VolT> rows = mc_rows(vol, p, x, y);
+    unsigned *code_row = code + ((long)x * p.NY + y) * p.NZ;
+    for (int seg = 0; seg < p.nseg; ++seg) {
+        if (list && !(ent.w & mc_chunk_bit(seg))) continue;          // nothing emitted here, nobody reads these codes
+        const int z0 = seg * kMcBlock + 4 * lane;
+        McSigns q[4];
+        int cnt = 0;
+        if (z0 < p.NZ) {
+            mc_signs4(rows, p, z0, q);
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    if ((q.cross >> a) & 1u) queue[k++] = ((unsigned)z << 2) | (unsigned)a;
-                __syncthreads();
-                for (int i = (int)threadIdx.x; i < tot; i += kMcBlock) {
-                    const long vi = (long)carry + i;
-                    if (vi < cap) mc_emit_vertex(vol, p, x, y, (int)(queue[i] >> 2), (int)(queue[i] & 3u), vi, verts, normals, values);
-                }
-                __syncthreads();
-            }
-            carry += (unsigned)tot;
+            for (int j = 0; j < 4; ++j) cnt += __popc(q[j].cross);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j].cross = 0u;
         }
+        int tot;
+        int rank = mc_wave_scan(cnt, &tot);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (z0 + j < p.NZ) code_row[z0 + j] = (q[j].cross << 29) | ((carry + (unsigned)rank) & kMcBaseMask);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if ((q[j].cross >> a) & 1u) queue[rank++] = ((unsigned)(z0 + j) << 2) | (unsigned)a;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // light lanes enqueued, all lanes emit: the fp64 interpolation / gradient work runs on full waves
+        for (int i = lane; i < tot; i += 64) {
+            const long vi = (long)carry + i;
+            const unsigned e = queue[i];
+            if (vi < cap) mc_emit_vertex(vol, p, x, y, (int)(e >> 2), (int)(e & 3u), vi, verts, normals, values);
+        }
+        __builtin_amdgcn_wave_barrier();
+        carry += (unsigned)tot;
     }
 }
 
 template <typename VolT>
 __global__ __launch_bounds__(kMcBlock) void mc_face_kernel(const VolT *__restrict__ vol, const McParams p,
                                                             const uint4 *__restrict__ entries, const uint4 *__restrict__ chunk_tot,
-                                                            const unsigned *__restrict__ list, const unsigned *__restrict__ code,
+                                                            const unsigned *__restrict__ list, long nrows, const unsigned *__restrict__ code,
                                                             int *__restrict__ faces, long cap) {
-    __shared__ int lds[4];
-    const long t = mc_tile(list);
+    // per wave: the kept triangles of one segment, (z - seg*256) << 12 | case << 4 | triangle number
+    __shared__ unsigned queue_all[kMcBlock / 64][kMcMaxTris * kMcBlock];
+    const long t = mc_tile(list, nrows);
+    if (t < 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned *queue = queue_all[threadIdx.x >> 6];
     const int x = (int)(t / p.NY), y = (int)(t - (long)x * p.NY);
     const uint4 ent = entries[t];
     long carry = (long)ent.y + chunk_tot[t / kMcChunk].y;
-    {
-        const McRows<VolT> rows = mc_rows(vol, p, x, y);
-        for (int seg = 0; seg < p.nseg; ++seg) {
-            if (list && !(ent.w & mc_chunk_bit(seg))) continue;
-            const int z = seg * kMcBlock + (int)threadIdx.x;
-            McSigns q;
-            q.above = q.eq = q.cross = 0u;
-            q.cell = false;
-            if (z < p.NZ) q = mc_signs(rows, p, z);
-            const int nt = mc_tri_count(q);
-            int tot;
-            const int rank = mc_block_scan(nt, lds, &tot);
-            long fi = carry + rank;
-            carry += tot;
-            if (nt == 0) continue;
-            const long idx = ((long)x * p.NY + y) * p.NZ + z;
-            const signed char *row = kMcTable + kMcRow * (int)q.above;
-            const int n = row[0];
-            for (int tr = 0; tr < n; ++tr) {
-                if (!mc_keep(row, tr, q.eq)) continue;
-                if (fi < cap) {
+    const McRows<VolT> rows = mc_rows(vol, p, x, y);
+    const long row_idx = ((long)x * p.NY + y) * p.NZ;
+    for (int seg = 0; seg < p.nseg; ++seg) {
+        if (list && !(ent.w & mc_chunk_bit(seg))) continue;
+        const int z0 = seg * kMcBlock + 4 * lane;
+        McSigns q[4];
+        int nt[4] = {0, 0, 0, 0};
+        int cnt = 0;
+        if (z0 < p.NZ) {
+            mc_signs4(rows, p, z0, q);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        int a, c0;
-                        mc_edge(row[1 + 3 * tr + k], a, c0);
-                        const long owner = idx + (long)(c0 & 1) * p.NY * p.NZ + (long)((c0 >> 1) & 1) * p.NZ + (long)((c0 >> 2) & 1);
-                        const unsigned cd = code[owner];
-                        const unsigned mask = cd >> 29;
-                        faces[3 * fi + k] = (int)((cd & kMcBaseMask) + (unsigned)__popc(mask & ((1u << a) - 1u)));
-                    }
-                }
-                ++fi;
+            for (int j = 0; j < 4; ++j) { nt[j] = mc_tri_count(q[j]); cnt += nt[j]; }
+        }
+        int tot;
+        int rank = mc_wave_scan(cnt, &tot);
+        if (tot == 0) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (nt[j] == 0) continue;
+            const signed char *row = kMcTable + kMcRow * (int)q[j].above;
+            const int n = row[0];
+            for (int tr = 0; tr < n; ++tr)
+                if (mc_keep(row, tr, q[j].eq)) queue[rank++] = ((unsigned)(4 * lane + j) << 12) | (q[j].above << 4) | (unsigned)tr;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // one triangle per lane: three code look-ups each
+        for (int i = lane; i < tot; i += 64) {
+            const long fi = carry + i;
+            if (fi >= cap) continue;
+            const unsigned e = queue[i];
+            const long idx = row_idx + seg * kMcBlock + (long)(e >> 12);
+            const signed char *row = kMcTable + kMcRow * (int)((e >> 4) & 255u);
+            const int tr = (int)(e & 15u);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int a, c0;
+                mc_edge(row[1 + 3 * tr + k], a, c0);
+                const long owner = idx + (long)(c0 & 1) * p.NY * p.NZ + (long)((c0 >> 1) & 1) * p.NZ + (long)((c0 >> 2) & 1);
+                const unsigned cd = code[owner];
+                const unsigned mask = cd >> 29;
+                faces[3 * fi + k] = (int)((cd & kMcBaseMask) + (unsigned)__popc(mask & ((1u << a) - 1u)));
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        carry += tot;
     }
 }
 
@@ -508,7 +655,7 @@ static bool mc_params(const int res[3], int step, double level, McParams &p) {
     if ((double)lo > level) lo = nextafterf(lo, -HUGE_VALF);
     p.lo_f = lo;
     p.eq_f = (double)(float)level == level ? (float)level : NAN;
-    return p.nty <= 0x7fffffff && p.NX <= 65535;            // grid.x / grid.y limits of the count pass
+    return true;
 }
 
 struct McWorkspace {
@@ -558,7 +705,9 @@ int dfh_mc_count(const void *vol, int vol_dtype, const int res[3], int step, dou
     DFH_REQUIRE(mc_params(res, step, level, p), "dfh_mc_count: more than 65535 lattice planes");
     const McWorkspace w = mc_workspace(p, workspace);
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)p.nty, (unsigned)p.NX);
+    const long ncount = (long)((p.nty + kMcBlock / 64 - 1) / (kMcBlock / 64)) * p.NX;
+    DFH_REQUIRE(ncount < (1L << 31), "dfh_mc_count: grid too large");
+    const dim3 grid((unsigned)ncount);
     if (vol_dtype == DFH_F32)
         hipLaunchKernelGGL(mc_count_kernel<float>, grid, dim3(kMcBlock), 0, s, (const float *)vol, p, w.entries);
     else
@@ -586,22 +735,23 @@ int dfh_mc_emit(const void *vol, int vol_dtype, const int res[3], int step, doub
     DFH_REQUIRE(mc_params(res, step, level, p), "dfh_mc_emit: more than 65535 lattice planes");
     DFH_REQUIRE(n_active_tiles <= p.ntiles, "dfh_mc_emit: n_active_tiles exceeds the tile count");
     const McWorkspace w = mc_workspace(p, workspace);
-    const long nlaunch = n_active_tiles >= 0 ? n_active_tiles : p.ntiles;        // < 0: visit every tile, no list
+    const long nrows = n_active_tiles >= 0 ? n_active_tiles : p.ntiles;          // < 0: visit every row, no list
     const unsigned *list = n_active_tiles >= 0 ? w.list : nullptr;
-    if (nlaunch == 0) return DFH_OK;
-    DFH_REQUIRE(nlaunch < (1L << 31), "dfh_mc_emit: too many tiles");
+    if (nrows == 0) return DFH_OK;
+    const long nlaunch = (nrows + kMcBlock / 64 - 1) / (kMcBlock / 64);          // one wave per row
+    DFH_REQUIRE(nlaunch < (1L << 31), "dfh_mc_emit: too many rows");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)nlaunch);
     if (vol_dtype == DFH_F32) {
-        hipLaunchKernelGGL(mc_vertex_kernel<float>, grid, dim3(kMcBlock), 0, s, (const float *)vol, p, w.entries, w.chunk_tot, list, w.code,
-                           verts, normals, values, cap_verts);
-        hipLaunchKernelGGL(mc_face_kernel<float>, grid, dim3(kMcBlock), 0, s, (const float *)vol, p, w.entries, w.chunk_tot, list, w.code,
-                           faces, cap_faces);
-    } else {
-        hipLaunchKernelGGL(mc_vertex_kernel<double>, grid, dim3(kMcBlock), 0, s, (const double *)vol, p, w.entries, w.chunk_tot, list,
+        hipLaunchKernelGGL(mc_vertex_kernel<float>, grid, dim3(kMcBlock), 0, s, (const float *)vol, p, w.entries, w.chunk_tot, list, nrows,
                            w.code, verts, normals, values, cap_verts);
-        hipLaunchKernelGGL(mc_face_kernel<double>, grid, dim3(kMcBlock), 0, s, (const double *)vol, p, w.entries, w.chunk_tot, list, w.code,
-                           faces, cap_faces);
+        hipLaunchKernelGGL(mc_face_kernel<float>, grid, dim3(kMcBlock), 0, s, (const float *)vol, p, w.entries, w.chunk_tot, list, nrows,
+                           w.code, faces, cap_faces);
+    } else {
+        hipLaunchKernelGGL(mc_vertex_kernel<double>, grid, dim3(kMcBlock), 0, s, (const double *)vol, p, w.entries, w.chunk_tot, list, nrows,
+                           w.code, verts, normals, values, cap_verts);
+        hipLaunchKernelGGL(mc_face_kernel<double>, grid, dim3(kMcBlock), 0, s, (const double *)vol, p, w.entries, w.chunk_tot, list, nrows,
+                           w.code, faces, cap_faces);
     }
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;

@@ -1,15 +1,23 @@
-"""TEST INFRASTRUCTURE ONLY (see oracle/README or DESIGN.md §6): numpy statement of the marching-cubes
-mesh extraction that csrc/dfh_mesh.hip implements, used by tests/ as the checker.
+"""TEST INFRASTRUCTURE ONLY: numpy statement of the marching-cubes mesh extraction that
+csrc/dfh_mesh.hip implements, used by tests/ as the checker.
 
 What it stands for in the reference: `measure.marching_cubes_lewiner(tsdf, level, step_size,
 allow_degenerate=False)` as called at core/fusion_dm.py:319-331,342 and core/fusion.py:554-568
-(skimage 0.13.1, not vendored, not installed here).  skimage's Lewiner case tables are not
-available, so triangle choice inside a cube, vertex order and face order are this build's own
-(tools/gen_mc_table.py) -- "parity unpinned" for those.  Pinned by the reference's own output mesh
-meshes/original.obj (tests/golden/g9_mesh.npz): vertices lie on lattice edges at the linearly
-interpolated crossing, in array-index coordinates; unit vertex normals pointing DOWN the gradient;
-faces wound so that their right-hand normal points UP the gradient; `level=None` means
-(min+max)/2 (skimage's documented default); zero-area faces are dropped (allow_degenerate=False).
+(skimage 0.13.1: a third-party dependency, not vendored, not installed here).  Its published
+algorithm: Lewiner et al. 2003 marching cubes -- vertices on the lattice edges at the linearly
+interpolated crossing of the level, per-configuration triangle tables.  skimage's tables are not
+available, so the table is derived (tools/gen_mc_table.py).  Pinned by the reference's own output
+mesh meshes/original.obj (tests/golden/g9_mesh.npz; tests/test_mesh_oracle.py):
+  * vertices on lattice edges, array-index coordinates; unit normals pointing DOWN the gradient; faces
+    wound with their right-hand normal UP the gradient; zero-area faces dropped;
+  * faces ordered cube by cube in C order, vertices numbered by first use in the right-to-left rows;
+  * the triangulation of the 88 sign configurations that occur in that mesh (adopted from it), and
+    the cut of an ambiguous cube face (above-level corners stay connected, as in its two instances);
+  * run on a signed distance field of that mesh, the mesh's face array comes back bit for bit.
+"Parity unpinned" (nothing in the reference covers it): the triangulation of the other 168
+configurations, skimage's value-dependent resolution of ambiguous faces / cube interiors (a fixed
+rule here), its vertex normals away from smooth fields (here: lattice central differences,
+interpolated along the edge), `values`, and `level=None` = (min+max)/2 (skimage's documented default).
 
 Output order, order="lattice" (what dfh_mc_emit produces):
   vertices: by owning lattice point in C order of the (sub-sampled) volume, then by edge axis 0,1,2;

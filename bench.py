@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-gn", action="store_true", help="skip the warp-solve (GN-iters/s) leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                                                       "rehearsing >1 rank on a single GPU)")
+    ap.add_argument("--no-frame", action="store_true", help="skip the end-to-end per-frame leg (single GPU only)")
     ap.add_argument("--gn-nodes", type=int, default=512)
     ap.add_argument("--gn-solves", type=int, default=5, help="timed solves of 10 GN iterations each")
     return ap.parse_args()
@@ -144,6 +145,90 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
             "hbm_bytes_per_iter_algorithmic": alg, "hbm_GBps_algorithmic": alg / (dt / n_it) / 1e9,
             "workload": "%d^3 canonical volume, %d-node warp field, DQB warp + projective association + %d GN "
                         "iterations per solve (fp64), samples sharded by axis-0 slab" % (R, N, iters)}
+
+
+def frame_leg(args, torch, scene):
+    """One non-rigid frame at config-3 scale on one GPU, the loop of the reference's test.py:116-131
+    with this build's device path: live depth -> live TSDF (K1), 10 GN iterations of the warp field
+    against the live depth (projective association), canonical <- live through the warp field (K3),
+    canonical mesh (marching cubes) and the surface samples for the next frame."""
+    import time as _t
+    from dynamicfusion_body_amd import kernels, mesh
+    from dynamicfusion_body_amd.pipeline import FrameSolver
+    R = args.res
+    H, W, fx, cx, cy = scene.CAMERAS["C2" if R <= 256 else "C5"]
+    K = scene.intrinsics(fx, cx, cy)
+    Kinv = np.linalg.inv(K)
+    scale, center, tdist = scene.grid_params(R)
+    # K1 stores min(tdist, sd) / scale, i.e. voxel units in [-4, 4]; this composed leg keeps every stage in
+    # those units (fill value and the truncation handed to the TSDF->TSDF update = tdist / scale = 4 voxels),
+    # unlike the reference's classes, which fill and truncate with the world-unit tdist (DESIGN.md section 4, quirks)
+    tvox = tdist / scale
+    T = torch.full((R, R, R), tvox, dtype=torch.float32, device="cuda")
+    Wt = torch.zeros((R, R, R), dtype=torch.float32, device="cuda")
+    for a in (0.0, 40.0, -40.0):
+        lw = scene.view_extrinsic(a)
+        d = torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda()
+        kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist)
+    N, k, iters = args.gn_nodes, 4, 10
+    fs = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=10)
+    node_pos, node_w = scene.fibonacci_nodes(N, R)
+    ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
+    fs.set_graph(node_pos, ident, node_w)
+    fs.set_canonical(T, Wt, band=4.0)
+    lw_cam = scene.view_extrinsic(0.0)
+    nframes = 6
+    depths = []
+    for f in range(nframes):                      # the sphere drifts and breathes a little every frame
+        off = np.array([0.10, -0.07, 0.05]) * (f + 1) * scale
+        depths.append(torch.from_numpy(scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=off,
+                                                          sphere_r=scene.SPHERE_R * (1.0 + 0.004 * (f + 1)))).cuda())
+    sv = fs.solver
+    ws = kernels.dqb_workspace((R, R, R))
+    live = torch.empty_like(T)
+    live_w = torch.empty_like(T)
+    ident_lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+    stages = {"live_tsdf": 0.0, "solve": 0.0, "tsdf_update": 0.0, "mesh": 0.0, "samples": 0.0}
+    info = {}
+
+    def frame(f, timed):
+        def mark(name, t0):
+            if timed:
+                torch.cuda.synchronize()
+                stages[name] += _t.perf_counter() - t0
+            return _t.perf_counter()
+        t0 = _t.perf_counter()
+        live.fill_(tvox); live_w.zero_()
+        kernels.integrate_depth(live, live_w, depths[f], K, Kinv, lw_cam, scale, center, tdist)
+        t0 = mark("live_tsdf", t0)
+        for _ in range(iters):
+            fs.gn_iteration(depths[f], lw_cam, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0)
+        t0 = mark("solve", t0)
+        kernels.fuse_volume_dqb(T, Wt, live, sv.node_pos, sv.node_dq, sv.node_w, k, ident_lw, tvox, workspace=ws,
+                                rebuild_candidates=(f == 0))
+        t0 = mark("tsdf_update", t0)
+        v, fc, n, val = mesh.marching_cubes(T, 0.0)
+        info["vertices"], info["faces"] = int(v.shape[0]), int(fc.shape[0])
+        t0 = mark("mesh", t0)
+        info["samples"] = fs.set_canonical(T, Wt, band=4.0)
+        mark("samples", t0)
+
+    frame(0, False)                               # warm-up (allocations, block pattern, candidate lists)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    for f in range(1, nframes):
+        frame(f, False)
+    torch.cuda.synchronize()
+    dt = (_t.perf_counter() - t0) / (nframes - 1)
+    for f in range(1, nframes):                   # second pass with a sync after every stage: the breakdown
+        frame(f, True)
+    cost, cnt = sv.cost()
+    return {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "frames_timed": nframes - 1,
+            "stage_ms": {kk: vv / (nframes - 1) * 1e3 for kk, vv in stages.items()},
+            "gn_iters_per_frame": iters, "nodes": N, "samples": info["samples"], "mesh_vertices": info["vertices"],
+            "mesh_faces": info["faces"], "final_cost": cost,
+            "workload": "%d^3, %d nodes: live TSDF (1 view) + %d GN iterations + DQB TSDF update + marching cubes + "
+                        "sample refresh, per frame, one GPU" % (R, N, iters)}
 
 
 def pmc_traffic(kernel_substr, res):
@@ -316,6 +401,8 @@ def main():
     if not args.no_gn:
         del T, Wt
         out["gn"] = gn_leg(args, torch, dist, scene, rank, world, barrier)
+        if world == 1 and not args.no_frame:
+            out["frame"] = frame_leg(args, torch, scene)
 
     if distributed:
         dist.barrier()

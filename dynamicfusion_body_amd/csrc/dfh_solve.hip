@@ -1305,7 +1305,7 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
     DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + 3 * ((size_t)iters + 2) + 2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4)), s));
     PcgParams p{n_nodes, lm_abs, lm_rel};
     dim3 grid((n_nodes + 255) / 256), block(256);
-    // One persistent launch when every row can have its own co-resident wave (N <= 16 waves x #CUs)
+    // One persistent launch when every row can have its own co-resident wave (N <= 16 waves x #CUs / 2)
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -1315,7 +1315,8 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
     int wpb = n_nodes <= 8 * 64 ? 8 : 16;             // fat workgroups: <= 64 partial sums per reduction where possible
     if (const char *e = getenv("DFH_PCG_WPB")) { const int v = atoi(e); if (v == 4 || v == 8) wpb = v; }
     const int nblk = (n_nodes + wpb - 1) / wpb;
-    if (nblk <= n_cu && nblk <= kMaxPcgBlocks && !getenv("DFH_PCG_MULTILAUNCH")) {
+    // at most half the CUs: two processes sharing the GPU can both be fully resident (no mutual starvation)
+    if (2 * nblk <= n_cu && nblk <= kMaxPcgBlocks && !getenv("DFH_PCG_MULTILAUNCH")) {
         unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
         double *part = scal + 3 * ((size_t)iters + 2);                                    // (2 per iteration + 1) reductions x nblk slots
         hipLaunchKernelGGL(pcg_persistent_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, z, pA, pB,

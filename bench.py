@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-gn", action="store_true", help="skip the warp-solve (GN-iters/s) leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                                                       "rehearsing >1 rank on a single GPU)")
-    ap.add_argument("--no-frame", action="store_true", help="skip the end-to-end per-frame leg (single GPU only)")
+    ap.add_argument("--no-frame", action="store_true", help="skip the end-to-end per-frame leg")
     ap.add_argument("--gn-nodes", type=int, default=512)
     ap.add_argument("--gn-solves", type=int, default=5, help="timed solves of 10 GN iterations each")
     return ap.parse_args()
@@ -147,35 +147,30 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
                         "iterations per solve (fp64), samples sharded by axis-0 slab" % (R, N, iters)}
 
 
-def frame_leg(args, torch, scene):
-    """One non-rigid frame at config-3 scale on one GPU, the loop of the reference's test.py:116-131
-    with this build's device path: live depth -> live TSDF (K1), 10 GN iterations of the warp field
-    against the live depth (projective association), canonical <- live through the warp field (K3),
-    canonical mesh (marching cubes) and the surface samples for the next frame."""
+def frame_leg(args, torch, dist, scene, rank, world, barrier):
+    """One non-rigid frame at config-3 scale, the loop of the reference's test.py:116-131 with this build's
+    device path (pipeline.SlabFrame): live depth -> live TSDF slab (K1) -> all-gather of the live volume
+    (N > 1) -> 10 GN iterations against the live depth (one all-reduce each) -> canonical slab <- live through
+    the warp field (K3) -> surface samples for the next frame (+ marching cubes of the canonical volume on one
+    GPU).  Strong scaling at N > 1: the SAME res^3 grid cut into axis-0 slabs."""
     import time as _t
-    from dynamicfusion_body_amd import kernels, mesh
-    from dynamicfusion_body_amd.pipeline import FrameSolver
+    from dynamicfusion_body_amd import mesh
+    from dynamicfusion_body_amd import dist as D
+    from dynamicfusion_body_amd.pipeline import SlabFrame
     R = args.res
     H, W, fx, cx, cy = scene.CAMERAS["C2" if R <= 256 else "C5"]
     K = scene.intrinsics(fx, cx, cy)
-    Kinv = np.linalg.inv(K)
     scale, center, tdist = scene.grid_params(R)
-    # K1 stores min(tdist, sd) / scale, i.e. voxel units in [-4, 4]; this composed leg keeps every stage in
-    # those units (fill value and the truncation handed to the TSDF->TSDF update = tdist / scale = 4 voxels),
-    # unlike the reference's classes, which fill and truncate with the world-unit tdist (DESIGN.md section 4, quirks)
-    tvox = tdist / scale
-    T = torch.full((R, R, R), tvox, dtype=torch.float32, device="cuda")
-    Wt = torch.zeros((R, R, R), dtype=torch.float32, device="cuda")
+    N, iters = args.gn_nodes, 10
+    node_pos, node_w = scene.fibonacci_nodes(N, R)
+    # K1 stores min(tdist, sd) / scale, i.e. voxel units in [-4, 4]; this composed loop keeps every stage in those
+    # units (fill value and the truncation of the TSDF->TSDF update = tdist / scale = 4 voxels), unlike the
+    # reference's classes, which fill and truncate with the world-unit tdist (DESIGN.md section 4, quirks)
+    sf = SlabFrame(K, scale, center, R, tdist / scale, node_pos, node_w, knn=4, pcg_iters=10, band=4.0)
     for a in (0.0, 40.0, -40.0):
         lw = scene.view_extrinsic(a)
-        d = torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda()
-        kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist)
-    N, k, iters = args.gn_nodes, 4, 10
-    fs = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=10)
-    node_pos, node_w = scene.fibonacci_nodes(N, R)
-    ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
-    fs.set_graph(node_pos, ident, node_w)
-    fs.set_canonical(T, Wt, band=4.0)
+        sf.integrate(torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda(), lw)
+    sf.refresh_samples()
     lw_cam = scene.view_extrinsic(0.0)
     nframes = 6
     depths = []
@@ -183,52 +178,32 @@ def frame_leg(args, torch, scene):
         off = np.array([0.10, -0.07, 0.05]) * (f + 1) * scale
         depths.append(torch.from_numpy(scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=off,
                                                           sphere_r=scene.SPHERE_R * (1.0 + 0.004 * (f + 1)))).cuda())
-    sv = fs.solver
-    ws = kernels.dqb_workspace((R, R, R))
-    live = torch.empty_like(T)
-    live_w = torch.empty_like(T)
-    ident_lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
-    stages = {"live_tsdf": 0.0, "solve": 0.0, "tsdf_update": 0.0, "mesh": 0.0, "samples": 0.0}
-    info = {}
+    info = {"vertices": None, "faces": None}
 
-    def frame(f, timed):
-        def mark(name, t0):
-            if timed:
-                torch.cuda.synchronize()
-                stages[name] += _t.perf_counter() - t0
-            return _t.perf_counter()
-        t0 = _t.perf_counter()
-        live.fill_(tvox); live_w.zero_()
-        kernels.integrate_depth(live, live_w, depths[f], K, Kinv, lw_cam, scale, center, tdist)
-        t0 = mark("live_tsdf", t0)
-        for _ in range(iters):
-            fs.gn_iteration(depths[f], lw_cam, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0)
-        t0 = mark("solve", t0)
-        kernels.fuse_volume_dqb(T, Wt, live, sv.node_pos, sv.node_dq, sv.node_w, k, ident_lw, tvox, workspace=ws,
-                                rebuild_candidates=(f == 0))
-        t0 = mark("tsdf_update", t0)
-        v, fc, n, val = mesh.marching_cubes(T, 0.0)
-        info["vertices"], info["faces"] = int(v.shape[0]), int(fc.shape[0])
-        t0 = mark("mesh", t0)
-        info["samples"] = fs.set_canonical(T, Wt, band=4.0)
-        mark("samples", t0)
+    def frame(f):
+        info["samples"] = sf.step(depths[f], lw_cam, gn_iters=iters)
+        if world == 1:
+            v, fc, n, val = mesh.marching_cubes(sf.T, 0.0)
+            info["vertices"], info["faces"] = int(v.shape[0]), int(fc.shape[0])
 
-    frame(0, False)                               # warm-up (allocations, block pattern, candidate lists)
-    torch.cuda.synchronize()
+    frame(0)                                      # warm-up (allocations, block pattern, candidate lists)
+    barrier()
     t0 = _t.perf_counter()
     for f in range(1, nframes):
-        frame(f, False)
-    torch.cuda.synchronize()
-    dt = (_t.perf_counter() - t0) / (nframes - 1)
-    for f in range(1, nframes):                   # second pass with a sync after every stage: the breakdown
-        frame(f, True)
-    cost, cnt = sv.cost()
-    return {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "frames_timed": nframes - 1,
-            "stage_ms": {kk: vv / (nframes - 1) * 1e3 for kk, vv in stages.items()},
-            "gn_iters_per_frame": iters, "nodes": N, "samples": info["samples"], "mesh_vertices": info["vertices"],
+        frame(f)
+    barrier()
+    dt = D.max_over_ranks([(_t.perf_counter() - t0) / (nframes - 1)])[0]
+    cost, cnt = sf.fs.solver.cost()
+    tot = torch.tensor([float(info["samples"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot)
+    return {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "frames_timed": nframes - 1, "scaling": "strong" if world > 1 else "n/a",
+            "gn_iters_per_frame": iters, "nodes": N, "samples": int(tot.item()), "mesh_vertices": info["vertices"],
             "mesh_faces": info["faces"], "final_cost": cost,
-            "workload": "%d^3, %d nodes: live TSDF (1 view) + %d GN iterations + DQB TSDF update + marching cubes + "
-                        "sample refresh, per frame, one GPU" % (R, N, iters)}
+            "exchange": "none" if world == 1 else "per frame: all-gather of the live volume (%.0f MB) + face-plane halo; per GN "
+                                                  "iteration: one all-reduce of the normal equations" % (R ** 3 * 4 / 1e6),
+            "workload": "%d^3 grid in %d axis-0 slab(s), %d nodes: live TSDF (1 view) + %d GN iterations + DQB TSDF update + "
+                        "sample refresh%s, per frame" % (R, world, N, iters, " + marching cubes" if world == 1 else "")}
 
 
 def pmc_traffic(kernel_substr, res):
@@ -400,9 +375,15 @@ def main():
 
     if not args.no_gn:
         del T, Wt
-        out["gn"] = gn_leg(args, torch, dist, scene, rank, world, barrier)
-        if world == 1 and not args.no_frame:
-            out["frame"] = frame_leg(args, torch, scene)
+        try:
+            out["gn"] = gn_leg(args, torch, dist, scene, rank, world, barrier)
+        except Exception as e:                        # a failure here must not cost the headline line
+            out["gn"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if not args.no_frame:
+            try:
+                out["frame"] = frame_leg(args, torch, dist, scene, rank, world, barrier)
+            except Exception as e:                    # the composed leg must never cost the headline line
+                out["frame"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     if distributed:
         dist.barrier()

@@ -3,6 +3,9 @@ RCCL over xGMI), the voxel grid cut into contiguous slabs along array axis 0 (th
 [x][y][z]; BASELINE north_star calls it the "Z-slab"), no exchange for TSDF integration, and ONE
 all-reduce(sum) per Gauss-Newton iteration over the flat buffer {J^T J blocks | J^T r | cost, count}
 (a few MB: latency-bound on xGMI, so it is a single collective, never one per tensor).
+The TSDF->TSDF update (K2/K3) samples the LIVE volume at warped positions, i.e. across slab faces: the
+live slabs are all-gathered once per frame (`allgather_planes`: one collective of the whole volume,
+bandwidth-bound: 67 MB at 256^3).
 
 Every function here also works on CPU tensors with the gloo backend (tests/test_dist_gloo.py)."""
 import torch
@@ -41,6 +44,61 @@ def union_sorted_keys(keys):
     dist.all_gather(parts, pad)
     allk = torch.cat(parts)
     return torch.unique(allk[allk >= 0])
+
+
+def allgather_planes(local, n_planes):
+    """Slabs of axis 0 (rank r holds planes slab_range(n_planes, r, world)) -> the whole volume on every
+    rank.  One all-gather of equal-sized (padded by at most one plane) buffers straight into the result."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    a, b = slab_range(n_planes, rank, ws)
+    if local.shape[0] != b - a:
+        raise ValueError("rank %d holds %d planes, its slab has %d" % (rank, local.shape[0], b - a))
+    plane = local.shape[1:]
+    m = -(-int(n_planes) // ws)                                   # largest slab
+    if n_planes % ws == 0:
+        full = torch.empty((n_planes,) + tuple(plane), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full, local.contiguous())
+        return full
+    buf = torch.zeros((m,) + tuple(plane), dtype=local.dtype, device=local.device)
+    buf[:b - a] = local
+    gathered = torch.empty((ws * m,) + tuple(plane), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, buf)
+    full = torch.empty((n_planes,) + tuple(plane), dtype=local.dtype, device=local.device)
+    for r in range(ws):
+        ra, rb = slab_range(n_planes, r, ws)
+        full[ra:rb] = gathered[r * m:r * m + (rb - ra)]
+    return full
+
+
+def halo_planes(local, n_planes):
+    """(plane a-1, plane b) of the neighbouring slabs, None at the ends of the grid: every rank contributes
+    its first and last plane to one all-gather (2 planes per rank: 0.5 MB at 256^2 fp32)."""
+    rank, ws = world()
+    if ws == 1:
+        return None, None
+    a, b = slab_range(n_planes, rank, ws)
+    if local.shape[0] != b - a:
+        raise ValueError("rank %d holds %d planes, its slab has %d" % (rank, local.shape[0], b - a))
+    mine = torch.zeros((2,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if b > a:
+        mine[0] = local[0]
+        mine[1] = local[-1]
+    allp = torch.empty((2 * ws,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(allp, mine)
+    lo = hi = None
+    for r in range(rank - 1, -1, -1):                 # nearest non-empty slab below / above
+        ra, rb = slab_range(n_planes, r, ws)
+        if rb > ra:
+            lo = allp[2 * r + 1]
+            break
+    for r in range(rank + 1, ws):
+        ra, rb = slab_range(n_planes, r, ws)
+        if rb > ra:
+            hi = allp[2 * r]
+            break
+    return lo, hi
 
 
 def allreduce_system(flat):

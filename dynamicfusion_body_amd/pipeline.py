@@ -72,11 +72,11 @@ def extract_surface_samples_torch(T, Wt, band, x0=0, max_samples=None):
 class FrameSolver:
     """Warp-field estimation of one live depth frame against the canonical volume."""
 
-    def __init__(self, K, scale, center, half, knn=4, pcg_iters=10):
+    def __init__(self, K, scale, center, half, knn=4, pcg_iters=10, distributed=True):
         self.K = np.asarray(K, dtype=np.float64)
         self.Kinv = np.linalg.inv(self.K)
         self.scale, self.center, self.half = float(scale), np.asarray(center, dtype=np.float64), float(half)
-        self.solver = WarpSolver(knn=knn, pcg_iters=pcg_iters)
+        self.solver = WarpSolver(knn=knn, pcg_iters=pcg_iters, distributed=distributed)
         self.knn = knn
         self.lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
 
@@ -101,3 +101,72 @@ class FrameSolver:
             self.gn_iteration(depth, lw_cam, rw, **kw)
             costs.append(self.solver.cost())
         return costs
+
+
+class SlabFrame:
+    """One rank's share of the per-frame loop (reference test.py:116-131) with the canonical volume cut into
+    axis-0 slabs: live depth -> this rank's live slab (K1, no exchange) -> all-gather of the live volume ->
+    GN iterations (samples of this slab; one all-reduce of the normal equations per iteration) -> canonical
+    slab <- live volume through the warp field (K3) -> this slab's samples for the next frame.
+    With one rank it is the single-GPU frame."""
+
+    def __init__(self, K, scale, center, res, tdist_vox, node_pos, node_w, knn=4, pcg_iters=10, band=4.0, volume_dtype=torch.float32,
+                 distributed=True):
+        from . import dist as D
+        self.D = D
+        self.distributed = bool(distributed)
+        self.R = int(res)
+        self.K = np.asarray(K, dtype=np.float64)
+        self.Kinv = np.linalg.inv(self.K)
+        self.scale, self.center, self.tvox = float(scale), np.asarray(center, dtype=np.float64), float(tdist_vox)
+        self.tdist_world = self.tvox * self.scale
+        self.rank, self.ws = D.world() if self.distributed else (0, 1)     # distributed=False: the whole grid, no collectives
+        self.a, self.b = D.slab_range(self.R, self.rank, self.ws)
+        R = self.R
+        self.T = torch.full((self.b - self.a, R, R), self.tvox, dtype=volume_dtype, device="cuda")
+        self.Wt = torch.zeros_like(self.T)
+        self.live = torch.empty_like(self.T)
+        self.live_w = torch.empty_like(self.T)
+        self.band, self.knn = float(band), int(knn)
+        self.fs = FrameSolver(K, scale, center, R / 2, knn=knn, pcg_iters=pcg_iters, distributed=self.distributed)
+        N = len(node_pos)
+        ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
+        self.fs.set_graph(node_pos, ident, node_w)
+        self.ws_dqb = kernels.dqb_workspace((R, R, R), (self.a, self.b))
+        self._first = True
+        self.ident_lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+
+    def integrate(self, depth, lw_cam):
+        """Fuse a depth map into this rank's canonical slab (initial frames)."""
+        R = self.R
+        kernels.integrate_depth(self.T, self.Wt, depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.tdist_world,
+                                tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b))
+
+    def refresh_samples(self):
+        """Samples of this slab.  Normals are central differences of T, also across the slab faces: the
+        neighbours' face planes come as a halo whose weight is 0 (they feed gradients, never samples), so the
+        union over ranks is exactly the whole-grid sample set."""
+        if self.ws == 1:
+            return self.fs.set_canonical(self.T, self.Wt, band=self.band, x0=self.a)
+        lo, hi = self.D.halo_planes(self.T, self.R)
+        Tp, Wp, x0 = [self.T], [self.Wt], self.a
+        if lo is not None:
+            Tp.insert(0, lo[None]); Wp.insert(0, torch.zeros_like(lo)[None]); x0 -= 1
+        if hi is not None:
+            Tp.append(hi[None]); Wp.append(torch.zeros_like(hi)[None])
+        return self.fs.set_canonical(torch.cat(Tp).contiguous(), torch.cat(Wp).contiguous(), band=self.band, x0=x0)
+
+    def step(self, depth, lw_cam, gn_iters=10, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0):
+        R = self.R
+        self.live.fill_(self.tvox)
+        self.live_w.zero_()
+        kernels.integrate_depth(self.live, self.live_w, depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.tdist_world,
+                                tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b))
+        live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
+        for _ in range(gn_iters):
+            self.fs.gn_iteration(depth, lw_cam, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist)
+        sv = self.fs.solver
+        kernels.fuse_volume_dqb(self.T, self.Wt, live_full, sv.node_pos, sv.node_dq, sv.node_w, self.knn, self.ident_lw, self.tvox,
+                                res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_dqb, rebuild_candidates=self._first)
+        self._first = False
+        return self.refresh_samples()

@@ -29,6 +29,8 @@ def test_slab_range_covers_exactly():
     t = torch.arange(4.0)
     assert D.allreduce_system(t) is t and D.max_over_ranks([1.0, 2.0]) == [1.0, 2.0]
     assert torch.equal(D.union_sorted_keys(torch.tensor([5, 1, 5, 3])), torch.tensor([1, 3, 5]))
+    v = torch.zeros(4, 2, 2)
+    assert D.allgather_planes(v, 4) is v and D.halo_planes(v, 4) == (None, None)
 
 
 def _free_port():
@@ -58,6 +60,23 @@ def _worker(rank, ws, port, out):
         assert torch.equal(part, full)
         mx = D.max_over_ranks([float(rank), 1.0 - rank])
         assert mx == [float(ws - 1), 1.0]
+        # live volume: slabs -> whole volume on every rank (even and uneven plane counts)
+        for planes in (10, 7):
+            vol = torch.arange(planes * 3 * 2, dtype=torch.float32).reshape(planes, 3, 2)
+            pa, pb = D.slab_range(planes, rank, ws)
+            assert torch.equal(D.allgather_planes(vol[pa:pb].clone(), planes), vol)
+        for planes in (10, 7):
+            vol = torch.arange(planes * 3 * 2, dtype=torch.float32).reshape(planes, 3, 2)
+            pa, pb = D.slab_range(planes, rank, ws)
+            lo, hi = D.halo_planes(vol[pa:pb].clone(), planes)
+            assert (lo is None) == (pa == 0) and (hi is None) == (pb == planes)
+            assert lo is None or torch.equal(lo, vol[pa - 1])
+            assert hi is None or torch.equal(hi, vol[pb])
+        try:
+            D.allgather_planes(torch.zeros(1, 3, 2), 10)
+            raise AssertionError("wrong slab size not rejected")
+        except ValueError:
+            pass
         out[rank] = 1
     finally:
         dist.destroy_process_group()

@@ -471,7 +471,11 @@ __device__ __forceinline__ double data_row(const double *__restrict__ node_dq, c
 
 // One 256-sample tile per block.  Samples must be sorted by their k-tuple of nodes (any order
 // is CORRECT; sorted order just means few runs per tile and therefore few atomics).
-template <int K>
+// PLANNED: the (tile, tuple) runs are static per frame, so each run owns a row of `partial`
+// ({upper triangle of its (6K)^2 Gram matrix | J^T r | 0.5 r^2 | count}, row = run_id[first sample]) and the
+// sums are STORED there; gn_gather_kernel then adds the rows into the blocks through a precomputed incidence
+// list: no floating-point atomics, same bits every run, about half the memory operations.
+template <int K, bool PLANNED>
 __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
                                                              const int *__restrict__ nbr, const double *__restrict__ wts,
                                                              const double *__restrict__ corr,
@@ -479,12 +483,12 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
                                                              const double *__restrict__ node_dq, const BuildParams p,
                                                              const int *__restrict__ row_ptr, const int *__restrict__ col,
                                                              double *__restrict__ vals, double *__restrict__ rhs,
-                                                             double *__restrict__ cost_count) {
+                                                             double *__restrict__ cost_count, const int *__restrict__ run_id,
+                                                             double *__restrict__ partial) {
     constexpr int NJ = 6 * K;                   // Jacobian entries per sample
     constexpr int LD = NJ + 1;                  // + residual
     __shared__ double sJ[kTile * LD];
     __shared__ int sIdx[kTile * K];
-    __shared__ int sHead[kTile];                // 1 where a run of equal tuples starts
     const int tid = threadIdx.x;
     const int s = blockIdx.x * kTile + tid;
     const int tile_n = min(kTile, p.S - blockIdx.x * kTile);
@@ -500,8 +504,10 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     for (int w_ = 0; w_ < wv; ++w_) pos += sWaveCnt[w_];
     const int n_valid = sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
     if (n_valid == 0) return;                                        // tiles without a valid sample contribute nothing
-    if (tid == 0) atomicAdd(cost_count + 1, (double)n_valid);        // valid-sample count
+    if (!PLANNED && tid == 0) atomicAdd(cost_count + 1, (double)n_valid);        // valid-sample count
+    __shared__ int sRow[PLANNED ? kTile : 1];                        // partial row of every compacted sample
     if (act) {
+        if (PLANNED) sRow[pos] = run_id[s];
         double Jrow[NJ];
         int idx[kKMaxS];
         double w[kKMaxS];
@@ -532,11 +538,15 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
                 for (int j = 0; j < K; ++j) head = head || (sIdx[tid * K + j] != sIdx[(tid - 1) * K + j]);
             }
         }
-        sHead[tid] = head ? 1 : 0;
+        // positions of the heads by ballot + prefix (same scheme as the compaction above)
+        const unsigned long long hb = __ballot(head);
+        if (lane == 0) sWaveCnt[wv] = __popcll(hb);       // (every thread passed the barrier after the first use)
         __syncthreads();
+        int hp = __popcll(hb & ((1ull << lane) - 1ull));
+        for (int w_ = 0; w_ < wv; ++w_) hp += sWaveCnt[w_];
+        if (head) sRun[hp] = tid;
         if (tid == 0) {
-            int n = 0;
-            for (int t = 0; t < n_valid; ++t) if (sHead[t]) sRun[n++] = t;
+            const int n = sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
             sRun[n] = n_valid;
             sNRuns = n;
         }
@@ -544,7 +554,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     }
     const int n_runs = sNRuns;
     // block index of every (slot a, slot b) node pair of every run, searched once, in parallel
-    constexpr bool kBlkTable = K <= 4;                     // 256 runs x K^2 ints must fit next to sJ
+    constexpr bool kBlkTable = K <= 4 && !PLANNED;         // 256 runs x K^2 ints must fit next to sJ
     __shared__ int sBlk[kBlkTable ? kTile * K * K : 1];
     if (kBlkTable) {
         for (int q = tid; q < n_runs * K * K; q += 256) {
@@ -556,6 +566,9 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     }
     // entries: upper triangle of the NJ x NJ Gram matrix, then NJ entries of J^T r, then cost
     constexpr int NUP = NJ * (NJ + 1) / 2;
+    if (PLANNED) {
+        if (tid < n_runs) partial[(size_t)sRow[sRun[tid]] * (NUP + NJ + 2) + NUP + NJ + 1] = (double)(sRun[tid + 1] - sRun[tid]);
+    }
     for (int e = tid; e < NUP + NJ + 1; e += 256) {
         int pa, pb;                              // Jacobian columns of this entry (pb == NJ: residual)
         if (e < NUP) {
@@ -569,14 +582,22 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         }
         for (int rn = 0; rn < n_runs; ++rn) {
             const int t0 = sRun[rn], t1 = sRun[rn + 1];
-            double acc0 = 0.0, acc1 = 0.0;
+            // four independent chains: the loop is bound by LDS latency, not bandwidth (fixed association order)
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
             int t = t0;
-            for (; t + 1 < t1; t += 2) {
-                acc0 += sJ[t * LD + pa] * sJ[t * LD + pb];
-                acc1 += sJ[(t + 1) * LD + pa] * sJ[(t + 1) * LD + pb];
+            for (; t + 3 < t1; t += 4) {
+                const double a0 = sJ[t * LD + pa], b0 = sJ[t * LD + pb];
+                const double a1 = sJ[(t + 1) * LD + pa], b1 = sJ[(t + 1) * LD + pb];
+                const double a2 = sJ[(t + 2) * LD + pa], b2 = sJ[(t + 2) * LD + pb];
+                const double a3 = sJ[(t + 3) * LD + pa], b3 = sJ[(t + 3) * LD + pb];
+                acc0 += a0 * b0; acc1 += a1 * b1; acc2 += a2 * b2; acc3 += a3 * b3;
             }
-            if (t < t1) acc0 += sJ[t * LD + pa] * sJ[t * LD + pb];
-            const double acc = acc0 + acc1;
+            for (; t < t1; ++t) acc0 += sJ[t * LD + pa] * sJ[t * LD + pb];
+            const double acc = (acc0 + acc1) + (acc2 + acc3);
+            if (PLANNED) {
+                partial[(size_t)sRow[t0] * (NUP + NJ + 2) + e] = pa == NJ ? 0.5 * acc : acc;
+                continue;
+            }
             if (acc == 0.0) continue;
             if (pb == NJ && pa == NJ) {
                 atomicAdd(cost_count, 0.5 * acc);
@@ -597,6 +618,88 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     }
 }
 
+// Second half of the planned build.  Workgroups [0, n_blocks): one per 6x6 block (a,b); its four waves take
+// every fourth entry of the block's list (blk_ent = row * K^2 + sa * K + sb), lanes 0..35 own entry (ia, ib) of the
+// block, and the four partial sums are added in a fixed order.  Next workgroups: J^T r, one wave per node, lane
+// (j, i) takes every tenth entry of the node's list (node_ent = row * K + slot) for unknown i.  Last workgroup:
+// cost and valid count, a fixed-order tree over the rows.  Lists are walked two entries at a time so that the
+// dependent index -> value loads of consecutive entries overlap.
+template <int K>
+__global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict__ partial, int n_rows, const int *__restrict__ blk_ptr,
+                                                        const int *__restrict__ blk_ent, int n_blocks,
+                                                        const int *__restrict__ node_ptr, const int *__restrict__ node_ent,
+                                                        int n_nodes, double *__restrict__ vals, double *__restrict__ rhs,
+                                                        double *__restrict__ cost_count, bool accumulate) {
+    // accumulate: add to what is there (second gather of the same build: the regulariser rows) instead of storing
+    constexpr int NJ = 6 * K, NUP = NJ * (NJ + 1) / 2, NE = NUP + NJ + 2;
+    const int nrw = (n_nodes + 3) / 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ double red[4][64];
+    if ((int)blockIdx.x < n_blocks) {
+        const int b = (int)blockIdx.x;
+        const int ia = (lane % 36) / 6, ib = lane % 6;
+        auto value = [&](int ent) {
+            const int row = ent / (K * K), pr = ent - row * (K * K);
+            int pa = (pr / K) * 6 + ia, pb = (pr % K) * 6 + ib;
+            if (pa > pb) { const int t = pa; pa = pb; pb = t; }
+            return partial[(size_t)row * NE + (pa * NJ - (pa * (pa - 1)) / 2 + (pb - pa))];
+        };
+        const int beg = blk_ptr[b], end = blk_ptr[b + 1];
+        double acc = 0.0;
+        if (lane < 36) {
+            int q = beg + wv;
+            for (; q + 4 < end; q += 8) {
+                const int e0 = blk_ent[q], e1 = blk_ent[q + 4];
+                const double v0 = value(e0), v1 = value(e1);
+                acc += v0;
+                acc += v1;
+            }
+            if (q < end) acc += value(blk_ent[q]);
+        }
+        red[wv][lane] = acc;
+        __syncthreads();
+        if (threadIdx.x < 36) {
+            const double v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+            double *dst = vals + 36 * (size_t)b + threadIdx.x;
+            *dst = accumulate ? *dst + v : v;
+        }
+    } else if ((int)blockIdx.x < n_blocks + nrw) {
+        const int a = ((int)blockIdx.x - n_blocks) * 4 + wv;
+        double acc = 0.0;
+        const int j = lane / 6, i = lane - 6 * j;                  // lanes 60..63 idle
+        if (a < n_nodes && j < 10) {
+            const int beg = node_ptr[a], end = node_ptr[a + 1];
+            for (int q = beg + j; q < end; q += 10) {
+                const int ent = node_ent[q];
+                const int row = ent / K, slot = ent - row * K;
+                acc += partial[(size_t)row * NE + NUP + slot * 6 + i];
+            }
+        }
+        double tot = acc;
+#pragma unroll
+        for (int k = 1; k < 10; ++k) {
+            const double o = __shfl(acc, lane + 6 * k, 64);
+            tot += (lane + 6 * k < 60) ? o : 0.0;
+        }
+        if (a < n_nodes && lane < 6) rhs[6 * a + lane] = accumulate ? rhs[6 * a + lane] + tot : tot;
+    } else {
+        double c = 0.0, n = 0.0;
+        for (int r = (int)threadIdx.x; r < n_rows; r += 256) {
+            c += partial[(size_t)r * NE + NUP + NJ];
+            n += partial[(size_t)r * NE + NUP + NJ + 1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); n += __shfl_xor(n, o, 64); }
+        if (lane == 0) { red[0][wv] = c; red[1][wv] = n; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double c0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3], c1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+            cost_count[0] = accumulate ? cost_count[0] + c0 : c0;
+            cost_count[1] = accumulate ? cost_count[1] + c1 : c1;
+        }
+    }
+}
+
 // Regularisation rows rho_ij = c_ij (W(q_i,v_j) - W(q_j,v_j)): one WAVE per (i, slot); lanes 0..35
 // own one entry (a,b) of the four 6x6 blocks (ii, jj, ij, ji), lanes 0..5 also the gradient, so the
 // ~150 fp64 atomics of a pair are issued side by side instead of one after the other.
@@ -606,13 +709,20 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
                                                             const double *__restrict__ node_w, double rw,
                                                             const int *__restrict__ row_ptr, const int *__restrict__ col,
                                                             double *__restrict__ vals, double *__restrict__ rhs,
-                                                            double *__restrict__ cost_count) {
+                                                            double *__restrict__ cost_count, double *__restrict__ partial_reg) {
+    // partial_reg != NULL (planned build): the pair's {upper triangle of the 12x12 Gram matrix of [J_i | J_j] |
+    // J^T rho | 0.5 rho^2 | 0} is STORED in row t (92 doubles) and gathered like a 2-node data row: no atomics.
+    constexpr int NE2 = 78 + 12 + 2;
+    auto up = [](int pa, int pb) { return pa * 12 - (pa * (pa - 1)) / 2 + (pb - pa); };
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= N * k) return;
     const int i = t / k;
     const int j = node_nbr[t];
-    if (i == j) return;                                            // zero rows, zero Jacobian
+    if (i == j) {                                                  // zero rows, zero Jacobian
+        if (partial_reg) for (int e = lane; e < NE2; e += 64) partial_reg[(size_t)t * NE2 + e] = 0.0;
+        return;
+    }
     const double vx = round_f32(node_pos[3 * j]), vy = round_f32(node_pos[3 * j + 1]), vz = round_f32(node_pos[3 * j + 2]);
     const double *qi = node_dq + 8 * i, *qj = node_dq + 8 * j;
     const D3 yi = dqb_warp_exact(qi, vx, vy, vz);
@@ -638,6 +748,19 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
         const double vjj = (ja[0] * jb[0] + ja[1] * jb[1]) + ja[2] * jb[2];
         const double vij = (ia[0] * jb[0] + ia[1] * jb[1]) + ia[2] * jb[2];
         const double vji = (ja[0] * ib[0] + ja[1] * ib[1]) + ja[2] * ib[2];
+        if (partial_reg) {
+            double *P = partial_reg + (size_t)t * NE2;
+            if (a <= b) { P[up(a, b)] = vii; P[up(6 + a, 6 + b)] = vjj; }
+            P[up(a, 6 + b)] = vij;                                 // (G[6+a][b] is lane (b,a)'s vij)
+            if (lane < 6) {
+                double gi[3], gj[3];
+                Jcol(yi, 1.0, si, lane, gi); Jcol(yj, -1.0, sj, lane, gj);
+                P[78 + lane] = (gi[0] * rho[0] + gi[1] * rho[1]) + gi[2] * rho[2];
+                P[84 + lane] = (gj[0] * rho[0] + gj[1] * rho[1]) + gj[2] * rho[2];
+            }
+            if (lane == 0) { P[90] = 0.5 * ((rho[0] * rho[0] + rho[1] * rho[1]) + rho[2] * rho[2]); P[91] = 0.0; }
+            return;
+        }
         const int bii = find_block(row_ptr, col, i, i), bjj = find_block(row_ptr, col, j, j);
         const int bij = find_block(row_ptr, col, i, j), bji = find_block(row_ptr, col, j, i);
         if (bii >= 0 && vii != 0.0) atomicAdd(vals + 36 * (size_t)bii + lane, vii);
@@ -1235,17 +1358,31 @@ int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *wei
     return DFH_OK;
 }
 
-int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
-                 const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,
-                 const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
-                 const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
-                 double *rhs, double *cost_count, void *stream) {
+static int gn_build_impl(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                         const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,
+                         const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                         const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                         double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                         const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                         const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, void *stream) {
     using namespace dfh;
+    const bool planned = blk_ptr != nullptr;
+    const bool planned_reg = planned && partial_reg != nullptr;
+    if (planned_reg) DFH_REQUIRE(rblk_ptr && rblk_ent && rnode_ptr && rnode_ent, "dfh_gn_build_planned: null regulariser plan array");
     DFH_REQUIRE(n_samples >= 0 && n_nodes >= 1 && n_blocks >= 1, "dfh_gn_build: bad sizes");
     DFH_REQUIRE(knn >= 1 && knn <= kKMaxS, "dfh_gn_build: knn=%d outside [1,%d]", knn, kKMaxS);
     DFH_REQUIRE(node_dq && node_pos && node_w && lw_dq && row_ptr && col && vals && rhs && cost_count, "dfh_gn_build: null pointer");
+    if (planned) {
+        DFH_REQUIRE(n_rows >= 0 && blk_ent && node_ptr && node_ent, "dfh_gn_build_planned: null plan array");
+        DFH_REQUIRE(n_samples == 0 || (run_id && partial && n_rows > 0), "dfh_gn_build_planned: samples without rows");
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (rhs == vals + 36 * (size_t)n_blocks && cost_count == rhs + 6 * (size_t)n_nodes) {
+    const size_t ne = (size_t)(6 * knn) * (6 * knn + 1) / 2 + 6 * knn + 2;
+    if (planned) {
+        // every block / rhs entry / cost is written by the gather: only the partial rows need clearing (runs
+        // without a valid sample this iteration are not written by the tile pass)
+        if (n_rows > 0) DFH_HIP_CHECK(hipMemsetAsync(partial, 0, sizeof(double) * ne * (size_t)n_rows, s));
+    } else if (rhs == vals + 36 * (size_t)n_blocks && cost_count == rhs + 6 * (size_t)n_nodes) {
         // the flat {blocks | rhs | cost,count} layout of the host solver: one memset
         DFH_HIP_CHECK(hipMemsetAsync(vals, 0, sizeof(double) * (36 * (size_t)n_blocks + 6 * (size_t)n_nodes + 2), s));
     } else {
@@ -1261,8 +1398,12 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
         dim3 grid((n_samples + kTile - 1) / kTile), block(256);
 #define DFH_BUILD(KK)                                                                                               \
     case KK:                                                                                                        \
-        hipLaunchKernelGGL(gn_build_data_kernel<KK>, grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, valid, \
-                           node_dq, p, row_ptr, col, vals, rhs, cost_count);                                        \
+        if (planned)                                                                                                \
+            hipLaunchKernelGGL((gn_build_data_kernel<KK, true>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
+                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial);            \
+        else                                                                                                        \
+            hipLaunchKernelGGL((gn_build_data_kernel<KK, false>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
+                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial);            \
         break
         switch (knn) {
             DFH_BUILD(1); DFH_BUILD(2); DFH_BUILD(3); DFH_BUILD(4); DFH_BUILD(5); DFH_BUILD(6); DFH_BUILD(7); DFH_BUILD(8);
@@ -1270,13 +1411,60 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
 #undef DFH_BUILD
         DFH_HIP_CHECK(hipGetLastError());
     }
+    if (planned) {
+        dim3 grid((unsigned)(n_blocks + (n_nodes + 3) / 4 + 1)), block(256);
+#define DFH_GATHER(KK)                                                                                              \
+    case KK:                                                                                                        \
+        hipLaunchKernelGGL(gn_gather_kernel<KK>, grid, block, 0, s, partial, n_rows, blk_ptr, blk_ent, n_blocks, node_ptr,  \
+                           node_ent, n_nodes, vals, rhs, cost_count, false);                                        \
+        break
+        switch (knn) {
+            DFH_GATHER(1); DFH_GATHER(2); DFH_GATHER(3); DFH_GATHER(4); DFH_GATHER(5); DFH_GATHER(6); DFH_GATHER(7); DFH_GATHER(8);
+        }
+#undef DFH_GATHER
+        DFH_HIP_CHECK(hipGetLastError());
+    }
     if (node_nbr && rw != 0.0) {
         const int n = n_nodes * knn;
         hipLaunchKernelGGL(gn_build_reg_kernel, dim3((n + 3) / 4), dim3(256), 0, s, node_nbr, n_nodes, knn, node_dq, node_pos,
-                           node_w, rw, row_ptr, col, vals, rhs, cost_count);
+                           node_w, rw, row_ptr, col, vals, rhs, cost_count, planned_reg ? partial_reg : nullptr);
+        if (planned_reg) {
+            dim3 grid((unsigned)(n_blocks + (n_nodes + 3) / 4 + 1)), block(256);
+            hipLaunchKernelGGL(gn_gather_kernel<2>, grid, block, 0, s, partial_reg, n, rblk_ptr, rblk_ent, n_blocks, rnode_ptr,
+                               rnode_ent, n_nodes, vals, rhs, cost_count, true);
+        }
         DFH_HIP_CHECK(hipGetLastError());
     }
     return DFH_OK;
+}
+
+int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                 const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,
+                 const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                 const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                 double *rhs, double *cost_count, void *stream) {
+    return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr, valid, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
+                         n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, nullptr, 0, nullptr, nullptr, nullptr,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+size_t dfh_gn_partial_doubles(int knn) {
+    if (knn < 1 || knn > dfh::kKMaxS) return 0;
+    return (size_t)(6 * knn) * (6 * knn + 1) / 2 + 6 * knn + 2;
+}
+
+int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                         const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,
+                         const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                         const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                         double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                         const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                         const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(blk_ptr, "dfh_gn_build_planned: null blk_ptr");
+    return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr, valid, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
+                         n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
+                         blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, stream);
 }
 
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {

@@ -8,6 +8,8 @@ hyper-parameters (`regularization_weight`, its /8 relaxation while the cost redu
 torch is used for allocation and for the once-per-frame index bookkeeping (sorting samples by
 node tuple, unique node pairs); every per-iteration step is a HIP kernel behind the C ABI.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -242,7 +244,49 @@ class WarpSolver:
         self.dx = torch.empty(6 * N, dtype=torch.float64, device="cuda")
         nbytes = self.lib.dfh_pcg_workspace_bytes(N, self.pcg_iters)
         self.pcg_ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device="cuda")
+        self._build_plan(keys)
         self._pattern = True
+
+    def _build_plan(self, keys):
+        """Static part of the data term (dfh_gn_build_planned): rows = runs of equal node tuples inside a
+        256-sample tile, and for every block / node the rows (and tuple slots) that contribute to it."""
+        N, k, S, dev = self.N, self.knn, self.S, "cuda"
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        if S == 0:
+            self.run_id = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.n_rows = 0
+            tup = torch.zeros((0, k), dtype=torch.int64, device=dev)
+        else:
+            idx = torch.arange(S, device=dev)
+            head = torch.ones(S, dtype=torch.bool, device=dev)
+            head[1:] = (self.snbr[1:] != self.snbr[:-1]).any(dim=1) | ((idx[1:] // 256) != (idx[:-1] // 256))
+            self.run_id = i32(torch.cumsum(head, 0) - 1)
+            tup = self.snbr[head].long()
+            self.n_rows = int(tup.shape[0])
+        R = self.n_rows
+
+        def lists(tup):
+            """CSR lists for the gather: per block the entries row*K^2 + sa*K + sb, per node the entries row*K + slot."""
+            key = (tup[:, :, None] * N + tup[:, None, :]).reshape(-1)
+            blk = torch.searchsorted(keys, key)
+            order = torch.argsort(blk, stable=True)
+            bp = i32(torch.searchsorted(blk[order].contiguous(), torch.arange(self.B + 1, device=dev)))
+            node = tup.reshape(-1)
+            order2 = torch.argsort(node, stable=True)
+            npt = i32(torch.searchsorted(node[order2].contiguous(), torch.arange(N + 1, device=dev)))
+            return bp, i32(order), npt, i32(order2)
+
+        self.blk_ptr, self.blk_ent, self.node_ptr, self.node_ent = lists(tup)
+        self.partial_reg = None
+        if self.node_nbr is not None:
+            ii = torch.arange(N, device=dev, dtype=torch.int64)[:, None].expand(N, k).reshape(-1)
+            pair = torch.stack([ii, self.node_nbr.long().reshape(-1)], dim=1)          # row t = i*k + slot
+            self.rblk_ptr, self.rblk_ent, self.rnode_ptr, self.rnode_ent = lists(pair)
+            self.partial_reg = torch.zeros(N * k * 92, dtype=torch.float64, device=dev)
+        ne = int(self.lib.dfh_gn_partial_doubles(k))
+        self.partial = torch.empty(max(1, R * ne), dtype=torch.float64, device=dev)
+        if R * k * k >= 2 ** 31:
+            raise ValueError("too many sample runs for 32-bit plan entries")
 
     # -- correspondences ---------------------------------------------------------------------
     def set_correspondences(self, corr, valid=None):
@@ -279,12 +323,24 @@ class WarpSolver:
         # not, so exactly one rank adds them before the all-reduce
         reg_here = (not self.distributed) or _dist.world()[0] == 0
         nn = 0 if (self.node_nbr is None or rw == 0.0 or not reg_here) else self.node_nbr.data_ptr()
-        _lib.check(self.lib.dfh_gn_build(self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(),
-                                         self.corr.data_ptr(), self.valid.data_ptr(), self.S, self.knn,
-                                         self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(), nn, self.N,
-                                         _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
-                                         self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(),
-                                         current_stream_ptr()), "dfh_gn_build")
+        if os.environ.get("DFH_GN_ATOMIC"):          # the atomics-based build (no plan needed), kept for A/B comparison
+            _lib.check(self.lib.dfh_gn_build(self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(),
+                                             self.corr.data_ptr(), self.valid.data_ptr(), self.S, self.knn,
+                                             self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(), nn, self.N,
+                                             _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
+                                             self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(),
+                                             current_stream_ptr()), "dfh_gn_build")
+        else:
+            _lib.check(self.lib.dfh_gn_build_planned(
+                self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.corr.data_ptr(),
+                self.valid.data_ptr(), self.S, self.knn, self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(),
+                nn, self.N, _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
+                self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(), self.run_id.data_ptr(), self.n_rows,
+                self.partial.data_ptr(), self.blk_ptr.data_ptr(), self.blk_ent.data_ptr(), self.node_ptr.data_ptr(),
+                self.node_ent.data_ptr(), *((self.partial_reg.data_ptr(), self.rblk_ptr.data_ptr(), self.rblk_ent.data_ptr(),
+                                             self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
+                                            if self.partial_reg is not None else (0, 0, 0, 0, 0)),
+                current_stream_ptr()), "dfh_gn_build_planned")
         if self.distributed:
             _dist.allreduce_system(self.system)   # no-op on one GPU; samples are sharded by slab
 

@@ -173,6 +173,26 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
                  const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
                  double *rhs, double *cost_count, void *stream);
 
+/* The same normal equations without floating-point atomics in the data term (same bits every run), for
+ * callers that prepare a plan once per frame (samples and their node tuples are static while the warp field
+ * moves).  Samples sorted by node tuple; a "row" = a maximal run of equal tuples inside one 256-sample tile:
+ *   run_id[s]           row of sample s (n_rows rows);  partial: n_rows x dfh_gn_partial_doubles(knn) scratch
+ *   blk_ptr (n_blocks+1), blk_ent   for block b the entries row * knn^2 + sa * knn + sb (slots sa, sb of the
+ *                                   row's tuple hold the block's row node and column node), any fixed order
+ *   node_ptr (n_nodes+1), node_ent  for node a the entries row * knn + slot
+ * The tile pass stores each row's {upper Gram triangle | J^T r | cost | count}; a gather pass adds them per block.
+ * partial_reg (n_nodes * knn rows of 92 doubles) + rblk_ptr / rblk_ent / rnode_ptr / rnode_ent: the same for the
+ * regulariser, a pair (i, node_nbr[i*knn+slot]) being a 2-node row (entries row * 4 + sa * 2 + sb, row * 2 + slot);
+ * partial_reg == NULL keeps the regulariser on atomics. */
+size_t dfh_gn_partial_doubles(int knn);
+int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                         const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,
+                         const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                         const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                         double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                         const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                         const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, void *stream);
+
 /* Block-Jacobi preconditioned CG on (A + lm_abs I + lm_rel diag(A)) x = -rhs, `iters` iterations, no
  * host synchronisation.  The damping is written into vals' diagonal (vals is consumed). */
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters);

@@ -151,6 +151,32 @@ def test_pcg_paths_agree_and_are_deterministic(golden, monkeypatch):
     assert torch.equal(x1, sv.dx)
 
 
+def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, monkeypatch):
+    """dfh_gn_build_planned (per-run partial rows + gather, regulariser included) has no floating-point
+    atomics: two builds give the same bits; dfh_gn_build (atomics) gives the same system to rounding."""
+    g, verts, norms, corr, nbr, vidx, npos, ndq, nw, lw, rw = load(golden)
+    rng = np.random.default_rng(3)
+    valid = (rng.random(len(verts)) < 0.7).astype(np.uint8)
+    monkeypatch.delenv("DFH_GN_ATOMIC", raising=False)
+    sv = make_solver(npos, ndq, nw, nbr, vidx, verts, norms, corr, nbr.shape[1], pcg_iters=5, valid=valid)
+    sv.build(lw, rw)
+    s1 = sv.system.clone()
+    sv.build(lw, rw)
+    assert torch.equal(s1, sv.system)
+    sv.build(lw, 0.0)                                   # without the regulariser rows
+    s0 = sv.system.clone()
+    monkeypatch.setenv("DFH_GN_ATOMIC", "1")
+    sv.build(lw, rw)
+    sa = sv.system.clone()
+    sv.build(lw, 0.0)
+    sa0 = sv.system.clone()
+    monkeypatch.delenv("DFH_GN_ATOMIC", raising=False)
+    for p_, a_ in ((s1, sa), (s0, sa0)):
+        assert float((p_ - a_).abs().max()) <= 1e-12 * float(a_.abs().max())
+        assert p_[-1] == a_[-1] and p_[-1] == float(valid.sum())          # valid-sample count
+    assert float((s1 - s0).abs().max()) > 0                               # the regulariser really contributes
+
+
 def test_lm_loop_vs_oracle(golden):
     """Noise-free target from a known field, identity start: GPU LM costs follow the oracle's GN
     with the same damping schedule to 1e-6 relative; cost falls by > 100x."""

@@ -207,10 +207,17 @@ class WarpSolver:
                 weights = torch.exp(-1.0 * (dist / (2 * self.node_w[nbr.long()])) ** 2)
             weights = _f64(weights, (self.knn,))
         self.order = None
+        self._tuple_key = None
         if sort and pos.shape[0] > 0:
-            # group samples with the same ordered node tuple: few runs per 256-sample tile
-            _, inv = torch.unique(nbr, dim=0, return_inverse=True)
-            self.order = torch.argsort(inv, stable=True)
+            # group samples with the same ordered node tuple: few runs per 256-sample tile.  The tuple is packed
+            # into one int64 (base-N digits, lexicographic order preserved) so that a 1-D radix sort does it.
+            key = self._pack_tuples(nbr)
+            if key is not None:
+                key, self.order = torch.sort(key, stable=True)
+                self._tuple_key = key
+            else:
+                _, inv = torch.unique(nbr, dim=0, return_inverse=True)
+                self.order = torch.argsort(inv, stable=True)
             pos, nrm, nbr, weights = pos[self.order], nrm[self.order], nbr[self.order], weights[self.order]
         self.spos, self.snrm = pos.contiguous(), nrm.contiguous()
         self.snbr, self.swts = nbr.contiguous(), weights.contiguous()
@@ -219,12 +226,32 @@ class WarpSolver:
         self.valid = torch.zeros(self.S, dtype=torch.uint8, device="cuda")
         self._pattern = None
 
+    def _pack_tuples(self, nbr):
+        """(S,k) node ids -> int64 keys whose order is the lexicographic order of the tuples; None if k digits
+        in base N do not fit."""
+        if float(self.N) ** self.knn >= 2.0 ** 62:
+            return None
+        key = nbr[:, 0].long()
+        for j in range(1, self.knn):
+            key = key * self.N + nbr[:, j].long()
+        return key
+
+    def _unpack_tuples(self, key):
+        cols = []
+        for _ in range(self.knn):
+            cols.append(key % self.N)
+            key = key // self.N
+        return torch.stack(cols[::-1], dim=1)
+
     def _build_pattern(self):
         N, k = self.N, self.knn
         keys = [torch.arange(N, device="cuda", dtype=torch.int64) * (N + 1)]             # diagonal
         if self.S > 0:
             # distinct node tuples only (the pattern is a function of the tuples, not of the samples)
-            tup = torch.unique(self.snbr, dim=0).long()
+            if self._tuple_key is not None:
+                tup = self._unpack_tuples(torch.unique_consecutive(self._tuple_key))
+            else:
+                tup = torch.unique(self.snbr, dim=0).long()
             keys.append((tup[:, :, None] * N + tup[:, None, :]).reshape(-1))
         if self.node_nbr is not None:
             i = torch.arange(N, device="cuda", dtype=torch.int64)[:, None].expand(N, k)
@@ -259,7 +286,9 @@ class WarpSolver:
         else:
             idx = torch.arange(S, device=dev)
             head = torch.ones(S, dtype=torch.bool, device=dev)
-            head[1:] = (self.snbr[1:] != self.snbr[:-1]).any(dim=1) | ((idx[1:] // 256) != (idx[:-1] // 256))
+            differs = (self._tuple_key[1:] != self._tuple_key[:-1]) if self._tuple_key is not None else \
+                (self.snbr[1:] != self.snbr[:-1]).any(dim=1)
+            head[1:] = differs | ((idx[1:] // 256) != (idx[:-1] // 256))
             self.run_id = i32(torch.cumsum(head, 0) - 1)
             tup = self.snbr[head].long()
             self.n_rows = int(tup.shape[0])

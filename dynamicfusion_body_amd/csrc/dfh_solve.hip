@@ -1189,6 +1189,215 @@ __global__ __launch_bounds__(1024) void pcg_persistent_kernel(const int *__restr
     if (lead) x[6 * a + lane] = ok ? xi : __builtin_nan("");
 }
 
+// ---- single-reduction PCG (Chronopoulos & Gear) -----------------------------------------------------------
+// A grid-wide reduction costs ~3 us across the eight XCDs (MI355X_MICROARCH.md, hand-off price list) and the
+// textbook recurrence needs two per iteration (p.Ap, then r.z).  This variant has ONE: with u = M^-1 r, w = A u,
+//   gamma = r.u, delta = w.u  (both in the same reduction),  beta = gamma / gamma_old,
+//   alpha = gamma / (delta - beta gamma / alpha_old),  p = u + beta p,  s = w + beta s  (= A p),
+//   x += alpha p,  r -= alpha s,  u = M^-1 r,  w = A u.
+// The exchange of the new u between rows would be a second synchronisation; it is avoided by linearity:
+// u_new = u - alpha t with t = M^-1 s = v + beta t_old, v = M^-1 w, so every row publishes (u, v, t_old) BEFORE
+// the reduction and its neighbours form its u_new themselves once alpha and beta are known -- with the same
+// expression the owner uses, hence the same bits.  Same iterates as the textbook PCG in exact arithmetic.
+// Published vectors live in two parity sets (written during iteration i for iteration i+1; the set being
+// overwritten was last read before the reduction that every row has since passed).
+struct BarrierLds2 {
+    double wave_part[2][16];
+    double total[2];
+    int ok;
+};
+
+// two grid-wide sums in one pass; slots = 2 * gridDim.x doubles (workgroup b: 2b, 2b+1), zero before the launch
+__device__ __forceinline__ bool grid_sum2(double *slots, unsigned *abort_flag, BarrierLds2 *lds, double v0, double v1 /* lane 0 */,
+                                          double *s0, double *s1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    __builtin_amdgcn_s_waitcnt(0);                      // this wave's published vectors have reached the coherence point
+    if (lane == 0) { lds->wave_part[0][wave] = v0; lds->wave_part[1][wave] = v1; }
+    __syncthreads();
+    if (wave == 0) {
+        if (lane < 2) {
+            double v = 0.0;
+            for (int w = 0; w < waves; ++w) v += lds->wave_part[lane][w];
+            if (__double_as_longlong(v) == 0) v = -0.0;
+            st_agent(slots + 2 * blockIdx.x + lane, v);
+        }
+        const int ns = 2 * (int)gridDim.x;              // slot index parity = which sum; b += 64 keeps a lane's parity
+        unsigned spins = 0;
+        int ok = 1;
+        double tot = 0.0;
+        for (;;) {
+            double v = 0.0;
+            bool all = true;
+            for (int b = lane; b < ns; b += 64) {
+                const double t = ld_agent(slots + b);
+                all = all && (__double_as_longlong(t) != 0);
+                v += t;
+            }
+            if (__all(all)) {
+#pragma unroll
+                for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);     // lanes 0 and 1 end with the two totals
+                tot = v;
+                break;
+            }
+            if (++spins > kSpinLimit || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane < 2) lds->total[lane] = tot;
+        if (lane == 0) lds->ok = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    *s0 = lds->total[0];
+    *s1 = lds->total[1];
+    return lds->ok != 0;
+}
+
+__global__ __launch_bounds__(1024) void pcg_cg1_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col, double *vals,
+                                                        const double *__restrict__ rhs, const PcgParams prm, int iters,
+                                                        double *__restrict__ x, double *pub /* 2 x {u, v, t} x 6N */, double *part,
+                                                        unsigned *abort_flag) {
+    __shared__ BarrierLds2 lds;
+    const int N = prm.N;
+    const size_t N6 = 6 * (size_t)N;
+    const int lane = threadIdx.x & 63;
+    const int waves = blockDim.x >> 6;
+    const int a = blockIdx.x * waves + (threadIdx.x >> 6);
+    const bool row = a < N;
+    const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63 idle in the SpMV
+    const int beg = row ? row_ptr[a] : 0, end = row ? row_ptr[a + 1] : 0;
+    const bool lead = row && lane < 6;
+    // damp the diagonal block (the damping lives in the matrix) and invert it: block-Jacobi preconditioner
+    const int dblk = lead ? find_block(row_ptr, col, a, a) : -1;
+    double Mi[6];
+    {
+        double D[36], Di[36];
+#pragma unroll
+        for (int t = 0; t < 36; ++t) D[t] = dblk >= 0 ? vals[36 * (size_t)dblk + t] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) D[7 * t] = D[7 * t] + prm.lm_abs + prm.lm_rel * D[7 * t];
+        inv6(D, Di);                                            // lanes 0..5 redundantly: same cost as one lane
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double v = Di[j];
+#pragma unroll
+            for (int rr = 1; rr < 6; ++rr) v = lane == rr ? Di[6 * rr + j] : v;
+            Mi[j] = lead ? v : 0.0;
+        }
+    }
+    // register cache of this row's blocks: lane (slot, i) holds row i of blocks beg+slot+10c
+    double Bc[kRowCache][6];
+    int cj[kRowCache];
+#pragma unroll
+    for (int c = 0; c < kRowCache; ++c) {
+        const int b = beg + slot + 10 * c;
+        const bool have = slot < 10 && b < end;
+        cj[c] = have ? col[b] : -1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Bc[c][j] = have ? vals[36 * (size_t)b + 6 * i + j] : 0.0;
+        if (have && cj[c] == a) Bc[c][i] = Bc[c][i] + prm.lm_abs + prm.lm_rel * Bc[c][i];     // same expression as D above
+    }
+    __builtin_amdgcn_s_waitcnt(0);                              // every read of the undamped diagonal has returned
+    if (dblk >= 0) {
+        const double d0 = vals[36 * (size_t)dblk + 7 * lane];
+        vals[36 * (size_t)dblk + 7 * lane] = d0 + prm.lm_abs + prm.lm_rel * d0;
+    }
+    // y = A q for this row, q_j = what the closure returns for element i of neighbour j (lane (slot, i) asks for
+    // element i; the six lanes of a slot trade them); result in lanes 0..5
+    auto spmv = [&](auto &&elem) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < kRowCache; ++c) {
+            const int j6 = 6 * (cj[c] >= 0 ? cj[c] : 0) + i;
+            const double qi = slot < 10 ? elem(j6) : 0.0;
+            const int base = 6 * slot;
+            const double q0 = __shfl(qi, base + 0, 64), q1 = __shfl(qi, base + 1, 64), q2 = __shfl(qi, base + 2, 64);
+            const double q3 = __shfl(qi, base + 3, 64), q4 = __shfl(qi, base + 4, 64), q5 = __shfl(qi, base + 5, 64);
+            if (cj[c] >= 0)
+                acc += ((Bc[c][0] * q0 + Bc[c][1] * q1) + (Bc[c][2] * q2 + Bc[c][3] * q3)) + (Bc[c][4] * q4 + Bc[c][5] * q5);
+        }
+        if (slot < 10) {
+            for (int b = beg + slot + 10 * kRowCache; b < end; b += 10) {      // rows wider than the cache
+                const double *B = vals + 36 * (size_t)b + 6 * i;
+                const int j6 = 6 * col[b];
+                const double q0 = elem(j6 + 0), q1 = elem(j6 + 1), q2 = elem(j6 + 2), q3 = elem(j6 + 3), q4 = elem(j6 + 4), q5 = elem(j6 + 5);
+                acc += ((B[0] * q0 + B[1] * q1) + (B[2] * q2 + B[3] * q3)) + (B[4] * q4 + B[5] * q5);
+            }
+        }
+        double y = acc;
+#pragma unroll
+        for (int k = 1; k < 10; ++k) {
+            const double o = __shfl(acc, lane + 6 * k, 64);
+            y += (lane + 6 * k < 60) ? o : 0.0;
+        }
+        return y;
+    };
+    auto minv = [&](double v) {                                 // (M^-1 v)_lane from the six entries in lanes 0..5
+        double o = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) o += Mi[j] * __shfl(v, j, 64);
+        return o;
+    };
+    auto dot2 = [&](double a0, double b0, double &g, double &d) {   // lanes 0..5 -> lane 0
+        g = lead ? a0 : 0.0;
+        d = lead ? b0 : 0.0;
+        g += __shfl_down(g, 4, 64); d += __shfl_down(d, 4, 64);
+        g += __shfl_down(g, 2, 64); d += __shfl_down(d, 2, 64);
+        g += __shfl_down(g, 1, 64); d += __shfl_down(d, 1, 64);
+    };
+    double *set[2] = {pub, pub + 3 * N6};                       // parity sets: u at +0, v at +N6, t at +2 N6
+    double xi = 0.0, ri = lead ? -rhs[6 * a + lane] : 0.0, pi = 0.0, si = 0.0, ti = 0.0;
+    double ui = minv(ri);
+    if (lead) st_agent(set[0] + 6 * a + lane, ui);
+    double g, d, gamma = 0.0, delta = 0.0;
+    bool ok = grid_sum2(part, abort_flag, &lds, 0.0, 0.0, &g, &d);          // plain barrier: u0 is out
+    part += 2 * gridDim.x;
+    double wi = 0.0, vi = 0.0;
+    if (ok) {
+        const double *u0 = set[0];
+        wi = spmv([&](int j6) { return ld_agent(u0 + j6); });
+        vi = minv(wi);
+        if (lead) {
+            st_agent(set[0] + N6 + 6 * a + lane, vi);
+            st_agent(set[0] + 2 * N6 + 6 * a + lane, 0.0);
+        }
+        dot2(ri * ui, wi * ui, g, d);
+    }
+    double gamma_prev = 0.0, alpha_prev = 0.0;
+    for (int it = 0; it < iters && ok; ++it) {
+        ok = grid_sum2(part + (size_t)it * 2 * gridDim.x, abort_flag, &lds, g, d, &gamma, &delta);
+        if (!ok) break;
+        const double beta = gamma_prev != 0.0 ? gamma / gamma_prev : 0.0;
+        const double denom = alpha_prev != 0.0 ? delta - (beta * gamma) / alpha_prev : delta;
+        const double alpha = denom != 0.0 ? gamma / denom : 0.0;
+        if (lead) {
+            pi = ui + beta * pi;
+            si = wi + beta * si;
+            ti = vi + beta * ti;
+            xi += alpha * pi;
+            ri = ri - alpha * si;
+            ui = ui - alpha * ti;
+        }
+        if (it == iters - 1) break;
+        const double *cur = set[it & 1];
+        double *nxt = set[(it & 1) ^ 1];
+        wi = spmv([&](int j6) { return ld_agent(cur + j6) - alpha * (ld_agent(cur + N6 + j6) + beta * ld_agent(cur + 2 * N6 + j6)); });
+        vi = minv(wi);
+        if (lead) {
+            st_agent(nxt + 6 * a + lane, ui);
+            st_agent(nxt + N6 + 6 * a + lane, vi);
+            st_agent(nxt + 2 * N6 + 6 * a + lane, ti);
+        }
+        dot2(ri * ui, wi * ui, g, d);
+        gamma_prev = gamma;
+        alpha_prev = alpha;
+    }
+    if (lead) x[6 * a + lane] = ok ? xi : __builtin_nan("");
+}
+
 // dq_a <- exp(xi_a) (x) dq_a  (exp: rotation exp(omega), translation v; oracle/gn_np.py)
 __global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ node_dq, const double *__restrict__ xi, int N,
                                                            double step) {
@@ -1507,8 +1716,12 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
     if (2 * nblk <= n_cu && nblk <= kMaxPcgBlocks && !getenv("DFH_PCG_MULTILAUNCH")) {
         unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
         double *part = scal + 3 * ((size_t)iters + 2);                                    // (2 per iteration + 1) reductions x nblk slots
-        hipLaunchKernelGGL(pcg_persistent_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, z, pA, pB,
-                           part, flag);
+        if (getenv("DFH_PCG_TWO_REDUCTIONS"))      // the textbook recurrence (two reductions per iteration), kept for A/B runs
+            hipLaunchKernelGGL(pcg_persistent_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, z, pA,
+                               pB, part, flag);
+        else                                       // Minv's 36 N doubles hold the two sets of published {u, v, t}
+            hipLaunchKernelGGL(pcg_cg1_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
+                               flag);
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }

@@ -412,6 +412,10 @@ struct BuildParams {
 
 constexpr int kTile = 256;
 
+// scratch row of the planned build: {upper Gram triangle | J^T r | cost | count | live flag}, padded to whole 64-byte lines
+__host__ __device__ constexpr int gn_row_entries(int K) { return (6 * K) * (6 * K + 1) / 2 + 6 * K + 2; }
+__host__ __device__ constexpr int gn_row_stride(int K) { return (gn_row_entries(K) + 1 + 7) / 8 * 8; }
+
 // Residual and 6-DoF Jacobian rows of one data sample (formulas: oracle/gn_np.py
 // data_residual_jacobian).  J is written as k x 6 into Jrow (row-major), returns r.
 __device__ __forceinline__ double data_row(const double *__restrict__ node_dq, const int *idx, const double *w, int k,
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
                                                              const int *__restrict__ row_ptr, const int *__restrict__ col,
                                                              double *__restrict__ vals, double *__restrict__ rhs,
                                                              double *__restrict__ cost_count, const int *__restrict__ run_id,
-                                                             double *__restrict__ partial) {
+                                                             double *__restrict__ partial, double *__restrict__ tile_cost) {
     constexpr int NJ = 6 * K;                   // Jacobian entries per sample
     constexpr int LD = NJ + 1;                  // + residual
     __shared__ double sJ[kTile * LD];
@@ -503,7 +507,14 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     int pos = __popcll(bal & ((1ull << lane) - 1ull));
     for (int w_ = 0; w_ < wv; ++w_) pos += sWaveCnt[w_];
     const int n_valid = sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
-    if (n_valid == 0) return;                                        // tiles without a valid sample contribute nothing
+    constexpr int NE_ = gn_row_entries(K), ST_ = gn_row_stride(K);  // live flag at [NE_]: 0 = row not written this iteration
+    const int row_first = PLANNED ? run_id[blockIdx.x * kTile] : 0;
+    const int rows_tile = PLANNED ? run_id[blockIdx.x * kTile + tile_n - 1] - row_first + 1 : 0;
+    if (n_valid == 0) {                                              // tiles without a valid sample contribute nothing:
+        if (PLANNED && tid < rows_tile) partial[(size_t)(row_first + tid) * ST_ + NE_] = 0.0;    // their rows are dead
+        if (PLANNED && tid == 0) { tile_cost[2 * blockIdx.x] = 0.0; tile_cost[2 * blockIdx.x + 1] = 0.0; }
+        return;
+    }
     if (!PLANNED && tid == 0) atomicAdd(cost_count + 1, (double)n_valid);        // valid-sample count
     __shared__ int sRow[PLANNED ? kTile : 1];                        // partial row of every compacted sample
     if (act) {
@@ -567,7 +578,15 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     // entries: upper triangle of the NJ x NJ Gram matrix, then NJ entries of J^T r, then cost
     constexpr int NUP = NJ * (NJ + 1) / 2;
     if (PLANNED) {
-        if (tid < n_runs) partial[(size_t)sRow[sRun[tid]] * (NUP + NJ + 2) + NUP + NJ + 1] = (double)(sRun[tid + 1] - sRun[tid]);
+        if (tid < n_runs) partial[(size_t)sRow[sRun[tid]] * ST_ + NUP + NJ + 1] = (double)(sRun[tid + 1] - sRun[tid]);
+        // live flags of this tile's rows: 1 where a run has valid samples this iteration, 0 elsewhere (dead rows are
+        // neither cleared here nor read by the gather)
+        __shared__ int sTouched[kTile];
+        if (tid < rows_tile) sTouched[tid] = 0;
+        __syncthreads();
+        if (tid < n_runs) sTouched[sRow[sRun[tid]] - row_first] = 1;
+        __syncthreads();
+        if (tid < rows_tile) partial[(size_t)(row_first + tid) * ST_ + NE_] = sTouched[tid] ? 1.0 : 0.0;
     }
     for (int e = tid; e < NUP + NJ + 1; e += 256) {
         int pa, pb;                              // Jacobian columns of this entry (pb == NJ: residual)
@@ -580,6 +599,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         } else {
             pa = NJ; pb = NJ;
         }
+        double tile_sum = 0.0;                       // (used by the thread that owns the cost entry)
         for (int rn = 0; rn < n_runs; ++rn) {
             const int t0 = sRun[rn], t1 = sRun[rn + 1];
             // four independent chains: the loop is bound by LDS latency, not bandwidth (fixed association order)
@@ -595,7 +615,8 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
             for (; t < t1; ++t) acc0 += sJ[t * LD + pa] * sJ[t * LD + pb];
             const double acc = (acc0 + acc1) + (acc2 + acc3);
             if (PLANNED) {
-                partial[(size_t)sRow[t0] * (NUP + NJ + 2) + e] = pa == NJ ? 0.5 * acc : acc;
+                partial[(size_t)sRow[t0] * ST_ + e] = pa == NJ ? 0.5 * acc : acc;
+                if (pa == NJ) tile_sum += 0.5 * acc;
                 continue;
             }
             if (acc == 0.0) continue;
@@ -615,6 +636,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
                 }
             }
         }
+        if (PLANNED && pa == NJ && pb == NJ) { tile_cost[2 * blockIdx.x] = tile_sum; tile_cost[2 * blockIdx.x + 1] = (double)n_valid; }
     }
 }
 
@@ -629,14 +651,25 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
                                                         const int *__restrict__ blk_ent, int n_blocks,
                                                         const int *__restrict__ node_ptr, const int *__restrict__ node_ent,
                                                         int n_nodes, double *__restrict__ vals, double *__restrict__ rhs,
-                                                        double *__restrict__ cost_count, bool accumulate) {
+                                                        double *__restrict__ cost_count, const double *__restrict__ cc, int n_cc,
+                                                        int cc_stride, bool accumulate, int only_part) {
+    // cc: n_cc {cost, count} pairs, cc_stride doubles apart (per tile for the data term, per pair row for the regulariser)
+    // only_part (debug timing): 0 = all, 1 = blocks, 2 = J^T r, 3 = cost
     // accumulate: add to what is there (second gather of the same build: the regulariser rows) instead of storing
-    constexpr int NJ = 6 * K, NUP = NJ * (NJ + 1) / 2, NE = NUP + NJ + 2;
+    constexpr int NJ = 6 * K, NUP = NJ * (NJ + 1) / 2, NE = gn_row_stride(K), kLive = gn_row_entries(K);   // NE = row stride
     const int nrw = (n_nodes + 3) / 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ double red[4][64];
-    if ((int)blockIdx.x < n_blocks) {
-        const int b = (int)blockIdx.x;
+    const int nbw = (n_blocks + 3) / 4;
+    if (only_part) {
+        const int part_of = (int)blockIdx.x < nbw ? 1 : ((int)blockIdx.x < nbw + nrw ? 2 : 3);
+        if (part_of != only_part) return;
+    }
+    if ((int)blockIdx.x < nbw) {
+        // one wave per block: entries fetched 64 at a time (coalesced), traded by shuffle, eight value loads in flight
+        const int b = (int)blockIdx.x * 4 + wv;
+        if (b >= n_blocks) return;
+        const int beg = blk_ptr[b], end = blk_ptr[b + 1];
         const int ia = (lane % 36) / 6, ib = lane % 6;
         auto value = [&](int ent) {
             const int row = ent / (K * K), pr = ent - row * (K * K);
@@ -644,35 +677,75 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
             if (pa > pb) { const int t = pa; pa = pb; pb = t; }
             return partial[(size_t)row * NE + (pa * NJ - (pa * (pa - 1)) / 2 + (pb - pa))];
         };
-        const int beg = blk_ptr[b], end = blk_ptr[b + 1];
+        // The walk is a chain of dependent loads (entry -> live flag -> values), so it is organised by hops, not by
+        // entries: up to 256 entries and then their flags are fetched together (two hops), the live ones are compacted
+        // in list order into LDS, and lanes 0..35 (one per block entry) add them with 16 value loads in flight.
+        __shared__ int sLiveB[4][256];
         double acc = 0.0;
-        if (lane < 36) {
-            int q = beg + wv;
-            for (; q + 4 < end; q += 8) {
-                const int e0 = blk_ent[q], e1 = blk_ent[q + 4];
-                const double v0 = value(e0), v1 = value(e1);
-                acc += v0;
-                acc += v1;
+        for (int base = beg; base < end; base += 256) {
+            int ent[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ent[u] = base + 64 * u + lane < end ? blk_ent[base + 64 * u + lane] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) on[u] = ent[u] >= 0 && partial[(size_t)(ent[u] / (K * K)) * NE + kLive] != 0.0;
+            int nl = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long m = __ballot(on[u]);
+                if (on[u]) sLiveB[wv][nl + __popcll(m & ((1ull << lane) - 1ull))] = ent[u];
+                nl += __popcll(m);
             }
-            if (q < end) acc += value(blk_ent[q]);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 36) {
+                int q = 0;
+                for (; q + 15 < nl; q += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = value(sLiveB[wv][q + u]);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc += v[u];
+                }
+                for (; q + 3 < nl; q += 4) {
+                    double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = value(sLiveB[wv][q + u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc += v[u];
+                }
+                for (; q < nl; ++q) acc += value(sLiveB[wv][q]);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        red[wv][lane] = acc;
-        __syncthreads();
-        if (threadIdx.x < 36) {
-            const double v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-            double *dst = vals + 36 * (size_t)b + threadIdx.x;
-            *dst = accumulate ? *dst + v : v;
+        if (lane < 36) {
+            double *dst = vals + 36 * (size_t)b + lane;
+            *dst = accumulate ? *dst + acc : acc;
         }
-    } else if ((int)blockIdx.x < n_blocks + nrw) {
-        const int a = ((int)blockIdx.x - n_blocks) * 4 + wv;
+    } else if ((int)blockIdx.x < nbw + nrw) {
+        const int a = ((int)blockIdx.x - nbw) * 4 + wv;
         double acc = 0.0;
         const int j = lane / 6, i = lane - 6 * j;                  // lanes 60..63 idle
-        if (a < n_nodes && j < 10) {
+        __shared__ int sLive[4][64];
+        if (a < n_nodes) {
             const int beg = node_ptr[a], end = node_ptr[a + 1];
-            for (int q = beg + j; q < end; q += 10) {
-                const int ent = node_ent[q];
-                const int row = ent / K, slot = ent - row * K;
-                acc += partial[(size_t)row * NE + NUP + slot * 6 + i];
+            for (int base = beg; base < end; base += 64) {
+                // 64 entries and their rows' live flags at once; the live ones, compacted in list order, are then taken
+                // ten at a time (lane group j takes the j-th of each ten) -- one value hop per ten entries
+                const int n = min(64, end - base);
+                int mine = lane < n ? node_ent[base + lane] : -1;
+                if (mine >= 0 && partial[(size_t)(mine / K) * NE + kLive] == 0.0) mine = -1;
+                const unsigned long long live = __ballot(mine >= 0);
+                if (mine >= 0) sLive[wv][__popcll(live & ((1ull << lane) - 1ull))] = mine;
+                __builtin_amdgcn_wave_barrier();
+                const int nl = __popcll(live);
+                if (j < 10) {
+                    for (int m = j; m < nl; m += 10) {
+                        const int ent = sLive[wv][m];
+                        const int row = ent / K, slot = ent - row * K;
+                        acc += partial[(size_t)row * NE + NUP + slot * 6 + i];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         double tot = acc;
@@ -684,9 +757,9 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
         if (a < n_nodes && lane < 6) rhs[6 * a + lane] = accumulate ? rhs[6 * a + lane] + tot : tot;
     } else {
         double c = 0.0, n = 0.0;
-        for (int r = (int)threadIdx.x; r < n_rows; r += 256) {
-            c += partial[(size_t)r * NE + NUP + NJ];
-            n += partial[(size_t)r * NE + NUP + NJ + 1];
+        for (int r = (int)threadIdx.x; r < n_cc; r += 256) {
+            c += cc[(size_t)r * cc_stride];
+            n += cc[(size_t)r * cc_stride + 1];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); n += __shfl_xor(n, o, 64); }
@@ -712,7 +785,7 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
                                                             double *__restrict__ cost_count, double *__restrict__ partial_reg) {
     // partial_reg != NULL (planned build): the pair's {upper triangle of the 12x12 Gram matrix of [J_i | J_j] |
     // J^T rho | 0.5 rho^2 | 0} is STORED in row t (92 doubles) and gathered like a 2-node data row: no atomics.
-    constexpr int NE2 = 78 + 12 + 2;
+    constexpr int NE2 = gn_row_stride(2), kLive2 = gn_row_entries(2);      // 96-double rows, live flag at [92]
     auto up = [](int pa, int pb) { return pa * 12 - (pa * (pa - 1)) / 2 + (pb - pa); };
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -720,7 +793,11 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
     const int i = t / k;
     const int j = node_nbr[t];
     if (i == j) {                                                  // zero rows, zero Jacobian
-        if (partial_reg) for (int e = lane; e < NE2; e += 64) partial_reg[(size_t)t * NE2 + e] = 0.0;
+        if (partial_reg && lane == 0) {                           // dead row (its cost / count are read unconditionally)
+            partial_reg[(size_t)t * NE2 + kLive2] = 0.0;
+            partial_reg[(size_t)t * NE2 + 90] = 0.0;
+            partial_reg[(size_t)t * NE2 + 91] = 0.0;
+        }
         return;
     }
     const double vx = round_f32(node_pos[3 * j]), vy = round_f32(node_pos[3 * j + 1]), vz = round_f32(node_pos[3 * j + 2]);
@@ -758,7 +835,7 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
                 P[78 + lane] = (gi[0] * rho[0] + gi[1] * rho[1]) + gi[2] * rho[2];
                 P[84 + lane] = (gj[0] * rho[0] + gj[1] * rho[1]) + gj[2] * rho[2];
             }
-            if (lane == 0) { P[90] = 0.5 * ((rho[0] * rho[0] + rho[1] * rho[1]) + rho[2] * rho[2]); P[91] = 0.0; }
+            if (lane == 0) { P[90] = 0.5 * ((rho[0] * rho[0] + rho[1] * rho[1]) + rho[2] * rho[2]); P[91] = 0.0; P[kLive2] = 1.0; }
             return;
         }
         const int bii = find_block(row_ptr, col, i, i), bjj = find_block(row_ptr, col, j, j);
@@ -1586,11 +1663,11 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
         DFH_REQUIRE(n_samples == 0 || (run_id && partial && n_rows > 0), "dfh_gn_build_planned: samples without rows");
     }
     hipStream_t s = (hipStream_t)stream;
-    const size_t ne = (size_t)(6 * knn) * (6 * knn + 1) / 2 + 6 * knn + 2;
+    const int n_tiles = (n_samples + kTile - 1) / kTile;
+    double *tile_cost = planned && partial ? partial + (size_t)n_rows * gn_row_stride(knn) : nullptr;   // 2 doubles per tile, behind the rows
     if (planned) {
-        // every block / rhs entry / cost is written by the gather: only the partial rows need clearing (runs
-        // without a valid sample this iteration are not written by the tile pass)
-        if (n_rows > 0) DFH_HIP_CHECK(hipMemsetAsync(partial, 0, sizeof(double) * ne * (size_t)n_rows, s));
+        // every block / rhs entry / cost is written by the gather, and every row of `partial` by the tile pass (rows
+        // without a valid sample this iteration are zeroed there): nothing to clear
     } else if (rhs == vals + 36 * (size_t)n_blocks && cost_count == rhs + 6 * (size_t)n_nodes) {
         // the flat {blocks | rhs | cost,count} layout of the host solver: one memset
         DFH_HIP_CHECK(hipMemsetAsync(vals, 0, sizeof(double) * (36 * (size_t)n_blocks + 6 * (size_t)n_nodes + 2), s));
@@ -1609,10 +1686,10 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
     case KK:                                                                                                        \
         if (planned)                                                                                                \
             hipLaunchKernelGGL((gn_build_data_kernel<KK, true>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
-                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial);            \
+                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost); \
         else                                                                                                        \
             hipLaunchKernelGGL((gn_build_data_kernel<KK, false>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
-                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial);            \
+                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost); \
         break
         switch (knn) {
             DFH_BUILD(1); DFH_BUILD(2); DFH_BUILD(3); DFH_BUILD(4); DFH_BUILD(5); DFH_BUILD(6); DFH_BUILD(7); DFH_BUILD(8);
@@ -1620,12 +1697,13 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
 #undef DFH_BUILD
         DFH_HIP_CHECK(hipGetLastError());
     }
+    const int dbg_part = getenv("DFH_DBG_GATHER_PART") ? atoi(getenv("DFH_DBG_GATHER_PART")) : 0;
     if (planned) {
-        dim3 grid((unsigned)(n_blocks + (n_nodes + 3) / 4 + 1)), block(256);
+        dim3 grid((unsigned)((n_blocks + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
 #define DFH_GATHER(KK)                                                                                              \
     case KK:                                                                                                        \
         hipLaunchKernelGGL(gn_gather_kernel<KK>, grid, block, 0, s, partial, n_rows, blk_ptr, blk_ent, n_blocks, node_ptr,  \
-                           node_ent, n_nodes, vals, rhs, cost_count, false);                                        \
+                           node_ent, n_nodes, vals, rhs, cost_count, tile_cost, n_tiles, 2, false, dbg_part);       \
         break
         switch (knn) {
             DFH_GATHER(1); DFH_GATHER(2); DFH_GATHER(3); DFH_GATHER(4); DFH_GATHER(5); DFH_GATHER(6); DFH_GATHER(7); DFH_GATHER(8);
@@ -1638,9 +1716,9 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
         hipLaunchKernelGGL(gn_build_reg_kernel, dim3((n + 3) / 4), dim3(256), 0, s, node_nbr, n_nodes, knn, node_dq, node_pos,
                            node_w, rw, row_ptr, col, vals, rhs, cost_count, planned_reg ? partial_reg : nullptr);
         if (planned_reg) {
-            dim3 grid((unsigned)(n_blocks + (n_nodes + 3) / 4 + 1)), block(256);
+            dim3 grid((unsigned)((n_blocks + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
             hipLaunchKernelGGL(gn_gather_kernel<2>, grid, block, 0, s, partial_reg, n, rblk_ptr, rblk_ent, n_blocks, rnode_ptr,
-                               rnode_ent, n_nodes, vals, rhs, cost_count, true);
+                               rnode_ent, n_nodes, vals, rhs, cost_count, partial_reg + 90, n, gn_row_stride(2), true, dbg_part);
         }
         DFH_HIP_CHECK(hipGetLastError());
     }
@@ -1659,7 +1737,7 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
 
 size_t dfh_gn_partial_doubles(int knn) {
     if (knn < 1 || knn > dfh::kKMaxS) return 0;
-    return (size_t)(6 * knn) * (6 * knn + 1) / 2 + 6 * knn + 2;
+    return (size_t)dfh::gn_row_stride(knn);
 }
 
 int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,

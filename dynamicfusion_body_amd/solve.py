@@ -311,9 +311,9 @@ class WarpSolver:
             ii = torch.arange(N, device=dev, dtype=torch.int64)[:, None].expand(N, k).reshape(-1)
             pair = torch.stack([ii, self.node_nbr.long().reshape(-1)], dim=1)          # row t = i*k + slot
             self.rblk_ptr, self.rblk_ent, self.rnode_ptr, self.rnode_ent = lists(pair)
-            self.partial_reg = torch.zeros(N * k * 92, dtype=torch.float64, device=dev)
+            self.partial_reg = torch.zeros(N * k * int(self.lib.dfh_gn_partial_doubles(2)), dtype=torch.float64, device=dev)
         ne = int(self.lib.dfh_gn_partial_doubles(k))
-        self.partial = torch.empty(max(1, R * ne), dtype=torch.float64, device=dev)
+        self.partial = torch.empty(max(1, R * ne) + 2 * ((S + 255) // 256), dtype=torch.float64, device=dev)   # rows | {cost, count} per tile
         if R * k * k >= 2 ** 31:
             raise ValueError("too many sample runs for 32-bit plan entries")
 

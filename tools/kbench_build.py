@@ -52,3 +52,6 @@ tile = (torch.nonzero(v).flatten() // 256)
 runs_total = int(chg.sum()) + 1 + int((tile[1:] != tile[:-1]).sum())
 ntiles = (sv.S + 255) // 256
 print("tiles %d, valid per tile %.1f, runs (valid samples) total ~%d = %.1f per tile, distinct tuples %d" % (ntiles, float(v.sum()) / ntiles, runs_total, runs_total / ntiles, torch.unique(nbv, dim=0).shape[0]))
+bp = sv.blk_ptr.long(); ll = bp[1:] - bp[:-1]
+npn = sv.node_ptr.long(); nl = npn[1:] - npn[:-1]
+print("plan: rows %d, block-list entries %d (max %d, mean %.1f, >256: %d), node-list max %d mean %.1f" % (sv.n_rows, int(ll.sum()), int(ll.max()), float(ll.float().mean()), int((ll > 256).sum()), int(nl.max()), float(nl.float().mean())))

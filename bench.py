@@ -180,11 +180,17 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
                                                           sphere_r=scene.SPHERE_R * (1.0 + 0.004 * (f + 1)))).cuda())
     info = {"vertices": None, "faces": None}
 
-    def frame(f):
-        info["samples"] = sf.step(depths[f], lw_cam, gn_iters=iters)
+    stages = {}
+
+    def frame(f, timed=False):
+        info["samples"] = sf.step(depths[f], lw_cam, gn_iters=iters, stage_ms=stages if timed else None)
         if world == 1:
+            t1 = _t.perf_counter()
             v, fc, n, val = mesh.marching_cubes(sf.T, 0.0)
             info["vertices"], info["faces"] = int(v.shape[0]), int(fc.shape[0])
+            if timed:
+                torch.cuda.synchronize()
+                stages["mesh"] = stages.get("mesh", 0.0) + (_t.perf_counter() - t1) * 1e3
 
     frame(0)                                      # warm-up (allocations, block pattern, candidate lists)
     barrier()
@@ -193,11 +199,14 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
         frame(f)
     barrier()
     dt = D.max_over_ranks([(_t.perf_counter() - t0) / (nframes - 1)])[0]
+    for f in range(1, nframes):                   # second, untimed-for-throughput pass with a sync after every stage
+        frame(f, timed=True)
     cost, cnt = sf.fs.solver.cost()
     tot = torch.tensor([float(info["samples"])], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tot)
     return {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "frames_timed": nframes - 1, "scaling": "strong" if world > 1 else "n/a",
+            "stage_ms_with_syncs": {kk: vv / (nframes - 1) for kk, vv in stages.items()},
             "gn_iters_per_frame": iters, "nodes": N, "samples": int(tot.item()), "mesh_vertices": info["vertices"],
             "mesh_faces": info["faces"], "final_cost": cost,
             "exchange": "none" if world == 1 else "per frame: all-gather of the live volume (%.0f MB) + face-plane halo; per GN "

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void fuse_volume_rigid_fast_kernel(float *__re
         const double hi = fmin(fmin(hx - qx, hy - qy), hz - qz);
         const double edge = fmin(fabs(lo), fabs(hi));              // distance to the nearest face of [0,R-1]^3 (or worse)
         bool ok = (lo >= 0.0) & (hi >= 0.0);
-        bool redo = !(fmin(fmin(fabs(qx), fabs(qy)), fabs(qz)) > 1e-9) | !(fmin(fmin(fabs(hx - qx), fabs(hy - qy)), fabs(hz - qz)) > 1e-9);
+        bool redo = (int)!(fmin(fmin(fabs(qx), fabs(qy)), fabs(qz)) > 1e-9) | (int)!(fmin(fmin(fabs(hx - qx), fabs(hy - qy)), fabs(hz - qz)) > 1e-9);
         (void)edge;
         double sv = 0.0;
         if (ok) {
@@ -248,9 +248,11 @@ struct DqbParams {
 // sorted (ascending, stable) insertion into a KS-slot list held in registers
 template <int KS>
 __device__ __forceinline__ void topk_insert(double (&bd)[KS], int (&bi)[KS], double d2, int idx) {
+    bool ins = false;                       // once inserted, everything below shifts down: equal distances keep their
 #pragma unroll
-    for (int i = 0; i < KS; ++i) {
-        const bool lt = d2 < bd[i];
+    for (int i = 0; i < KS; ++i) {          // arrival order (a stable sort, KD-tree-like: ties go to the lower node index)
+        const bool lt = ins || d2 < bd[i];
+        ins = lt;
         const double td = bd[i];
         const int ti = bi[i];
         bd[i] = lt ? d2 : td;

@@ -175,9 +175,11 @@ __global__ __launch_bounds__(256) void gn_build_rigid_kernel(const double *__res
 }
 
 __device__ __forceinline__ void top8_insert_s(double (&bd)[kKMaxS], int (&bi)[kKMaxS], double d2, int idx) {
+    bool ins = false;                       // once inserted, everything below shifts down: equal distances keep their
 #pragma unroll
-    for (int i = 0; i < kKMaxS; ++i) {
-        const bool lt = d2 < bd[i];
+    for (int i = 0; i < kKMaxS; ++i) {      // arrival order (a stable sort: ties go to the lower node index)
+        const bool lt = ins || d2 < bd[i];
+        ins = lt;
         const double td = bd[i];
         const int ti = bi[i];
         bd[i] = lt ? d2 : td;
@@ -273,35 +275,118 @@ __global__ __launch_bounds__(256) void closest_corr_kernel(const double *__restr
 
 // ------------------------------------------------------------------------------- sample setup
 
-// k nearest nodes + Gaussian blend weights of arbitrary sample points (brute force over all
-// nodes: runs once per frame, S*N distance evaluations).
+// k nearest nodes + Gaussian blend weights of arbitrary sample points.  The 256 samples of a workgroup are
+// consecutive band voxels, i.e. spatially coherent: with their bounding box B, any sample's k-th nearest node is no
+// farther than the k-th smallest over nodes of maxdist(node, B), so only nodes with mindist(node, B) within that bound
+// can be among anyone's k nearest.  Those candidates (kept in node order, so ties resolve as in a full scan) are
+// scanned; everything else is skipped.  Same result as brute force, ~10x fewer distance evaluations.
+constexpr int kKnnCand = 512;              // candidate capacity in LDS; more -> plain scan of all nodes
+
 __global__ __launch_bounds__(256) void sample_knn_kernel(const double *__restrict__ spos, int S, const double *__restrict__ node_pos,
                                                           const double *__restrict__ node_w, int N, int k,
                                                           int *__restrict__ nbr, double *__restrict__ wts) {
-    __shared__ double sp[256 * 3];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double sp[kKnnCand * 3];
+    __shared__ int sid[kKnnCand];
+    __shared__ double sred[6][4];
+    __shared__ double sbox[6];
+    __shared__ int scount[5];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = blockIdx.x * 256 + tid;
     const bool act = i < S;
     const double px = act ? spos[3 * (size_t)i] : 0.0, py = act ? spos[3 * (size_t)i + 1] : 0.0, pz = act ? spos[3 * (size_t)i + 2] : 0.0;
+    // ---- bounding box of the workgroup's samples
+    {
+        const double big = __builtin_huge_val();
+        double v[6] = {act ? px : big, act ? py : big, act ? pz : big, act ? -px : big, act ? -py : big, act ? -pz : big};   // min of (x, -x)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v[c] = fmin(v[c], __shfl_xor(v[c], o, 64));
+            if (lane == 0) sred[c][wv] = v[c];
+        }
+        __syncthreads();
+        if (tid < 6) sbox[tid] = fmin(fmin(sred[tid][0], sred[tid][1]), fmin(sred[tid][2], sred[tid][3]));
+        __syncthreads();
+    }
+    const double lox = sbox[0], loy = sbox[1], loz = sbox[2], hix = -sbox[3], hiy = -sbox[4], hiz = -sbox[5];
+    // ---- bound: k-th smallest maxdist^2(node, box); k rounds of "smallest value above the previous one" (ties make the
+    //      bound only larger, which is safe)
+    auto maxd2 = [&](int n) {
+        const double x = node_pos[3 * n], y = node_pos[3 * n + 1], z = node_pos[3 * n + 2];
+        const double dx = fmax(fabs(x - lox), fabs(x - hix)), dy = fmax(fabs(y - loy), fabs(y - hiy)), dz = fmax(fabs(z - loz), fabs(z - hiz));
+        return (dx * dx + dy * dy) + dz * dz;
+    };
+    double prev = -1.0;
+    for (int r = 0; r < k; ++r) {
+        double m = __builtin_huge_val();
+        for (int n = tid; n < N; n += 256) {
+            const double d = maxd2(n);
+            if (d > prev && d < m) m = d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o, 64));
+        if (lane == 0) sred[0][wv] = m;
+        __syncthreads();
+        prev = fmin(fmin(sred[0][0], sred[0][1]), fmin(sred[0][2], sred[0][3]));
+        __syncthreads();
+    }
+    // (k distinct values were found when N >= k distinct distances exist; with fewer, prev = +inf: every node qualifies)
+    const double bound = prev * (1.0 + 1e-12) + 1e-300;
+    // ---- candidates: mindist^2(node, box) <= bound, compacted in node order
+    int total = 0;
+    bool fits = true;
+    for (int base = 0; base < N && fits; base += 256) {
+        const int n = base + tid;
+        bool keep = false;
+        if (n < N) {
+            const double x = node_pos[3 * n], y = node_pos[3 * n + 1], z = node_pos[3 * n + 2];
+            const double dx = fmax(fmax(lox - x, x - hix), 0.0), dy = fmax(fmax(loy - y, y - hiy), 0.0), dz = fmax(fmax(loz - z, z - hiz), 0.0);
+            keep = (dx * dx + dy * dy) + dz * dz <= bound;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) scount[wv] = __popcll(bal);
+        __syncthreads();
+        int pos = total + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; ++w) pos += scount[w];
+        const int add = scount[0] + scount[1] + scount[2] + scount[3];
+        if (total + add > kKnnCand) fits = false;                    // (block-uniform)
+        else if (keep) {
+            sid[pos] = n;
+            sp[3 * pos] = node_pos[3 * n]; sp[3 * pos + 1] = node_pos[3 * n + 1]; sp[3 * pos + 2] = node_pos[3 * n + 2];
+        }
+        total += add;
+        __syncthreads();
+    }
     double bd[kKMaxS];
     int bi[kKMaxS];
 #pragma unroll
     for (int j = 0; j < kKMaxS; ++j) { bd[j] = __builtin_huge_val(); bi[j] = -1; }
-    for (int base = 0; base < N; base += 256) {
-        const int n = min(256, N - base);
-        if ((int)threadIdx.x < n) {
-            sp[3 * threadIdx.x] = node_pos[3 * (base + threadIdx.x)];
-            sp[3 * threadIdx.x + 1] = node_pos[3 * (base + threadIdx.x) + 1];
-            sp[3 * threadIdx.x + 2] = node_pos[3 * (base + threadIdx.x) + 2];
-        }
-        __syncthreads();
+    if (fits) {
         if (act) {
-            for (int j = 0; j < n; ++j) {
+            for (int j = 0; j < total; ++j) {
                 const double dx = px - sp[3 * j], dy = py - sp[3 * j + 1], dz = pz - sp[3 * j + 2];
                 const double d2 = (dx * dx + dy * dy) + dz * dz;
-                if (d2 < bd[kKMaxS - 1]) top8_insert_s(bd, bi, d2, base + j);
+                if (d2 < bd[kKMaxS - 1]) top8_insert_s(bd, bi, d2, sid[j]);
             }
         }
-        __syncthreads();
+    } else {
+        for (int base = 0; base < N; base += 256) {                 // too many candidates for LDS: scan all nodes
+            const int n = min(256, N - base);
+            __syncthreads();
+            if (tid < n) {
+                sp[3 * tid] = node_pos[3 * (base + tid)];
+                sp[3 * tid + 1] = node_pos[3 * (base + tid) + 1];
+                sp[3 * tid + 2] = node_pos[3 * (base + tid) + 2];
+            }
+            __syncthreads();
+            if (act) {
+                for (int j = 0; j < n; ++j) {
+                    const double dx = px - sp[3 * j], dy = py - sp[3 * j + 1], dz = pz - sp[3 * j + 2];
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2 < bd[kKMaxS - 1]) top8_insert_s(bd, bi, d2, base + j);
+                }
+            }
+        }
     }
     if (!act) return;
 #pragma unroll

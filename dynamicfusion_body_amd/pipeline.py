@@ -156,17 +156,34 @@ class SlabFrame:
             Tp.append(hi[None]); Wp.append(torch.zeros_like(hi)[None])
         return self.fs.set_canonical(torch.cat(Tp).contiguous(), torch.cat(Wp).contiguous(), band=self.band, x0=x0)
 
-    def step(self, depth, lw_cam, gn_iters=10, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0):
+    def step(self, depth, lw_cam, gn_iters=10, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0, stage_ms=None):
+        """stage_ms: optional dict; when given, the device is synchronised after every stage and the stage's wall
+        time (ms) is added under its name (for breakdowns only: the syncs cost throughput)."""
+        import time as _t
+        t0 = [_t.perf_counter()]
+
+        def mark(name):
+            if stage_ms is not None:
+                torch.cuda.synchronize()
+                now = _t.perf_counter()
+                stage_ms[name] = stage_ms.get(name, 0.0) + (now - t0[0]) * 1e3
+                t0[0] = now
         R = self.R
         self.live.fill_(self.tvox)
         self.live_w.zero_()
         kernels.integrate_depth(self.live, self.live_w, depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.tdist_world,
                                 tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b))
+        mark("live_tsdf")
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
+        mark("allgather")
         for _ in range(gn_iters):
             self.fs.gn_iteration(depth, lw_cam, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist)
+        mark("solve")
         sv = self.fs.solver
         kernels.fuse_volume_dqb(self.T, self.Wt, live_full, sv.node_pos, sv.node_dq, sv.node_w, self.knn, self.ident_lw, self.tvox,
                                 res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_dqb, rebuild_candidates=self._first)
         self._first = False
-        return self.refresh_samples()
+        mark("tsdf_update")
+        n = self.refresh_samples()
+        mark("samples")
+        return n

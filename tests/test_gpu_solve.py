@@ -62,6 +62,18 @@ def test_sample_knn_vs_oracle():
         assert np.array_equal(nbr.cpu().numpy(), loc)
         w = G.blend_weights(pts, npos[loc], nw[loc])
         assert np.abs(wts.cpu().numpy() - w).max() <= 1e-15 * 4
+    # spatially coherent samples (consecutive band voxels along z, as the extraction emits them): the bounding-box
+    # pruning is active; more nodes than the candidate capacity; duplicated nodes = exact distance ties (lower index wins)
+    for N, k in ((1500, 4), (700, 8), (600, 3)):
+        npos = rng.uniform(0, 120, size=(N, 3)); nw = rng.uniform(2, 6, size=N)
+        npos[N // 2:N // 2 + 20] = npos[:20]
+        z = np.arange(900, dtype=np.float64)
+        pts = np.stack([20.0 + (z // 300) + 0.3 * np.sin(z), 33.0 + 0.2 * np.cos(z), (z % 300) * 0.4], axis=1)
+        pts = np.concatenate([pts, rng.uniform(0, 120, size=(300, 3))])      # and one incoherent tail (no pruning there)
+        nbr, wts = solve.sample_knn(pts, npos, nw, k)
+        loc = O.knn_bruteforce(pts, npos, k)
+        assert np.array_equal(nbr.cpu().numpy(), loc)
+        assert np.abs(wts.cpu().numpy() - G.blend_weights(pts, npos[loc], nw[loc])).max() <= 1e-15 * 4
 
 
 def make_solver(npos, ndq, nw, nbr, vidx, verts, norms, corr, knn, pcg_iters=400, sort=True, valid=None):

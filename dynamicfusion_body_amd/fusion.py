@@ -222,6 +222,46 @@ class Fusion:
         fr = _solve.residual_reg(dqs, nbr[vidx], pos, w, rw)
         return torch.cat([fd, fr]).cpu().numpy()
 
+    def setupCorrespondences(self, curr_tsdf, method='cnn', prune_result=True, tolerance=0.2, live_vertices=None):
+        """Closest-point correspondences of the DQB-warped canonical vertices in the live surface; reference
+        core/fusion.py:243-314, the branch taken without a CNN session (`self._sess is None or method ==
+        'clpts'`): live mesh by marching cubes, warp each vertex / normal with its blended node DQs and `_lw`,
+        knn nearest live vertices, smallest point-to-plane cost.  With `prune_result`, vertices whose best cost
+        exceeds `tolerance` are removed from `_vertices / _normals / _neighbor_look_up / _correspondences`, `_faces`
+        is dropped and the nodes are re-anchored to their nearest remaining vertex (:297-313).  Not reproduced: at
+        HEAD the pruned index is shadowed by the inner loop variable (`idx_pruned.append(idx)` appends a LIVE vertex
+        index, :273-274) -- the intended canonical index is used.  `live_vertices` replaces the marching-cubes call."""
+        if self._vertices is None or self._normals is None or len(self._neighbor_look_up) == 0:
+            raise ValueError('canonical vertices / normals / _neighbor_look_up have not been set')
+        self._curr_tsdf = curr_tsdf
+        lverts = self.marching_cubes(curr_tsdf, step_size=1)[0] if live_vertices is None else np.asarray(live_vertices)
+        if len(lverts) < self._knn:
+            raise ValueError('fewer live vertices than knn')
+        V = np.asarray(self._vertices, dtype=np.float64)
+        Nn = np.asarray(self._normals, dtype=np.float64)
+        nbr = np.asarray(self._neighbor_look_up, dtype=np.int64)
+        pos, dq, w, _ = self.node_arrays()
+        vp, wn = _solve.warp_points(V, Nn, np.asarray(self._lw, dtype=np.float64), nbr=nbr, node_dq=dq, node_pos=pos, node_w=w)
+        corr, cost, keep = _solve.closest_correspondences(vp, wn, np.asarray(lverts, dtype=np.float64), self._knn, tolerance)
+        corr = corr.cpu().numpy()
+        keep = keep.cpu().numpy().astype(bool)
+        self._correspondences = corr
+        if prune_result:
+            if self._verbose:
+                print('ratio of correspondence outlier rejection', float((~keep).sum()) / float(len(V)))
+            self._vertices = np.asarray(self._vertices)[keep]
+            self._correspondences = corr[keep]
+            self._neighbor_look_up = nbr[keep]
+            self._normals = np.asarray(self._normals)[keep]
+            self._faces = None
+            if len(self._vertices) > 0 and getattr(self, '_radius', None) is not None:
+                from scipy.spatial import cKDTree
+                vt = cKDTree(np.asarray(self._vertices, dtype=np.float64))
+                for i in range(len(self._nodes)):
+                    nd = self._nodes[i]
+                    _, vidx = vt.query(np.asarray(nd[1], dtype=np.float64))
+                    self._nodes[i] = (int(vidx), nd[1], nd[2], 2 * self._radius)
+
     def solve(self, correspondences=None, method='cnn', precompute_lw=True, tukey_data_weight=0.2,
               huber_regularization_weight=0.001, regularization_weight=1, iterations=10, pcg_iters=30):
         """Estimate the warp field {dg_SE3} for the current correspondences; call surface of
@@ -230,10 +270,11 @@ class Fusion:
         by Levenberg-Marquardt on 6-DoF twists with analytic Jacobians (HIP kernels).  Kept from
         the reference: the optional global `_lw` pre-fit on `computef_lw` (:350-364) and the /8
         relaxation of `regularization_weight` while the cost reduction stays in (5 %, 90 %)
-        (:405-412).  Re-association between rounds needs marching cubes (:370-371) and is the
-        caller's job."""
+        (:405-412), and -- with method='clpts' and no explicit correspondences -- the re-association against
+        the stored live volume after the `_lw` pre-fit and before every later round (:364-365, :370-371)."""
         if correspondences is not None:
             self._correspondences = correspondences
+        reassociate = method == 'clpts' and correspondences is None and self._curr_tsdf is not None
         V, Nn, nbr, C = self._vertex_state()
         pos, dq, w, vidx = self.node_arrays()
         self._itercounter += 1
@@ -247,13 +288,26 @@ class Fusion:
             x1, n1 = self._blend_warp_batch(sv0, V, Nn)
             lw, _ = _solve.solve_rigid_gn(np.asarray(self._lw, dtype=np.float64), x1, n1, C, iters=iterations)
             self._lw = lw
+            if reassociate:
+                self.setupCorrespondences(self._curr_tsdf, method='clpts')       # :364-365 (may prune vertices)
         rounds = 3 if method == 'clpts' else 1
-        sv = _solve.WarpSolver(knn=nbr.shape[1], pcg_iters=pcg_iters)
-        sv.set_graph(pos, dq, w, node_nbr=nbr[vidx])
-        sv.set_samples(V, Nn, nbr=nbr)
-        sv.set_correspondences(C)
+
+        def make_solver():
+            V, Nn, nbr, C = self._vertex_state()
+            pos, dq, w, vidx = self.node_arrays()
+            s_ = _solve.WarpSolver(knn=nbr.shape[1], pcg_iters=pcg_iters)
+            s_.set_graph(pos, dq, w, node_nbr=nbr[vidx])
+            s_.set_samples(V, Nn, nbr=nbr)
+            s_.set_correspondences(C)
+            return s_
+
+        sv = make_solver()
         self.last_costs = []
-        for _ in range(rounds):
+        for rnd in range(rounds):
+            if rnd > 0 and reassociate:
+                self._write_back(sv)
+                self.setupCorrespondences(self._curr_tsdf, method='clpts')       # :370-371
+                sv = make_solver()
             costs = sv.solve_lm(np.asarray(self._lw, dtype=np.float64), regularization_weight, iters=iterations, lm_abs=1e-3)
             self.last_costs.append(costs)
             cost_before, cost_after = costs[0], costs[-1]
@@ -262,6 +316,9 @@ class Fusion:
                 regularization_weight /= 8                                      # :407-408
             else:
                 break
+        self._write_back(sv)
+
+    def _write_back(self, sv):
         new_dq = sv.node_dq.cpu().numpy()
         for idx in range(len(self._nodes)):                                     # :400-403
             nd = self._nodes[idx]

@@ -340,6 +340,55 @@ def test_setup_correspondences_matches_reference(golden):
     assert np.abs(cost.cpu().numpy() - co).max() <= 1e-12 and np.array_equal(keep.cpu().numpy().astype(bool), ko)
     with pytest.raises(ValueError):
         solve.closest_correspondences(vp, wn, g["lverts"][:2], k, 0.2)
+    # the class method: Fusion.setupCorrespondences, closest-points branch (core/fusion.py:243-314)
+    from dynamicfusion_body_amd import Fusion
+    def fresh():
+        fu = Fusion(np.zeros((4, 4, 4)), 1.0, knn=k, write_warpfield=False)
+        fu._vertices, fu._normals, fu._lw = g["verts"].copy(), g["norms"].copy(), g["lw"]
+        fu._neighbor_look_up = g["nbr"].copy()
+        fu._nodes = [(0, g["node_pos"][i], g["node_dq"][i], float(g["node_w"][i])) for i in range(len(g["node_pos"]))]
+        fu._radius = 1.5
+        return fu
+    fu = fresh()
+    fu.setupCorrespondences(None, method='clpts', prune_result=False, tolerance=0.2, live_vertices=g["lverts"])
+    assert np.array_equal(np.asarray(fu._correspondences), g["nr_corr"]) and len(fu._vertices) == len(g["verts"])
+    fu = fresh()
+    fu.setupCorrespondences(None, method='clpts', prune_result=True, tolerance=0.2, live_vertices=g["lverts"])
+    assert 0 < ko.sum() < len(ko)
+    assert np.array_equal(fu._vertices, g["verts"][ko]) and np.array_equal(fu._normals, g["norms"][ko])
+    assert np.array_equal(fu._neighbor_look_up, g["nbr"][ko]) and np.array_equal(fu._correspondences, g["nr_corr"][ko])
+    assert fu._faces is None
+    for nd in fu._nodes:                                             # nodes re-anchored to their nearest kept vertex
+        assert nd[0] == int(np.argmin(np.linalg.norm(g["verts"][ko] - nd[1], axis=1))) and nd[3] == 3.0
+
+
+def test_fusion_frame_loop_with_mesh_correspondences():
+    """The reference's non-rigid frame loop on the Fusion class, every step on the device path: initial mesh and
+    graph, live mesh + closest-point correspondences, three rounds of [associate -> minimise] (`solve(method=
+    'clpts')` re-associating against the stored live volume), DQB TSDF update, graph update."""
+    from dynamicfusion_body_amd import Fusion
+    R = 40
+    X, Y, Z = np.meshgrid(*(np.arange(R),) * 3, indexing="ij")
+    sd = lambda c, r: np.clip(np.sqrt((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2) - r, -3.0, 3.0).astype(np.float32)
+    fu = Fusion(sd((19.6, 20.2, 19.9), 11.5), 3.0, subsample_rate=3.0, knn=4, marching_cubes_step_size=1, write_warpfield=False)
+    fu._lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+    fu.initialize_canonical()
+    nv0, nn0 = len(fu._vertices), len(fu._nodes)
+    live = sd((20.3, 19.8, 20.4), 11.7)                               # moved and slightly inflated
+    fu.setupCorrespondences(live, method='clpts', prune_result=True, tolerance=2.0)
+    assert 0.5 * nv0 < len(fu._vertices) <= nv0 and len(fu._correspondences) == len(fu._vertices)
+    f0 = fu.computef(np.concatenate([n[2] for n in fu._nodes]), 0.2, 0.001, 1)
+    c0 = 0.5 * float(f0 @ f0)
+    fu.solve(method='clpts', precompute_lw=True, regularization_weight=1, iterations=8)
+    f1 = fu.computef(np.concatenate([n[2] for n in fu._nodes]), 0.2, 0.001, 1)
+    c1 = 0.5 * float(f1 @ f1)
+    assert c1 < 0.2 * c0, (c0, c1)
+    assert 1 <= len(fu.last_costs) <= 3
+    T0 = fu._tsdf.copy()
+    fu.updateTSDF(live)
+    assert np.abs(fu._tsdf - T0).max() > 0.05
+    fu.update_graph()
+    assert len(fu._nodes) >= nn0 and fu._faces is not None and len(fu._correspondences) == 0
 
 
 def test_icp_compute_live_tsdf_recovers_rigid_motion():

@@ -318,6 +318,32 @@ class Fusion:
                 break
         self._write_back(sv)
 
+    def computeSparsity(self, n, m):
+        """Jacobian sparsity of `computef` for a solver that wants it (reference core/fusion.py:416-442): data row
+        idx touches the 8 DQ entries of each of its k nodes; the three regularisation rows of node idx touch node
+        idx and the nodes in the look-up row of its anchor vertex.  (Only the first of the node's k regulariser
+        triples is marked there -- reproduced; this build's own solver does not use it.)"""
+        from scipy.sparse import coo_matrix
+        nbr = np.asarray(self._neighbor_look_up, dtype=np.int64)
+        V = len(self._vertices)
+        N = len(self._nodes)
+        e8 = np.arange(8)
+        rows = [np.repeat(np.arange(V), nbr.shape[1] * 8)]
+        cols = [(8 * nbr[:, :, None] + e8).reshape(-1)]
+        vidx = np.array([int(nd[0]) for nd in self._nodes], dtype=np.int64)
+        node_cols = np.concatenate([np.arange(N)[:, None], nbr[vidx]], axis=1)            # (N, 1+k)
+        r3 = V + 3 * np.arange(N)[:, None] + np.arange(3)                                 # (N, 3)
+        rows.append(np.repeat(r3.reshape(-1), node_cols.shape[1] * 8))
+        cols.append(np.tile((8 * node_cols[:, :, None] + e8).reshape(N, 1, -1), (1, 3, 1)).reshape(-1))
+        r, c = np.concatenate(rows), np.concatenate(cols)
+        mat = coo_matrix((np.ones(len(r), dtype=np.float32), (r, c)), shape=(n, m)).tocsr()       # duplicates add up:
+        mat.data[:] = 1.0                                                                          # entries are flags
+        return mat.tolil()
+
+    def write_live_frame_mesh(self, path, filename, warpfield_path):
+        """Reference core/fusion.py:589-590: an empty stub there too."""
+        pass
+
     def _write_back(self, sv):
         new_dq = sv.node_dq.cpu().numpy()
         for idx in range(len(self._nodes)):                                     # :400-403

@@ -216,6 +216,16 @@ class FusionDM:
         verts, faces, normals, values = _mesh.marching_cubes(self._T, 0.0, 1, as_numpy=True)
         _mesh.write_obj(os.path.join(path, filename), verts, faces, normals, ind=self._IND)
 
+    def write_live_frame_mesh(self, path, filename, warpfield_path):
+        """Reference core/fusion_dm.py:357-358: an empty stub there too."""
+        pass
+
+    def average_edge_dist_in_face(self, f):
+        """Reference core/fusion_dm.py:360-364."""
+        v1, v2, v3 = (np.asarray(self._vertices[i]) for i in f[:3])
+        d = lambda a, b: np.linalg.norm(a - b)
+        return (d(v1, v2) + d(v1, v3) + d(v2, v3)) / 3
+
     def setupCorrespondences(self, curr_tsdf, prune_result=True, tolerance=1.0, live_vertices=None):
         """Closest-point correspondences of the canonical vertices in the live surface; reference
         core/fusion_dm.py:219-244 (warp by `_lw`, knn nearest live vertices, smallest point-to-plane

@@ -66,3 +66,26 @@ def test_file_formats(golden, tmp_path):
     back = pickle.load(open(f, "rb"))
     assert back[0][0] == 3 and np.array_equal(back[0][2], np.arange(8.0)) and back[0][3] == 6.2
     assert io.read_warp_field(f)[0][0] == 3
+
+
+def test_compute_sparsity_pattern():
+    """Fusion.computeSparsity against the reference's loops (core/fusion.py:416-442) restated here."""
+    from dynamicfusion_body_amd import Fusion
+    rng = np.random.default_rng(0)
+    V, N, k = 23, 7, 3
+    fu = Fusion(np.zeros((4, 4, 4)), 1.0, knn=k, write_warpfield=False)
+    fu._vertices = rng.normal(size=(V, 3))
+    fu._neighbor_look_up = np.array([rng.choice(N, size=k, replace=False) for _ in range(V)])
+    fu._nodes = [(int(rng.integers(V)), rng.normal(size=3), np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), 1.0) for _ in range(N)]
+    n, m = V + 3 * k * N, 8 * N
+    S = fu.computeSparsity(n, m).toarray()
+    want = np.zeros((n, m), dtype=np.float32)
+    for idx in range(V):
+        for loc in fu._neighbor_look_up[idx]:
+            want[idx, 8 * loc:8 * loc + 8] = 1
+    for idx in range(N):
+        for r in range(3):
+            want[V + 3 * idx + r, 8 * idx:8 * idx + 8] = 1
+            for nidx in fu._neighbor_look_up[fu._nodes[idx][0]]:
+                want[V + 3 * idx + r, 8 * nidx:8 * nidx + 8] = 1
+    assert np.array_equal(S, want)

@@ -76,7 +76,15 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
     ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
     fs.set_graph(node_pos, ident, node_w)
     a, b = D.slab_range(R, rank, world)
-    S = fs.set_canonical(T[a:b], Wt[a:b], band=4.0, x0=a)
+    # this rank's samples; normals are central differences across the slab faces too: one halo plane each side with
+    # weight 0 (gradients only), so the union over ranks is the single-GPU sample set
+    lo, hi = max(a - 1, 0), min(b + 1, R)
+    Wp = Wt[lo:hi].clone()
+    if lo < a:
+        Wp[0] = 0
+    if hi > b:
+        Wp[-1] = 0
+    S = fs.set_canonical(T[lo:hi].contiguous(), Wp, band=4.0, x0=lo)
     lw_cam = scene.view_extrinsic(0.0)
     live = scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=np.array([0.6, -0.4, 0.3]) * scale,
                               sphere_r=scene.SPHERE_R * 1.02)

@@ -1418,7 +1418,9 @@ __device__ __forceinline__ bool grid_sum2(double *slots, unsigned *abort_flag, B
     return lds->ok != 0;
 }
 
-__global__ __launch_bounds__(1024) void pcg_cg1_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col, double *vals,
+// MAXT = largest workgroup it is launched with: 512 leaves 256 VGPRs per lane (no spills in the prologue's 6x6 inverse)
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col, double *vals,
                                                         const double *__restrict__ rhs, const PcgParams prm, int iters,
                                                         double *__restrict__ x, double *pub /* 2 x {u, v, t} x 6N */, double *part,
                                                         unsigned *abort_flag) {
@@ -1432,25 +1434,8 @@ __global__ __launch_bounds__(1024) void pcg_cg1_kernel(const int *__restrict__ r
     const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63 idle in the SpMV
     const int beg = row ? row_ptr[a] : 0, end = row ? row_ptr[a + 1] : 0;
     const bool lead = row && lane < 6;
-    // damp the diagonal block (the damping lives in the matrix) and invert it: block-Jacobi preconditioner
-    const int dblk = lead ? find_block(row_ptr, col, a, a) : -1;
-    double Mi[6];
-    {
-        double D[36], Di[36];
-#pragma unroll
-        for (int t = 0; t < 36; ++t) D[t] = dblk >= 0 ? vals[36 * (size_t)dblk + t] : 0.0;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) D[7 * t] = D[7 * t] + prm.lm_abs + prm.lm_rel * D[7 * t];
-        inv6(D, Di);                                            // lanes 0..5 redundantly: same cost as one lane
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            double v = Di[j];
-#pragma unroll
-            for (int rr = 1; rr < 6; ++rr) v = lane == rr ? Di[6 * rr + j] : v;
-            Mi[j] = lead ? v : 0.0;
-        }
-    }
-    // register cache of this row's blocks: lane (slot, i) holds row i of blocks beg+slot+10c
+    // register cache of this row's blocks: lane (slot, i) holds row i of blocks beg+slot+10c; the diagonal block gets
+    // its damping here (the damping lives in the matrix: it is also written back below)
     double Bc[kRowCache][6];
     int cj[kRowCache];
 #pragma unroll
@@ -1460,12 +1445,53 @@ __global__ __launch_bounds__(1024) void pcg_cg1_kernel(const int *__restrict__ r
         cj[c] = have ? col[b] : -1;
 #pragma unroll
         for (int j = 0; j < 6; ++j) Bc[c][j] = have ? vals[36 * (size_t)b + 6 * i + j] : 0.0;
-        if (have && cj[c] == a) Bc[c][i] = Bc[c][i] + prm.lm_abs + prm.lm_rel * Bc[c][i];     // same expression as D above
+        if (have && cj[c] == a) {
+            Bc[c][i] = Bc[c][i] + prm.lm_abs + prm.lm_rel * Bc[c][i];
+            vals[36 * (size_t)b + 7 * i] = Bc[c][i];           // (only this lane reads that element, and it has)
+        }
     }
-    __builtin_amdgcn_s_waitcnt(0);                              // every read of the undamped diagonal has returned
-    if (dblk >= 0) {
-        const double d0 = vals[36 * (size_t)dblk + 7 * lane];
-        vals[36 * (size_t)dblk + 7 * lane] = d0 + prm.lm_abs + prm.lm_rel * d0;
+    // block-Jacobi preconditioner: the damped diagonal block, from the register cache when it is there (six lanes hold
+    // its rows: 36 shuffles instead of a binary search and a reload), else found and loaded the slow way
+    double D[36];
+    bool cached = false;
+#pragma unroll
+    for (int c = 0; c < kRowCache; ++c) {
+        const unsigned long long m = __ballot(row && slot < 10 && cj[c] == a);
+        if (m != 0ull && !cached) {                            // (wave-uniform)
+            const int base = __ffsll((long long)m) - 1;        // lane (slot_d, 0)
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) D[6 * r + j] = __shfl(Bc[c][j], base + r, 64);
+            cached = true;
+        }
+    }
+    if (!cached) {
+        const int dblk = lead ? find_block(row_ptr, col, a, a) : -1;
+        __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+        for (int t = 0; t < 36; ++t) D[t] = dblk >= 0 ? vals[36 * (size_t)dblk + t] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) D[7 * t] = D[7 * t] + prm.lm_abs + prm.lm_rel * D[7 * t];
+        __builtin_amdgcn_s_waitcnt(0);                          // every read of the undamped diagonal has returned
+        if (dblk >= 0) {
+            double dv = D[0];
+#pragma unroll
+            for (int rr = 1; rr < 6; ++rr) dv = lane == rr ? D[7 * rr] : dv;
+            vals[36 * (size_t)dblk + 7 * lane] = dv;
+        }
+    }
+    double Mi[6];
+    {
+        double Di[36];
+        inv6(D, Di);                                            // lanes 0..5 redundantly: same cost as one lane
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double v = Di[j];
+#pragma unroll
+            for (int rr = 1; rr < 6; ++rr) v = lane == rr ? Di[6 * rr + j] : v;
+            Mi[j] = lead ? v : 0.0;
+        }
     }
     // y = A q for this row, q_j = what the closure returns for element i of neighbour j (lane (slot, i) asks for
     // element i; the six lanes of a slot trade them); result in lanes 0..5
@@ -1883,8 +1909,12 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
             hipLaunchKernelGGL(pcg_persistent_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, z, pA,
                                pB, part, flag);
         else                                       // Minv's 36 N doubles hold the two sets of published {u, v, t}
-            hipLaunchKernelGGL(pcg_cg1_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
-                               flag);
+            if (wpb <= 8)
+                hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv,
+                                   part, flag);
+            else
+                hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv,
+                                   part, flag);
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }

@@ -1112,12 +1112,15 @@ __global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double 
 }
 
 // ---- persistent PCG: the whole iteration loop in one launch --------------------------------------
-// Same arithmetic as pcg_spmv_kernel + pcg_update_xr_kernel, but every wave owns ONE node row for
-// the whole solve: its 6x6 blocks (up to kRowCache per lane slot), its rows of Minv and its six
-// entries of x, r, z, p stay in registers; per iteration only the neighbours' (z, p_prev) are read
-// (agent-scope loads) and two grid-wide barriers replace the two kernel boundaries.  The grid is
-// sized so that all workgroups are co-resident (<= one per CU); the barrier spin is bounded and an
-// abort flag makes every wave leave if one ever times out (x is then NaN, never a hang).
+// Every wave owns ONE node row for the whole solve: its 6x6 blocks (up to kRowCache per lane slot), its rows of the
+// block-Jacobi inverse and its six entries of the CG vectors stay in registers; per iteration only the neighbours'
+// published vectors are read (agent-scope loads) and ONE grid-wide reduction, which doubles as the grid barrier,
+// replaces the kernel boundaries.  The grid is sized so that all workgroups are co-resident (<= one per CU on at
+// most half the CUs); the spin is bounded and an abort flag makes every wave leave if one ever times out (x is
+// then NaN, never a hang).  Reductions: every workgroup adds its waves' values in LDS (fixed order) and publishes the
+// partial with an agent-coherent store into a slot that is all-zero bits before the launch (a zero partial is stored
+// as -0.0, so "bits != 0" is the arrival flag); wave 0 polls all slots and adds them in a fixed order: same bits
+// every run and on every rank, no floating-point atomics, no counters, no cache-wide fences.
 constexpr int kRowCache = 3;               // blocks per lane slot held in registers (rows <= 30 blocks)
 constexpr unsigned kSpinLimit = 1u << 22;  // ~seconds
 constexpr int kMaxPcgBlocks = 512;         // persistent path only for grids up to this many workgroups
@@ -1127,228 +1130,6 @@ __device__ __forceinline__ double ld_agent(const double *p) {
 }
 __device__ __forceinline__ void st_agent(double *p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Grid-wide sum that doubles as the grid barrier.  `slots` = gridDim.x doubles, all-zero bits
-// before the launch (the host memsets them), used by exactly one reduction.  Every workgroup adds
-// its waves' values in LDS (fixed order) and publishes the partial with an agent-coherent store; a
-// partial whose bits are all zero is published as -0.0, so "bits != 0" is the arrival flag.  Wave 0
-// then polls all slots and adds them in a fixed order (same bits every run and on every rank).
-// Everything a wave published before (agent-coherent stores followed by s_waitcnt 0) is visible to
-// whoever has seen its workgroup's partial.  No cache-wide fences and no read-modify-write atomics:
-// per reduction the critical path is store -> poll.  The spin is bounded and an abort flag makes
-// every workgroup leave if one ever times out.  Returns false (block-uniform) on abort.
-struct BarrierLds {
-    double wave_part[16];
-    double total;
-    int ok;
-};
-
-__device__ __forceinline__ bool grid_sum(double *slots, unsigned *abort_flag, BarrierLds *lds, double wave_val /* lane 0 */,
-                                         double *sum_out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    __builtin_amdgcn_s_waitcnt(0);                      // this wave's published z / p have reached the coherence point
-    if (lane == 0) lds->wave_part[wave] = wave_val;
-    __syncthreads();
-    if (wave == 0) {
-        if (lane == 0) {
-            double v = 0.0;
-            for (int w = 0; w < waves; ++w) v += lds->wave_part[w];
-            if (__double_as_longlong(v) == 0) v = -0.0;
-            st_agent(slots + blockIdx.x, v);
-        }
-        const int nb = (int)gridDim.x;
-        unsigned spins = 0;
-        int ok = 1;
-        double tot = 0.0;
-        if (nb <= 64) {
-            // one slot per lane; two polls in flight so that a new arrival is seen half a round trip sooner
-            const double *my = slots + (lane < nb ? lane : 0);
-            double t0 = ld_agent(my);
-            for (;;) {
-                const double t1 = ld_agent(my);
-                if (__all(lane >= nb || __double_as_longlong(t0) != 0)) break;
-                t0 = ld_agent(my);
-                if (__all(lane >= nb || __double_as_longlong(t1) != 0)) { t0 = t1; break; }
-                if (++spins > kSpinLimit || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-            }
-            double v = lane < nb ? t0 : 0.0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            tot = v;
-        } else {
-            for (;;) {
-                double v = 0.0;
-                bool all = true;
-                for (int b = lane; b < nb; b += 64) {
-                    const double t = ld_agent(slots + b);
-                    all = all && (__double_as_longlong(t) != 0);
-                    v += t;
-                }
-                if (__all(all)) {
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                    tot = v;
-                    break;
-                }
-                if (++spins > kSpinLimit || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        if (lane == 0) { lds->total = tot; lds->ok = ok; }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    *sum_out = lds->total;
-    return lds->ok != 0;
-}
-
-__global__ __launch_bounds__(1024) void pcg_persistent_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col,
-                                                               double *vals, const double *__restrict__ rhs, const PcgParams prm,
-                                                               int iters, double *__restrict__ x, double *z, double *pA, double *pB,
-                                                               double *part, unsigned *abort_flag) {
-    __shared__ BarrierLds lds;
-    const int N = prm.N;
-    const int lane = threadIdx.x & 63;
-    const int waves = blockDim.x >> 6;
-    const int a = blockIdx.x * waves + (threadIdx.x >> 6);
-    const bool row = a < N;
-    const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63 idle in the SpMV
-    const int beg = row ? row_ptr[a] : 0, end = row ? row_ptr[a + 1] : 0;
-    const bool lead = row && lane < 6;
-    // -- what pcg_init_kernel does, per row: damp the diagonal block (the damping lives in the
-    //    matrix), invert it (block-Jacobi preconditioner), r0 = -rhs, z0 = Minv r0 -------------
-    const int dblk = lead ? find_block(row_ptr, col, a, a) : -1;
-    double Mi[6];
-    {
-        double D[36], Di[36];
-#pragma unroll
-        for (int t = 0; t < 36; ++t) D[t] = dblk >= 0 ? vals[36 * (size_t)dblk + t] : 0.0;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) D[7 * t] = D[7 * t] + prm.lm_abs + prm.lm_rel * D[7 * t];
-        inv6(D, Di);                                            // lanes 0..5 redundantly: same cost as one lane
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            double v = Di[j];
-#pragma unroll
-            for (int rr = 1; rr < 6; ++rr) v = lane == rr ? Di[6 * rr + j] : v;
-            Mi[j] = lead ? v : 0.0;
-        }
-    }
-    // register cache of this row's blocks: lane (slot, i) holds row i of blocks beg+slot+10c
-    double Bc[kRowCache][6];
-    int cj[kRowCache];
-#pragma unroll
-    for (int c = 0; c < kRowCache; ++c) {
-        const int b = beg + slot + 10 * c;
-        const bool have = slot < 10 && b < end;
-        cj[c] = have ? col[b] : -1;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) Bc[c][j] = have ? vals[36 * (size_t)b + 6 * i + j] : 0.0;
-        if (have && cj[c] == a) Bc[c][i] = Bc[c][i] + prm.lm_abs + prm.lm_rel * Bc[c][i];     // same expression as D above
-    }
-    __builtin_amdgcn_s_waitcnt(0);                              // every read of the undamped diagonal has returned
-    if (dblk >= 0) {
-        double dv = 0.0;
-        {
-            const double d0 = vals[36 * (size_t)dblk + 7 * lane];
-            dv = d0 + prm.lm_abs + prm.lm_rel * d0;
-        }
-        vals[36 * (size_t)dblk + 7 * lane] = dv;
-    }
-    double xi = 0.0, ri = lead ? -rhs[6 * a + lane] : 0.0, pi = 0.0;
-    double zi = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) zi += Mi[j] * __shfl(ri, j, 64);
-    double contrib = 0.0;
-    if (lead) {
-        st_agent(z + 6 * a + lane, zi);
-        contrib = ri * zi;
-    }
-    contrib += __shfl_down(contrib, 4, 64);
-    contrib += __shfl_down(contrib, 2, 64);
-    contrib += __shfl_down(contrib, 1, 64);
-    double rz_prev = 0.0, rz_cur = 0.0;
-    bool ok = grid_sum(part, abort_flag, &lds, contrib, &rz_cur);
-    part += gridDim.x;
-    double *p_prev = pA, *p_cur = pB;
-    const unsigned nblk = gridDim.x;
-    for (int it = 0; it < iters && ok; ++it) {
-        const double beta = rz_prev != 0.0 ? rz_cur / rz_prev : 0.0;
-        double acc = 0.0;
-#pragma unroll
-        for (int c = 0; c < kRowCache; ++c) {
-            // lane (slot, i) fetches entry i of its neighbour's new direction; the six lanes of the slot trade them
-            const int j6 = 6 * (cj[c] >= 0 ? cj[c] : 0) + i;
-            const double qi = slot < 10 ? ld_agent(z + j6) + beta * ld_agent(p_prev + j6) : 0.0;
-            const int base = 6 * slot;
-            const double q0 = __shfl(qi, base + 0, 64), q1 = __shfl(qi, base + 1, 64), q2 = __shfl(qi, base + 2, 64);
-            const double q3 = __shfl(qi, base + 3, 64), q4 = __shfl(qi, base + 4, 64), q5 = __shfl(qi, base + 5, 64);
-            if (cj[c] >= 0)
-                acc += ((Bc[c][0] * q0 + Bc[c][1] * q1) + (Bc[c][2] * q2 + Bc[c][3] * q3)) + (Bc[c][4] * q4 + Bc[c][5] * q5);
-        }
-        if (slot < 10) {
-            for (int b = beg + slot + 10 * kRowCache; b < end; b += 10) {      // rows wider than the cache
-                const double *B = vals + 36 * (size_t)b + 6 * i;
-                const double *zj = z + 6 * col[b];
-                const double *pj = p_prev + 6 * col[b];
-                const double q0 = ld_agent(zj + 0) + beta * ld_agent(pj + 0), q1 = ld_agent(zj + 1) + beta * ld_agent(pj + 1);
-                const double q2 = ld_agent(zj + 2) + beta * ld_agent(pj + 2), q3 = ld_agent(zj + 3) + beta * ld_agent(pj + 3);
-                const double q4 = ld_agent(zj + 4) + beta * ld_agent(pj + 4), q5 = ld_agent(zj + 5) + beta * ld_agent(pj + 5);
-                acc += ((B[0] * q0 + B[1] * q1) + (B[2] * q2 + B[3] * q3)) + (B[4] * q4 + B[5] * q5);
-            }
-        }
-        double y = acc;
-#pragma unroll
-        for (int k = 1; k < 10; ++k) {
-            const double o = __shfl(acc, lane + 6 * k, 64);
-            y += (lane + 6 * k < 60) ? o : 0.0;
-        }
-        contrib = 0.0;
-        if (lead) {
-            pi = zi + beta * pi;
-            st_agent(p_cur + 6 * a + lane, pi);
-            contrib = pi * y;
-        }
-        contrib += __shfl_down(contrib, 4, 64);
-        contrib += __shfl_down(contrib, 2, 64);
-        contrib += __shfl_down(contrib, 1, 64);
-        double pAp;
-        ok = grid_sum(part + (size_t)(2 * it) * nblk, abort_flag, &lds, contrib, &pAp);
-        if (!ok) break;
-        const double alpha = pAp != 0.0 ? rz_cur / pAp : 0.0;
-        if (lead) {
-            xi += alpha * pi;
-            ri = ri - alpha * y;
-        }
-        double zz = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) zz += Mi[j] * __shfl(ri, j, 64);
-        contrib = 0.0;
-        if (lead) {
-            zi = zz;
-            st_agent(z + 6 * a + lane, zi);
-            contrib = ri * zi;
-        }
-        contrib += __shfl_down(contrib, 4, 64);
-        contrib += __shfl_down(contrib, 2, 64);
-        contrib += __shfl_down(contrib, 1, 64);
-        double rz_next;
-        ok = grid_sum(part + (size_t)(2 * it + 1) * nblk, abort_flag, &lds, contrib, &rz_next);
-        if (!ok) break;
-        rz_prev = rz_cur;
-        rz_cur = rz_next;
-        double *t = p_prev; p_prev = p_cur; p_cur = t;
-    }
-    if (lead) x[6 * a + lane] = ok ? xi : __builtin_nan("");
 }
 
 // ---- single-reduction PCG (Chronopoulos & Gear) -----------------------------------------------------------
@@ -1905,16 +1686,13 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
     if (2 * nblk <= n_cu && nblk <= kMaxPcgBlocks && !getenv("DFH_PCG_MULTILAUNCH")) {
         unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
         double *part = scal + 3 * ((size_t)iters + 2);                                    // (2 per iteration + 1) reductions x nblk slots
-        if (getenv("DFH_PCG_TWO_REDUCTIONS"))      // the textbook recurrence (two reductions per iteration), kept for A/B runs
-            hipLaunchKernelGGL(pcg_persistent_kernel, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, z, pA,
-                               pB, part, flag);
-        else                                       // Minv's 36 N doubles hold the two sets of published {u, v, t}
-            if (wpb <= 8)
-                hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv,
-                                   part, flag);
-            else
-                hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv,
-                                   part, flag);
+        // Minv's 36 N doubles hold the two sets of published {u, v, t}
+        if (wpb <= 8)
+            hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
+                               flag);
+        else
+            hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
+                               flag);
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }

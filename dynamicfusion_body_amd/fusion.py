@@ -280,12 +280,7 @@ class Fusion:
         self._itercounter += 1
         if precompute_lw:
             # x' = W(lw, x1): the rigid GN on the pre-warped points is exactly computef_lw's problem
-            ident = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
-            loc = nbr
-            sv0 = _solve.WarpSolver(knn=nbr.shape[1])
-            sv0.set_graph(pos, dq, w)
-            sv0.set_samples(V, Nn, nbr=loc, sort=False)
-            x1, n1 = self._blend_warp_batch(sv0, V, Nn)
+            x1, n1 = self._blend_warp_batch(V, Nn, nbr)
             lw, _ = _solve.solve_rigid_gn(np.asarray(self._lw, dtype=np.float64), x1, n1, C, iters=iterations)
             self._lw = lw
             if reassociate:
@@ -350,25 +345,13 @@ class Fusion:
             nd = self._nodes[idx]
             self._nodes[idx] = (nd[0], nd[1], new_dq[idx], nd[3])
 
-    def _blend_warp_batch(self, sv, V, Nn):
-        """(x1, n1): vertices / normals warped by the blended node DQs only (no `_lw`)."""
-        ident = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
-        zero = np.zeros_like(V)
-        # n'.(x' - 0) with identity lw gives no access to x1 itself, so evaluate the three unit
-        # "normals" e_c through the residual evaluator:  r_c = e_c'.x1' ... simpler: host blend.
+    def _blend_warp_batch(self, V, Nn, nbr):
+        """(x1, n1): vertices / normals warped by the blended node DQs only, on the device (dfh_warp_points with an
+        identity `_lw`: the identity warp returns its float32-rounded input exactly, and that rounding is the one the
+        rigid fit applies to its points anyway, `core/util.py:69`)."""
         pos, dq, w, _ = self.node_arrays()
-        nbr = sv.snbr.cpu().numpy().astype(np.int64)
-        wt = sv.swts.cpu().numpy()
-        b = np.einsum('sk,skc->sc', wt, dq[nbr])
-        b = b / np.sqrt(np.sum(b * b, axis=1, keepdims=True))
-        from .dq import qmul
-        r, d = b[:, :4], b[:, 4:]
-        rc = r * np.array([1.0, -1.0, -1.0, -1.0])
-        P = np.concatenate([np.zeros((len(V), 1)), V.astype(np.float32).astype(np.float64)], axis=1)
-        Nq = np.concatenate([np.zeros((len(V), 1)), Nn.astype(np.float32).astype(np.float64)], axis=1)
-        x1 = (qmul(qmul(r, P), rc) + 2.0 * qmul(d, rc))[:, 1:]
-        n1 = qmul(qmul(r, Nq), rc)[:, 1:]
-        return x1, n1
+        ident = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+        return _solve.warp_points(V, Nn, ident, nbr=nbr, node_dq=dq, node_pos=pos, node_w=w)
 
     # ------------------------------------------------------------------ graph maintenance (§8(f) rank 3)
     def marching_cubes(self, tsdf=None, step_size=0):

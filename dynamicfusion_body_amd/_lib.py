@@ -42,6 +42,7 @@ _SIGNATURES = {
                                 _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, _vp, _vp]),
     "dfh_gn_build": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _c_double_p, _dbl,
                             _vp, _vp, _int, _vp, _vp, _vp, _vp]),
+    "dfh_permute_samples": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dfh_gn_partial_doubles": (ctypes.c_size_t, [_int]),
     "dfh_gn_build_planned": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _c_double_p, _dbl,
                                     _vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -218,13 +218,23 @@ class WarpSolver:
             else:
                 _, inv = torch.unique(nbr, dim=0, return_inverse=True)
                 self.order = torch.argsort(inv, stable=True)
-            pos, nrm, nbr, weights = pos[self.order], nrm[self.order], nbr[self.order], weights[self.order]
+            pos, nrm, nbr, weights = self._permute(pos, nrm, nbr, weights)
         self.spos, self.snrm = pos.contiguous(), nrm.contiguous()
         self.snbr, self.swts = nbr.contiguous(), weights.contiguous()
         self.S = pos.shape[0]
         self.corr = torch.zeros((self.S, 3), dtype=torch.float64, device="cuda")
         self.valid = torch.zeros(self.S, dtype=torch.uint8, device="cuda")
         self._pattern = None
+
+    def _permute(self, pos, nrm, nbr, weights):
+        """The four per-sample arrays in `self.order`, one fused pass (dfh_permute_samples)."""
+        pos, nrm, nbr, weights = pos.contiguous(), nrm.contiguous(), nbr.contiguous(), weights.contiguous()
+        out = (torch.empty_like(pos), torch.empty_like(nrm), torch.empty_like(nbr), torch.empty_like(weights))
+        order = self.order.contiguous()
+        _lib.check(self.lib.dfh_permute_samples(order.data_ptr(), pos.shape[0], self.knn, pos.data_ptr(), nrm.data_ptr(), nbr.data_ptr(),
+                                                weights.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                                out[3].data_ptr(), current_stream_ptr()), "dfh_permute_samples")
+        return out
 
     def _pack_tuples(self, nbr):
         """(S,k) node ids -> int64 keys whose order is the lexicographic order of the tuples; None if k digits

@@ -155,6 +155,11 @@ int dfh_sample_knn(const double *sample_pos, int n_samples, const double *node_p
  * take the nearest depth pixel z = -depth[rint(v)][rint(u)] (:196), back-project K^-1 (z [u,v,1])
  * (:198-200) and map back to index space.  valid_out[s] = 0 when outside the image, no depth, or farther
  * than max_dist voxels from the warped sample (max_dist <= 0: no gate). */
+/* out[i] = in[order[i]] for the four per-sample arrays at once (samples are sorted by node tuple before the build:
+ * few runs per 256-sample tile).  order: n_samples int64 indices, a permutation. */
+int dfh_permute_samples(const long *order, int n_samples, int knn, const double *pos, const double *nrm, const int *nbr,
+                        const double *weights, double *pos_out, double *nrm_out, int *nbr_out, double *weights_out, void *stream);
+
 int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *weights, int n_samples, int knn,
                      const double *node_dq, const double lw_dq[8], const void *depth, int depth_dtype, int H, int W,
                      const double K[9], const double Kinv[9], const double lw_cam[12], double scale,

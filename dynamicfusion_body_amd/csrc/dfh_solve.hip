@@ -400,6 +400,25 @@ __global__ __launch_bounds__(256) void sample_knn_kernel(const double *__restric
     }
 }
 
+// Samples into the order of `order` (the sort by node tuple): positions, normals, node ids and blend weights in one pass.
+__global__ __launch_bounds__(256) void permute_samples_kernel(const long *__restrict__ order, int S, int k, const double *__restrict__ pos,
+                                                              const double *__restrict__ nrm, const int *__restrict__ nbr,
+                                                              const double *__restrict__ wts, double *__restrict__ pos_o,
+                                                              double *__restrict__ nrm_o, int *__restrict__ nbr_o, double *__restrict__ wts_o) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    const size_t src = (size_t)order[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pos_o[3 * (size_t)i + c] = pos[3 * src + c];
+        nrm_o[3 * (size_t)i + c] = nrm[3 * src + c];
+    }
+    for (int j = 0; j < k; ++j) {
+        nbr_o[(size_t)i * k + j] = nbr[src * k + j];
+        wts_o[(size_t)i * k + j] = wts[src * k + j];
+    }
+}
+
 // ------------------------------------------------------------------------------- association
 struct AssocParams {
     Mat3 K, Kinv;
@@ -1492,6 +1511,18 @@ int dfh_sample_knn(const double *sample_pos, int n_samples, const double *node_p
     DFH_REQUIRE(sample_pos && node_pos && node_w && nbr_out && weights_out, "dfh_sample_knn: null pointer");
     hipLaunchKernelGGL(sample_knn_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, (hipStream_t)stream, sample_pos,
                        n_samples, node_pos, node_w, n_nodes, knn, nbr_out, weights_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_permute_samples(const long *order, int n_samples, int knn, const double *pos, const double *nrm, const int *nbr,
+                        const double *weights, double *pos_out, double *nrm_out, int *nbr_out, double *weights_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_samples >= 0 && knn >= 1 && knn <= kKMaxS, "dfh_permute_samples: bad sizes");
+    if (n_samples == 0) return DFH_OK;
+    DFH_REQUIRE(order && pos && nrm && nbr && weights && pos_out && nrm_out && nbr_out && weights_out, "dfh_permute_samples: null pointer");
+    hipLaunchKernelGGL(permute_samples_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, (hipStream_t)stream, order, n_samples, knn, pos,
+                       nrm, nbr, weights, pos_out, nrm_out, nbr_out, weights_out);
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }

@@ -230,7 +230,7 @@ static int launch_rigid(void *tsdf, void *tsdf_w, const void *live, RigidParams 
 // K3: node search + DQ blending
 // ------------------------------------------------------------------------------------------
 constexpr int kBX = 4, kBY = 4, kBZ = 16;      // brick = one 256-thread block, z fastest (64-B rows)
-constexpr int kCap = 128;                       // candidate nodes kept per brick
+constexpr int kCap = 256;                       // candidate nodes kept per brick (<= 256: one per thread when staged)
 constexpr int kKMax = 8;                        // knn <= 8
 // half diagonal of the voxel-centre span of a brick
 #define DFH_BRICK_RADIUS 7.7942286340599480     /* sqrt(1.5^2 + 1.5^2 + 7.5^2) */

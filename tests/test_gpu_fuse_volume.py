@@ -150,15 +150,15 @@ def test_g4_dqb_golden(golden, vol_dtype):
     assert np.all(np.abs(fu._tsdf - g["T_after3"]) <= tol * (1 + np.abs(g["T_after3"])))
 
 
-@pytest.mark.parametrize("res,N,k", [((24, 20, 40), 60, 4), ((16, 16, 16), 9, 3), ((12, 28, 33), 300, 8), ((8, 8, 16), 5, 1)])
+@pytest.mark.parametrize("res,N,k", [((24, 20, 40), 60, 4), ((16, 16, 16), 9, 3), ((12, 28, 33), 420, 8), ((8, 8, 16), 5, 1)])
 def test_dqb_vs_oracle(res, N, k):
     """Random graphs, ragged grids, knn 1..8; includes bricks far from every node (large candidate
     radius) and N > candidate capacity (brute-force fallback inside the brick)."""
     rng = np.random.default_rng(N * 31 + k)
     tdist = 2.0
     node_pos = rng.uniform(0, np.array(res) - 1, size=(N, 3))
-    if N >= 100:                       # cluster: > kCap (128) candidates around one brick -> brute-force fallback
-        node_pos[:200] = np.array(res) / 2.0 + rng.normal(size=(200, 3)) * 1.5
+    if N >= 100:                       # cluster: > kCap (256) candidates around one brick -> brute-force fallback
+        node_pos[:320] = np.array(res) / 2.0 + rng.normal(size=(320, 3)) * 1.5
     node_dq = np.array([small_dq(rng, 0.08, 0.4, 1 + 0.02 * rng.normal()) for _ in range(N)])
     node_w = rng.uniform(2.0, 5.0, size=N)
     lw = small_dq(rng, 0.05, 0.3, 0.99)

@@ -41,7 +41,7 @@ kernels.fuse_volume_dqb(T, W, live, node_pos, node_dq, node_w, k, lw, tdist, wor
 P = torch.from_numpy(node_pos).cuda(); Q = torch.from_numpy(node_dq).cuda(); Wn = torch.from_numpy(node_w).cuda()
 ms_c = timeit(lambda: kernels.fuse_volume_dqb(T, W, live, P, Q, Wn, k, lw, tdist, workspace=ws, rebuild_candidates=True), 3)
 ms = timeit(lambda: kernels.fuse_volume_dqb(T, W, live, P, Q, Wn, k, lw, tdist, workspace=ws, rebuild_candidates=False), a.reps)
-cnt = ws.view(-1, 129)[:, 0]
+cnt = ws.view(-1, 257)[:, 0]          # kCap + 1 ints per brick (csrc/dfh_fuse_volume.hip)
 print("K3 dqb    %d^3, %d nodes: %8.1f us (+%.1f us candidate rebuild)  %8.0f Mvox/s  alg %.0f GB/s (%.1f%% of 8 TB/s)"
       % (R, N, ms * 1e3, (ms_c - ms) * 1e3, R ** 3 / ms / 1e3, alg / ms / 1e6, alg / ms / 1e6 / 80))
 print("   candidates per brick: mean %.1f max %d, overflow bricks %d of %d" % (float(cnt.clamp(min=0).float().mean()), int(cnt.max()), int((cnt < 0).sum()), cnt.numel()))

@@ -7,11 +7,16 @@ import torch
 from dynamicfusion_body_amd import scene
 from dynamicfusion_body_amd.pipeline import SlabFrame, extract_surface_samples
 from dynamicfusion_body_amd.solve import sample_knn
-R = 256
-H, W, fx, cx, cy = scene.CAMERAS["C2"]
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--res", type=int, default=256)
+ap.add_argument("--nodes", type=int, default=512)
+a = ap.parse_args()
+R = a.res
+H, W, fx, cx, cy = scene.CAMERAS["C2" if R <= 256 else "C5"]
 K = scene.intrinsics(fx, cx, cy)
 scale, center, tdist = scene.grid_params(R)
-node_pos, node_w = scene.fibonacci_nodes(512, R)
+node_pos, node_w = scene.fibonacci_nodes(a.nodes, R)
 sf = SlabFrame(K, scale, center, R, tdist / scale, node_pos, node_w, knn=4, pcg_iters=10, band=4.0)
 for ang in (0.0, 40.0, -40.0):
     lw = scene.view_extrinsic(ang)

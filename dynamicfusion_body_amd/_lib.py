@@ -49,6 +49,7 @@ _SIGNATURES = {
                                     _vp]),
     "dfh_pcg_workspace_bytes": (ctypes.c_size_t, [_int, _int]),
     "dfh_pcg_solve": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dfh_pcg_solve_update": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp, _dbl, _vp]),
     "dfh_apply_twist": (_int, [_vp, _vp, _int, _dbl, _vp]),
     "dfh_surface_workspace_bytes": (ctypes.c_size_t, [_c_int_p]),
     "dfh_surface_count": (_int, [_vp, _vp, _int, _c_int_p, _dbl, _vp, ctypes.c_size_t, _vp, _vp]),

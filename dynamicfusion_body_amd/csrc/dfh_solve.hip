@@ -1151,6 +1151,8 @@ __device__ __forceinline__ void st_agent(double *p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ void apply_twist_one(double *__restrict__ d, double ox, double oy, double oz, double vx, double vy, double vz);
+
 // ---- single-reduction PCG (Chronopoulos & Gear) -----------------------------------------------------------
 // A grid-wide reduction costs ~3 us across the eight XCDs (MI355X_MICROARCH.md, hand-off price list) and the
 // textbook recurrence needs two per iteration (p.Ap, then r.z).  This variant has ONE: with u = M^-1 r, w = A u,
@@ -1223,7 +1225,8 @@ template <int MAXT>
 __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col, double *vals,
                                                         const double *__restrict__ rhs, const PcgParams prm, int iters,
                                                         double *__restrict__ x, double *pub /* 2 x {u, v, t} x 6N */, double *part,
-                                                        unsigned *abort_flag) {
+                                                        unsigned *abort_flag, double *__restrict__ update_dq, double update_step) {
+    // update_dq != NULL: the row's wave also applies its twist, update_dq[a] <- exp(update_step * x_a) (x) update_dq[a]
     __shared__ BarrierLds2 lds;
     const int N = prm.N;
     const size_t N6 = 6 * (size_t)N;
@@ -1384,26 +1387,35 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
         alpha_prev = alpha;
     }
     if (lead) x[6 * a + lane] = ok ? xi : __builtin_nan("");
+    if (update_dq && ok) {
+        const double xs = update_step * xi;
+        const double t0 = __shfl(xs, 0, 64), t1 = __shfl(xs, 1, 64), t2 = __shfl(xs, 2, 64);
+        const double t3 = __shfl(xs, 3, 64), t4 = __shfl(xs, 4, 64), t5 = __shfl(xs, 5, 64);
+        if (row && lane == 0) apply_twist_one(update_dq + 8 * (size_t)a, t0, t1, t2, t3, t4, t5);
+    }
 }
 
 // dq_a <- exp(xi_a) (x) dq_a  (exp: rotation exp(omega), translation v; oracle/gn_np.py)
-__global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ node_dq, const double *__restrict__ xi, int N,
-                                                           double step) {
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= N) return;
-    const double ox = step * xi[6 * a], oy = step * xi[6 * a + 1], oz = step * xi[6 * a + 2];
-    const double vx = step * xi[6 * a + 3], vy = step * xi[6 * a + 4], vz = step * xi[6 * a + 5];
+// dq <- exp(step * xi) (x) dq for one node (exp: rotation exp(omega), translation v; oracle/gn_np.py)
+__device__ __forceinline__ void apply_twist_one(double *__restrict__ d, double ox, double oy, double oz, double vx, double vy, double vz) {
     const double th = sqrt(ox * ox + oy * oy + oz * oz);
     const double half = 0.5 * th;
     const double s = th < 1e-8 ? 0.5 - th * th / 48.0 : sin(half) / th;
     const Q4 q{cos(half), s * ox, s * oy, s * oz};
     const Q4 qe = qscale(qmul(qpure(vx, vy, vz), q), 0.5);
-    double *d = node_dq + 8 * a;
     const Q4 r{d[0], d[1], d[2], d[3]}, dd{d[4], d[5], d[6], d[7]};
     const Q4 nr = qmul(q, r);
     const Q4 nd = qadd(qmul(q, dd), qmul(qe, r));
     d[0] = nr.w; d[1] = nr.x; d[2] = nr.y; d[3] = nr.z;
     d[4] = nd.w; d[5] = nd.x; d[6] = nd.y; d[7] = nd.z;
+}
+
+__global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ node_dq, const double *__restrict__ xi, int N,
+                                                           double step) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= N) return;
+    apply_twist_one(node_dq + 8 * a, step * xi[6 * a], step * xi[6 * a + 1], step * xi[6 * a + 2], step * xi[6 * a + 3],
+                    step * xi[6 * a + 4], step * xi[6 * a + 5]);
 }
 
 }  // namespace dfh
@@ -1684,8 +1696,9 @@ size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
                              2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4));
 }
 
-int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
-                  double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, void *stream) {
+static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
+                          double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, double *update_dq,
+                          double update_step, void *stream) {
     using namespace dfh;
     DFH_REQUIRE(n_nodes >= 1 && iters >= 1, "dfh_pcg_solve: bad sizes");
     DFH_REQUIRE(row_ptr && col && vals && rhs && x_out && workspace, "dfh_pcg_solve: null pointer");
@@ -1720,10 +1733,10 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
         // Minv's 36 N doubles hold the two sets of published {u, v, t}
         if (wpb <= 8)
             hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
-                               flag);
+                               flag, update_dq, update_step);
         else
             hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
-                               flag);
+                               flag, update_dq, update_step);
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }
@@ -1738,8 +1751,23 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
         hipLaunchKernelGGL(pcg_update_xr_kernel, dim3((n_nodes + 39) / 40), block, 0, s, n_nodes, Minv, x_out, r, p_cur, Ap, z, sc);
         double *t = p_prev; p_prev = p_cur; p_cur = t;
     }
+    if (update_dq)
+        hipLaunchKernelGGL(apply_twist_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, update_dq, x_out, n_nodes, update_step);
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
+}
+
+int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
+                  double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, void *stream) {
+    return pcg_solve_impl(row_ptr, col, vals, rhs, n_nodes, iters, lm_abs, lm_rel, x_out, workspace, workspace_bytes, nullptr, 0.0, stream);
+}
+
+int dfh_pcg_solve_update(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
+                         double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, double *node_dq,
+                         double step, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(node_dq, "dfh_pcg_solve_update: null node_dq");
+    return pcg_solve_impl(row_ptr, col, vals, rhs, n_nodes, iters, lm_abs, lm_rel, x_out, workspace, workspace_bytes, node_dq, step, stream);
 }
 
 int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream) {

@@ -396,8 +396,10 @@ class WarpSolver:
     def step(self, lw_dq, rw, lm_abs=0.0, lm_rel=0.0):
         """One asynchronous GN iteration (no host synchronisation)."""
         self.build(lw_dq, rw)
-        self.solve_linear(lm_abs, lm_rel)
-        self.apply()
+        _lib.check(self.lib.dfh_pcg_solve_update(self.row_ptr.data_ptr(), self.col.data_ptr(), self.vals.data_ptr(), self.rhs.data_ptr(),
+                                                 self.N, self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(),
+                                                 self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, self.node_dq.data_ptr(), 1.0,
+                                                 current_stream_ptr()), "dfh_pcg_solve_update")
 
     def cost(self):
         """(0.5*|r|^2, valid sample count) of the last build (synchronises)."""

@@ -206,6 +206,12 @@ size_t dfh_pcg_workspace_bytes(int n_nodes, int iters);
 int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
                   double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* dfh_pcg_solve followed by dfh_apply_twist(node_dq, x_out, n_nodes, step) in the same launch where the persistent
+ * kernel runs (each row's wave updates its own node): one GN iteration's solve + update. */
+int dfh_pcg_solve_update(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
+                         double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, double *node_dq,
+                         double step, void *stream);
+
 /* node_dq[a] <- exp(step * xi[a]) (x) node_dq[a]; exp = rotation exp(omega), translation v. */
 int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream);
 

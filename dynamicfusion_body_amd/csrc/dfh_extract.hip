@@ -86,7 +86,10 @@ __global__ __launch_bounds__(1024) void surface_scan_kernel(int *__restrict__ bl
         block_count[b] = (int)run;            // capacity is checked by the host against the total
         run += c;
     }
-    if (t == 1023) *total_out = part[1023];
+    if (t == 1023) {
+        *total_out = part[1023];
+        block_count[nblocks] = (int)part[1023];          // sentinel: block b emits offset[b+1] - offset[b] samples
+    }
 }
 
 template <typename VolT>
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void surface_emit_kernel(const VolT *__restric
                                                             double *__restrict__ pos_out, double *__restrict__ nrm_out,
                                                             long capacity) {
     __shared__ int wave_cnt[4];
+    if (block_offset[blockIdx.x + 1] == block_offset[blockIdx.x]) return;       // nothing to emit: do not re-read the voxels
     const long v0 = (long)blockIdx.x * kExVox + threadIdx.x * 4;
     double pos[4][3], nrm[4][3];
     bool ok[4];
@@ -132,7 +136,7 @@ extern "C" {
 size_t dfh_surface_workspace_bytes(const int res[3]) {
     if (!res || res[0] <= 0 || res[1] <= 0 || res[2] <= 0) return 0;
     const long nvox = (long)res[0] * res[1] * res[2];
-    return sizeof(int) * (size_t)((nvox + dfh::kExVox - 1) / dfh::kExVox) + sizeof(long);
+    return sizeof(int) * (size_t)((nvox + dfh::kExVox - 1) / dfh::kExVox + 1) + sizeof(long);      // counts + sentinel
 }
 
 int dfh_surface_count(const void *tsdf, const void *tsdf_w, int vol_dtype, const int res[3], double band, void *workspace,

@@ -95,7 +95,7 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
     def one_solve():
         sv.node_dq.copy_(ident_t)
         for _ in range(iters):
-            fs.gn_iteration(depth, lw_cam, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0)
+            fs.gn_iteration(depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0)
 
     one_solve()                                   # warm-up (also builds the block pattern)
     barrier()
@@ -179,13 +179,14 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
         lw = scene.view_extrinsic(a)
         sf.integrate(torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda(), lw)
     sf.refresh_samples()
-    lw_cam = scene.view_extrinsic(0.0)
+    lws = [scene.view_extrinsic(a) for a in (0.0, 40.0, -40.0)]
+    lw_cam = lws
     nframes = 6
     depths = []
-    for f in range(nframes):                      # the sphere drifts and breathes a little every frame
+    for f in range(nframes):                      # the sphere drifts and breathes a little every frame; three views per frame
         off = np.array([0.10, -0.07, 0.05]) * (f + 1) * scale
-        depths.append(torch.from_numpy(scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=off,
-                                                          sphere_r=scene.SPHERE_R * (1.0 + 0.004 * (f + 1)))).cuda())
+        depths.append([torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0, sphere_offset=off,
+                                                           sphere_r=scene.SPHERE_R * (1.0 + 0.004 * (f + 1)))).cuda() for lw in lws])
     info = {"vertices": None, "faces": None}
 
     stages = {}
@@ -219,7 +220,7 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
             "mesh_faces": info["faces"], "final_cost": cost,
             "exchange": "none" if world == 1 else "per frame: all-gather of the live volume (%.0f MB) + face-plane halo; per GN "
                                                   "iteration: one all-reduce of the normal equations" % (R ** 3 * 4 / 1e6),
-            "workload": "%d^3 grid in %d axis-0 slab(s), %d nodes: live TSDF (1 view) + %d GN iterations + DQB TSDF update + "
+            "workload": "%d^3 grid in %d axis-0 slab(s), %d nodes: live TSDF (3 views) + %d GN iterations + DQB TSDF update + "
                         "sample refresh%s, per frame" % (R, world, N, iters, " + marching cubes" if world == 1 else "")}
 
 

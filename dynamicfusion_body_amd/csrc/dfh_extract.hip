@@ -41,9 +41,12 @@ __device__ __forceinline__ bool band_sample(const VolT *__restrict__ T, const Vo
     if (pos) {
         const double nx = gx / n, ny = gy / n, nz = gz / n;
         nrm[0] = nx; nrm[1] = ny; nrm[2] = nz;
-        pos[0] = (double)(x + p.x0) - t * nx;
-        pos[1] = (double)y - t * ny;
-        pos[2] = (double)z - t * nz;
+        // one Newton step onto the zero level set: centre - T grad / |grad|^2  (a projective TSDF has |grad| > 1 on
+        // surfaces oblique to the camera; stepping by T along the unit normal would overshoot there)
+        const double st = t / n;
+        pos[0] = (double)(x + p.x0) - st * nx;
+        pos[1] = (double)y - st * ny;
+        pos[2] = (double)z - st * nz;
     }
     return true;
 }

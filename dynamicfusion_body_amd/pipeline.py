@@ -43,7 +43,7 @@ def extract_surface_samples_torch(T, Wt, band, x0=0, max_samples=None):
     """Same samples on torch ops (works on CPU tensors).  Band voxels of a slab
     starting at global plane x0 -> (surface points (S,3) in global index space, unit normals).
     Normals are central differences of T inside the slab (one-sided at its faces); points are the
-    voxel centres projected onto the zero level set along the normal."""
+    voxel centres moved onto the zero level set by one Newton step, centre - T grad / |grad|^2."""
     Tf = T.to(torch.float64)
     mask = (Wt > 0) & (Tf.abs() < band)
     idx = mask.nonzero(as_tuple=False)
@@ -65,7 +65,7 @@ def extract_surface_samples_torch(T, Wt, band, x0=0, max_samples=None):
     n = g / nrm
     pos = idx.to(torch.float64)
     pos[:, 0] += x0
-    pos = pos - Tf[idx[:, 0], idx[:, 1], idx[:, 2]][:, None] * n
+    pos = pos - (Tf[idx[:, 0], idx[:, 1], idx[:, 2]][:, None] / nrm) * n          # one Newton step: T grad / |grad|^2
     return pos.contiguous(), n.contiguous()
 
 
@@ -156,8 +156,11 @@ class SlabFrame:
             Tp.append(hi[None]); Wp.append(torch.zeros_like(hi)[None])
         return self.fs.set_canonical(torch.cat(Tp).contiguous(), torch.cat(Wp).contiguous(), band=self.band, x0=x0)
 
-    def step(self, depth, lw_cam, gn_iters=10, rw=0.05, lm_abs=1e-2, lm_rel=1e-2, max_dist=4.0, stage_ms=None):
-        """stage_ms: optional dict; when given, the device is synchronised after every stage and the stage's wall
+    def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, stage_ms=None):
+        """Defaults (regulariser weight, LM damping, association gate in voxels) are the ones under which the loop tracks
+        a +-0.5 voxel oscillation of the bench scene for hundreds of frames without drift (tools/soak.py); with a 4-voxel
+        gate and weak damping, nodes without data support wander and the TSDF update then corrupts the canonical volume.
+        stage_ms: optional dict; when given, the device is synchronised after every stage and the stage's wall
         time (ms) is added under its name (for breakdowns only: the syncs cost throughput)."""
         import time as _t
         t0 = [_t.perf_counter()]
@@ -169,10 +172,18 @@ class SlabFrame:
                 stage_ms[name] = stage_ms.get(name, 0.0) + (now - t0[0]) * 1e3
                 t0[0] = now
         R = self.R
+        # `depth` / `lw_cam` may be lists: the live volume is then fused from all of them (as the reference's
+        # compute_live_tsdf does, core/fusion_dm.py:166-170); the warp solve associates against the first one
+        depth_list = list(depth) if isinstance(depth, (list, tuple)) else [depth]
+        lw_list = list(lw_cam) if isinstance(depth, (list, tuple)) else [lw_cam]
+        if len(depth_list) != len(lw_list):
+            raise ValueError('length of camera matrix array must equal that of depth maps')
+        depth, lw_cam = depth_list[0], lw_list[0]
         self.live.fill_(self.tvox)
         self.live_w.zero_()
-        kernels.integrate_depth(self.live, self.live_w, depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.tdist_world,
-                                tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b))
+        for d_, l_ in zip(depth_list, lw_list):
+            kernels.integrate_depth(self.live, self.live_w, d_, self.K, self.Kinv, l_, self.scale, self.center, self.tdist_world,
+                                    tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b))
         mark("live_tsdf")
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
         mark("allgather")

@@ -42,7 +42,8 @@ def view_extrinsic(angle_deg, centre=SPHERE_C):
 def render_depth(K, lw, H, W, invalid_frac=0.02, seed=1234, dtype=np.float64,
                  sphere_c=SPHERE_C, sphere_r=SPHERE_R, wall_z=WALL_Z, sphere_offset=None):
     """Analytic ray-sphere / ray-plane depth, stored negative; `invalid_frac` of the
-    pixels are zeroed with np.random.default_rng(seed)."""
+    pixels are zeroed with np.random.default_rng(seed).  wall_z=None: no back wall (pixels off the
+    sphere carry no measurement)."""
     Kinv = np.linalg.inv(K)
     v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
     d = np.stack([u, v, np.ones_like(u)], axis=-1) @ Kinv.T          # ray dirs, d_z == 1
@@ -56,11 +57,14 @@ def render_depth(K, lw, H, W, invalid_frac=0.02, seed=1234, dtype=np.float64,
     disc = dc * dc - dd * (cc @ cc - sphere_r * sphere_r)
     ts = np.where(disc >= 0, (dc - np.sqrt(np.maximum(disc, 0))) / dd, np.inf)
     ts = np.where(ts > 0, ts, np.inf)
-    n_c = R @ np.array([0.0, 0.0, 1.0])
-    p_c = R @ np.array([0.0, 0.0, wall_z]) + t
-    den = d @ n_c
-    tw = np.where(np.abs(den) > 1e-12, (n_c @ p_c) / np.where(np.abs(den) > 1e-12, den, 1.0), np.inf)
-    tw = np.where(tw > 0, tw, np.inf)
+    if wall_z is None:
+        tw = np.full_like(ts, np.inf)
+    else:
+        n_c = R @ np.array([0.0, 0.0, 1.0])
+        p_c = R @ np.array([0.0, 0.0, wall_z]) + t
+        den = d @ n_c
+        tw = np.where(np.abs(den) > 1e-12, (n_c @ p_c) / np.where(np.abs(den) > 1e-12, den, 1.0), np.inf)
+        tw = np.where(tw > 0, tw, np.inf)
     depth = np.minimum(ts, tw)
     depth = np.where(np.isfinite(depth), depth, 0.0)
     if invalid_frac > 0:

@@ -218,7 +218,7 @@ int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step,
 /* ---- surface samples for the solve (stand-in for marching cubes, core/fusion.py:554-568) -----------
  * Every band voxel (w > 0, |T| < band; T in voxel units as fuseDepths stores it) whose TSDF gradient
  * (central differences inside the slab, one-sided at its faces) is non-zero yields one sample: position
- * = voxel centre - T * n (global index space, plane 0 of the buffer is global plane x0), normal n =
+ * = voxel centre - T * gradient / |gradient|^2 (one Newton step; global index space, plane 0 of the buffer is global plane x0), normal n =
  * gradient / |gradient|.  Samples come out in voxel order, deterministically.
  *   dfh_surface_count : per-block counts + exclusive scan into `workspace`, *total_out (device) = count
  *   dfh_surface_emit  : writes min(total, capacity) samples (n x 3 fp64 each); uses the same workspace. */

@@ -89,13 +89,13 @@ class FrameSolver:
         self.solver.set_samples(pos, nrm)
         return pos.shape[0]
 
-    def gn_iteration(self, depth, lw_cam, rw, lm_abs=1e-3, lm_rel=1e-3, max_dist=4.0):
+    def gn_iteration(self, depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0):
         """associate -> build (+ all-reduce) -> PCG -> twist update; asynchronous."""
         sv = self.solver
         sv.associate_depth(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, max_dist)
         sv.step(self.lw, rw, lm_abs, lm_rel)
 
-    def solve(self, depth, lw_cam, rw, iters=10, **kw):
+    def solve(self, depth, lw_cam, rw=5.0, iters=10, **kw):
         costs = []
         for _ in range(iters):
             self.gn_iteration(depth, lw_cam, rw, **kw)

@@ -95,7 +95,7 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
     def one_solve():
         sv.node_dq.copy_(ident_t)
         for _ in range(iters):
-            fs.gn_iteration(depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0)
+            fs.gn_iteration(depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5)
 
     one_solve()                                   # warm-up (also builds the block pattern)
     barrier()

@@ -512,7 +512,8 @@ __device__ __forceinline__ int find_block(const int *__restrict__ row_ptr, const
 struct BuildParams {
     DQ lw;
     int S, k, N;
-};
+    double huber;             // > 0: IRLS weight min(1, huber / |r|) on the data rows (the reference's solver runs
+};                            //      least_squares(loss='huber'), f_scale 1: core/fusion.py:389); 0: plain least squares
 
 constexpr int kTile = 256;
 
@@ -631,9 +632,15 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
             idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
             w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
         }
-        const double r = data_row(node_dq, idx, w, K, p.lw.q, spos[3 * (size_t)s], spos[3 * (size_t)s + 1], spos[3 * (size_t)s + 2],
-                                  snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], corr[3 * (size_t)s],
-                                  corr[3 * (size_t)s + 1], corr[3 * (size_t)s + 2], Jrow);
+        double r = data_row(node_dq, idx, w, K, p.lw.q, spos[3 * (size_t)s], spos[3 * (size_t)s + 1], spos[3 * (size_t)s + 2],
+                            snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], corr[3 * (size_t)s],
+                            corr[3 * (size_t)s + 1], corr[3 * (size_t)s + 2], Jrow);
+        if (p.huber > 0.0 && fabs(r) > p.huber) {              // sqrt of the IRLS weight on the row and its residual
+            const double sc = sqrt(p.huber / fabs(r));
+            r *= sc;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) Jrow[j] *= sc;
+        }
 #pragma unroll
         for (int j = 0; j < K; ++j) sIdx[pos * K + j] = idx[j];
 #pragma unroll
@@ -1585,9 +1592,11 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
                          const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
                          double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
                          const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
-                         const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, void *stream) {
+                         const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                         void *stream) {
     using namespace dfh;
     const bool planned = blk_ptr != nullptr;
+    DFH_REQUIRE(huber_delta >= 0.0, "dfh_gn_build: negative huber_delta");
     const bool planned_reg = planned && partial_reg != nullptr;
     if (planned_reg) DFH_REQUIRE(rblk_ptr && rblk_ent && rnode_ptr && rnode_ent, "dfh_gn_build_planned: null regulariser plan array");
     DFH_REQUIRE(n_samples >= 0 && n_nodes >= 1 && n_blocks >= 1, "dfh_gn_build: bad sizes");
@@ -1615,7 +1624,7 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
         DFH_REQUIRE(sample_pos && sample_nrm && nbr && weights && corr && valid, "dfh_gn_build: null sample pointer");
         BuildParams p;
         for (int i = 0; i < 8; ++i) p.lw.q[i] = lw_dq[i];
-        p.S = n_samples; p.k = knn; p.N = n_nodes;
+        p.S = n_samples; p.k = knn; p.N = n_nodes; p.huber = huber_delta;
         dim3 grid((n_samples + kTile - 1) / kTile), block(256);
 #define DFH_BUILD(KK)                                                                                               \
     case KK:                                                                                                        \
@@ -1667,7 +1676,7 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
                  double *rhs, double *cost_count, void *stream) {
     return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr, valid, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
                          n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, nullptr, 0, nullptr, nullptr, nullptr,
-                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, stream);
 }
 
 size_t dfh_gn_partial_doubles(int knn) {
@@ -1681,12 +1690,13 @@ int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, con
                          const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
                          double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
                          const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
-                         const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, void *stream) {
+                         const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                         void *stream) {
     using namespace dfh;
     DFH_REQUIRE(blk_ptr, "dfh_gn_build_planned: null blk_ptr");
     return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr, valid, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
                          n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
-                         blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, stream);
+                         blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream);
 }
 
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {

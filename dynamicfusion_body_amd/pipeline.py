@@ -89,11 +89,11 @@ class FrameSolver:
         self.solver.set_samples(pos, nrm)
         return pos.shape[0]
 
-    def gn_iteration(self, depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0):
+    def gn_iteration(self, depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.0):
         """associate -> build (+ all-reduce) -> PCG -> twist update; asynchronous."""
         sv = self.solver
         sv.associate_depth(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, max_dist)
-        sv.step(self.lw, rw, lm_abs, lm_rel)
+        sv.step(self.lw, rw, lm_abs, lm_rel, huber)
 
     def solve(self, depth, lw_cam, rw=5.0, iters=10, **kw):
         costs = []
@@ -156,8 +156,8 @@ class SlabFrame:
             Tp.append(hi[None]); Wp.append(torch.zeros_like(hi)[None])
         return self.fs.set_canonical(torch.cat(Tp).contiguous(), torch.cat(Wp).contiguous(), band=self.band, x0=x0)
 
-    def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, stage_ms=None):
-        """Defaults (regulariser weight, LM damping, association gate in voxels) are the ones under which the loop tracks
+    def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5, stage_ms=None):
+        """Defaults (regulariser weight, LM damping, association gate and Huber threshold in voxels) are the ones under which the loop tracks
         a +-0.5 voxel oscillation of the bench scene for hundreds of frames without drift (tools/soak.py); with a 4-voxel
         gate and weak damping, nodes without data support wander and the TSDF update then corrupts the canonical volume.
         stage_ms: optional dict; when given, the device is synchronised after every stage and the stage's wall
@@ -188,7 +188,7 @@ class SlabFrame:
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
         mark("allgather")
         for _ in range(gn_iters):
-            self.fs.gn_iteration(depth, lw_cam, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist)
+            self.fs.gn_iteration(depth, lw_cam, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist, huber=huber)
         mark("solve")
         sv = self.fs.solver
         kernels.fuse_volume_dqb(self.T, self.Wt, live_full, sv.node_pos, sv.node_dq, sv.node_w, self.knn, self.ident_lw, self.tvox,

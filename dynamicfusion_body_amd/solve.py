@@ -354,7 +354,7 @@ class WarpSolver:
                                              current_stream_ptr()), "dfh_gn_associate")
 
     # -- iteration ---------------------------------------------------------------------------
-    def build(self, lw_dq, rw):
+    def build(self, lw_dq, rw, huber=0.0):
         """J^T J (block-sparse), J^T r and the cost 0.5*|computef|^2 at the current node DQs."""
         if self._pattern is None:
             self._build_pattern()
@@ -379,7 +379,7 @@ class WarpSolver:
                 self.node_ent.data_ptr(), *((self.partial_reg.data_ptr(), self.rblk_ptr.data_ptr(), self.rblk_ent.data_ptr(),
                                              self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
                                             if self.partial_reg is not None else (0, 0, 0, 0, 0)),
-                current_stream_ptr()), "dfh_gn_build_planned")
+                float(huber), current_stream_ptr()), "dfh_gn_build_planned")
         if self.distributed:
             _dist.allreduce_system(self.system)   # no-op on one GPU; samples are sharded by slab
 
@@ -393,9 +393,9 @@ class WarpSolver:
         _lib.check(self.lib.dfh_apply_twist(self.node_dq.data_ptr(), self.dx.data_ptr(), self.N, float(step),
                                             current_stream_ptr()), "dfh_apply_twist")
 
-    def step(self, lw_dq, rw, lm_abs=0.0, lm_rel=0.0):
-        """One asynchronous GN iteration (no host synchronisation)."""
-        self.build(lw_dq, rw)
+    def step(self, lw_dq, rw, lm_abs=0.0, lm_rel=0.0, huber=0.0):
+        """One asynchronous GN iteration (no host synchronisation).  huber > 0: Huber IRLS weights on the data rows."""
+        self.build(lw_dq, rw, huber)
         _lib.check(self.lib.dfh_pcg_solve_update(self.row_ptr.data_ptr(), self.col.data_ptr(), self.vals.data_ptr(), self.rhs.data_ptr(),
                                                  self.N, self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(),
                                                  self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, self.node_dq.data_ptr(), 1.0,

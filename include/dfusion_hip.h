@@ -190,7 +190,10 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
  * 64-byte lines; rows without a valid sample in this iteration are flagged dead and skipped); a gather pass adds them per block.
  * partial_reg (n_nodes * knn rows of dfh_gn_partial_doubles(2) doubles) + rblk_ptr / rblk_ent / rnode_ptr / rnode_ent: the same for the
  * regulariser, a pair (i, node_nbr[i*knn+slot]) being a 2-node row (entries row * 4 + sa * 2 + sb, row * 2 + slot);
- * partial_reg == NULL keeps the regulariser on atomics. */
+ * partial_reg == NULL keeps the regulariser on atomics.
+ * huber_delta > 0: every data row and its residual are scaled by sqrt(min(1, huber_delta / |r|)), the IRLS form of the
+ * Huber loss the reference's solver uses (least_squares(loss='huber'), core/fusion.py:389); cost_count[0] is then the
+ * weighted cost.  0 = plain least squares. */
 size_t dfh_gn_partial_doubles(int knn);
 int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
                          const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,
@@ -198,7 +201,8 @@ int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, con
                          const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
                          double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
                          const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
-                         const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, void *stream);
+                         const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                         void *stream);
 
 /* Block-Jacobi preconditioned CG on (A + lm_abs I + lm_rel diag(A)) x = -rhs, `iters` iterations, no
  * host synchronisation.  The damping is written into vals' diagonal (vals is consumed). */

@@ -189,6 +189,31 @@ def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, mon
     assert float((s1 - s0).abs().max()) > 0                               # the regulariser really contributes
 
 
+def test_huber_weights_vs_oracle(golden):
+    """huber > 0: every data row and its residual scaled by sqrt(min(1, huber / |r|)) -- the IRLS form of the loss the
+    reference's solver uses (least_squares(loss='huber'), core/fusion.py:389) -- against the oracle's J, r with the
+    same weights; huber = 0 is the plain system."""
+    g, verts, norms, corr, nbr, vidx, npos, ndq, nw, lw, rw = load(golden)
+    N = len(npos)
+    sv = make_solver(npos, ndq, nw, nbr, vidx, verts, norms, corr, nbr.shape[1])
+    r, J = G.data_residual_jacobian(ndq, verts, norms, corr, nbr, npos, nw, lw)
+    rho, nb, Ji, Jj = G.reg_residual_jacobian(ndq, vidx, nbr, npos, nw, rw)
+    delta = float(np.percentile(np.abs(r), 60))                       # 40 % of the rows are down-weighted
+    sc = np.sqrt(np.minimum(1.0, delta / np.maximum(np.abs(r), 1e-300)))
+    assert 0.2 < (sc < 1).mean() < 0.6
+    sv.build(lw, rw, huber=delta)
+    A, b = sv.dense_normal_equations()
+    cost, cnt = sv.cost()
+    Jw = J * sc.reshape((-1,) + (1,) * (J.ndim - 1))
+    Ao, bo, co = G.assemble_dense(N, r * sc, Jw, nbr, rho, nb, Ji, Jj)
+    assert abs(cost - co) <= 1e-12 * co and cnt == len(verts)
+    assert np.abs(A - Ao).max() <= 1e-10 * np.abs(Ao).max() and np.abs(b - bo).max() <= 1e-10 * np.abs(bo).max()
+    sv.build(lw, rw)
+    A0, b0 = sv.dense_normal_equations()
+    Ap, bp, _ = G.assemble_dense(N, r, J, nbr, rho, nb, Ji, Jj)
+    assert np.abs(A0 - Ap).max() <= 1e-10 * np.abs(Ap).max() and np.abs(A0 - A).max() > 1e-6 * np.abs(A0).max()
+
+
 def test_lm_loop_vs_oracle(golden):
     """Noise-free target from a known field, identity start: GPU LM costs follow the oracle's GN
     with the same damping schedule to 1e-6 relative; cost falls by > 100x."""

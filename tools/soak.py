@@ -25,7 +25,7 @@ depths = [[torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, in
 t0 = time.perf_counter()
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for f in range(frames):
-    sf.step(depths[f % 21], lws, gn_iters=10)
+    sf.step(depths[f % 21], lws, gn_iters=10, huber=float(os.environ.get('HUBER', '0.5')), max_dist=float(os.environ.get('GATE', '2')))
     if f % 50 == 49:
         dq = sf.fs.solver.node_dq
         assert torch.isfinite(dq).all(), "non-finite warp field at frame %d" % f

@@ -622,6 +622,8 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     }
     if (!PLANNED && tid == 0) atomicAdd(cost_count + 1, (double)n_valid);        // valid-sample count
     __shared__ int sRow[PLANNED ? kTile : 1];                        // partial row of every compacted sample
+    __shared__ double sObj[4];
+    double obj = 0.0;
     if (act) {
         if (PLANNED) sRow[pos] = run_id[s];
         double Jrow[NJ];
@@ -635,7 +637,9 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         double r = data_row(node_dq, idx, w, K, p.lw.q, spos[3 * (size_t)s], spos[3 * (size_t)s + 1], spos[3 * (size_t)s + 2],
                             snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], corr[3 * (size_t)s],
                             corr[3 * (size_t)s + 1], corr[3 * (size_t)s + 2], Jrow);
-        if (p.huber > 0.0 && fabs(r) > p.huber) {              // sqrt of the IRLS weight on the row and its residual
+        obj = 0.5 * r * r;                                     // this sample's term of the objective
+        if (p.huber > 0.0 && fabs(r) > p.huber) {              // Huber: rho = delta (|r| - delta / 2) beyond delta, and the
+            obj = p.huber * (fabs(r) - 0.5 * p.huber);         // row and its residual get sqrt of the IRLS weight
             const double sc = sqrt(p.huber / fabs(r));
             r *= sc;
 #pragma unroll
@@ -647,7 +651,16 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         for (int j = 0; j < NJ; ++j) sJ[pos * LD + j] = Jrow[j];
         sJ[pos * LD + NJ] = r;
     }
+    if (PLANNED) {                                                   // the tile's objective, added in a fixed order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) obj += __shfl_xor(obj, o, 64);
+        if (lane == 0) sObj[wv] = obj;
+    }
     __syncthreads();
+    if (PLANNED && tid == 0) {
+        tile_cost[2 * blockIdx.x] = ((sObj[0] + sObj[1]) + sObj[2]) + sObj[3];
+        tile_cost[2 * blockIdx.x + 1] = (double)n_valid;
+    }
     // run boundaries: sRun[0..n_runs] are the offsets in the compacted list where the node tuple changes
     __shared__ int sRun[kTile + 1];
     __shared__ int sNRuns;
@@ -710,7 +723,6 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         } else {
             pa = NJ; pb = NJ;
         }
-        double tile_sum = 0.0;                       // (used by the thread that owns the cost entry)
         for (int rn = 0; rn < n_runs; ++rn) {
             const int t0 = sRun[rn], t1 = sRun[rn + 1];
             // four independent chains: the loop is bound by LDS latency, not bandwidth (fixed association order)
@@ -727,7 +739,6 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
             const double acc = (acc0 + acc1) + (acc2 + acc3);
             if (PLANNED) {
                 partial[(size_t)sRow[t0] * ST_ + e] = pa == NJ ? 0.5 * acc : acc;
-                if (pa == NJ) tile_sum += 0.5 * acc;
                 continue;
             }
             if (acc == 0.0) continue;
@@ -747,7 +758,6 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
                 }
             }
         }
-        if (PLANNED && pa == NJ && pb == NJ) { tile_cost[2 * blockIdx.x] = tile_sum; tile_cost[2 * blockIdx.x + 1] = (double)n_valid; }
     }
 }
 

@@ -263,11 +263,12 @@ class Fusion:
                     self._nodes[i] = (int(vidx), nd[1], nd[2], 2 * self._radius)
 
     def solve(self, correspondences=None, method='cnn', precompute_lw=True, tukey_data_weight=0.2,
-              huber_regularization_weight=0.001, regularization_weight=1, iterations=10, pcg_iters=30):
+              huber_regularization_weight=0.001, regularization_weight=1, iterations=10, pcg_iters=30, huber_delta=1.0):
         """Estimate the warp field {dg_SE3} for the current correspondences; call surface of
         reference core/fusion.py:327-412.  The reference hands `computef` to scipy's trust-region
         solver with finite-difference Jacobians; here the same cost 0.5*|computef|^2 is minimised
-        by Levenberg-Marquardt on 6-DoF twists with analytic Jacobians (HIP kernels).  Kept from
+        by Levenberg-Marquardt on 6-DoF twists with analytic Jacobians (HIP kernels), under the Huber loss the
+        reference passes to scipy (`loss='huber'`, f_scale 1 -> huber_delta = 1, data rows; :389).  Kept from
         the reference: the optional global `_lw` pre-fit on `computef_lw` (:350-364) and the /8
         relaxation of `regularization_weight` while the cost reduction stays in (5 %, 90 %)
         (:405-412), and -- with method='clpts' and no explicit correspondences -- the re-association against
@@ -303,7 +304,8 @@ class Fusion:
                 self._write_back(sv)
                 self.setupCorrespondences(self._curr_tsdf, method='clpts')       # :370-371
                 sv = make_solver()
-            costs = sv.solve_lm(np.asarray(self._lw, dtype=np.float64), regularization_weight, iters=iterations, lm_abs=1e-3)
+            costs = sv.solve_lm(np.asarray(self._lw, dtype=np.float64), regularization_weight, iters=iterations, lm_abs=1e-3,
+                                huber=huber_delta)
             self.last_costs.append(costs)
             cost_before, cost_after = costs[0], costs[-1]
             reduct_rate = (cost_before - cost_after) / cost_before if cost_before > 0 else 0.0

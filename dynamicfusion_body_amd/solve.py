@@ -414,12 +414,13 @@ class WarpSolver:
         A[rows, self.col.long()] = self.vals.view(self.B, 6, 6)
         return A.permute(0, 2, 1, 3).reshape(6 * N, 6 * N).cpu().numpy(), self.rhs.cpu().numpy()
 
-    def solve_lm(self, lw_dq, rw, iters=10, lm_abs=1e-6, lm_rel=0.0, adaptive=True):
+    def solve_lm(self, lw_dq, rw, iters=10, lm_abs=1e-6, lm_rel=0.0, adaptive=True, huber=0.0):
         """Levenberg-Marquardt loop.  A step that raises the cost is undone and retried with 10x
         the damping; an accepted step relaxes the damping by 3x.  Returns the costs
-        [initial, after step 1, ...] (0.5*|computef|^2 over valid rows)."""
+        [initial, after step 1, ...] (0.5*|computef|^2 over valid rows; with huber > 0 the Huber objective of the data
+        rows, minimised by iteratively re-weighted steps)."""
         lam_a, lam_r = float(lm_abs), float(lm_rel)
-        self.build(lw_dq, rw)
+        self.build(lw_dq, rw, huber)
         c_cur, _ = self.cost()
         costs = [c_cur]
         for _ in range(iters):
@@ -431,7 +432,7 @@ class WarpSolver:
                 self.rhs.copy_(saved_rhs)
                 self.solve_linear(lam_a, lam_r)
                 self.apply()
-                self.build(lw_dq, rw)                   # cost at the trial point = next iteration's system
+                self.build(lw_dq, rw, huber)                   # cost at the trial point = next iteration's system
                 c_new, _ = self.cost()
                 if not adaptive or c_new <= c_cur * (1 + 1e-12):
                     accepted = True
@@ -439,7 +440,7 @@ class WarpSolver:
                 self.node_dq.copy_(saved_dq)
                 lam_a, lam_r = max(lam_a, 1e-9) * 10.0, max(lam_r, 1e-6) * 10.0
             if not accepted:
-                self.build(lw_dq, rw)
+                self.build(lw_dq, rw, huber)
                 break
             c_cur = c_new
             costs.append(c_cur)

@@ -193,7 +193,8 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
  * partial_reg == NULL keeps the regulariser on atomics.
  * huber_delta > 0: every data row and its residual are scaled by sqrt(min(1, huber_delta / |r|)), the IRLS form of the
  * Huber loss the reference's solver uses (least_squares(loss='huber'), core/fusion.py:389); cost_count[0] is then the
- * weighted cost.  0 = plain least squares. */
+ * Huber objective sum rho(r), rho = r^2 / 2 up to huber_delta and huber_delta (|r| - huber_delta / 2) beyond, plus the
+ * regulariser's 0.5 |rho|^2.  0 = plain least squares. */
 size_t dfh_gn_partial_doubles(int knn);
 int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
                          const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,

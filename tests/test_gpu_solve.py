@@ -206,7 +206,9 @@ def test_huber_weights_vs_oracle(golden):
     cost, cnt = sv.cost()
     Jw = J * sc.reshape((-1,) + (1,) * (J.ndim - 1))
     Ao, bo, co = G.assemble_dense(N, r * sc, Jw, nbr, rho, nb, Ji, Jj)
-    assert abs(cost - co) <= 1e-12 * co and cnt == len(verts)
+    a_ = np.abs(r)
+    huber_obj = float(np.where(a_ <= delta, 0.5 * r * r, delta * (a_ - 0.5 * delta)).sum() + 0.5 * float((rho * rho).sum()))
+    assert abs(cost - huber_obj) <= 1e-12 * huber_obj and cnt == len(verts)           # the Huber objective, not the IRLS-weighted one
     assert np.abs(A - Ao).max() <= 1e-10 * np.abs(Ao).max() and np.abs(b - bo).max() <= 1e-10 * np.abs(bo).max()
     sv.build(lw, rw)
     A0, b0 = sv.dense_normal_equations()

@@ -388,13 +388,19 @@ __device__ __forceinline__ D3 dqb_blend_warp(const double *__restrict__ node_dq,
     return dqb_warp_exact(lw, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));   // :512
 }
 
-template <typename VolT, typename LiveT, int KS>
+// MODE 0: search the brick's candidates; 1: search and store the k indices per voxel; 2: load the stored indices.
+// The k nearest nodes of a voxel centre depend on the node positions only, which stay put while the graph is
+// unchanged (only node_dq moves from frame to frame), so every frame after the first skips the search: 2*k bytes
+// per voxel read instead of the LDS-staged scan.  Distances are recomputed from the indices with the same
+// expression, so the result is bit-identical to the search path.
+template <typename VolT, typename LiveT, int KS, int MODE>
 __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__ tsdf, VolT *__restrict__ tsdf_w,
                                                                const LiveT *__restrict__ live,
                                                                const double *__restrict__ node_pos,
                                                                const double *__restrict__ node_dq,
                                                                const double *__restrict__ node_w,
-                                                               const int *__restrict__ cand, const DqbParams p) {
+                                                               const int *__restrict__ cand,
+                                                               unsigned short *__restrict__ knn_cache, const DqbParams p) {
     const long brick = blockIdx.x;
     const int bz = (int)(brick % p.nbz);
     const int by = (int)((brick / p.nbz) % p.nby);
@@ -405,16 +411,47 @@ __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__
     const int xl = bx * kBX + lx, y = by * kBY + ly, z = bz * kBZ + lz;
     const bool inb = (xl < p.nx) && (y < p.Y) && (z < p.Z);
     const double px = (double)(p.x0 + xl), py = (double)y, pz = (double)z;
+    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z;
     double bd[KS];
     int bi[KS];
-    block_knn<KS>(node_pos, cand + brick * (kCap + 1), p.N, px, py, pz, inb, bd, bi);
-    if (!inb) return;
+    if (MODE == 2) {
+        if (!inb) return;
+        unsigned short id[KS];
+        if (KS == 4 && p.k == 4) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(knn_cache + off * 4);
+            id[0] = (unsigned short)(v.x & 0xffffu); id[1] = (unsigned short)(v.x >> 16);
+            id[2] = (unsigned short)(v.y & 0xffffu); id[3] = (unsigned short)(v.y >> 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) id[j] = j < p.k ? knn_cache[off * p.k + j] : (unsigned short)0;
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const int gi = min((int)id[j], p.N - 1);          // a stale or foreign workspace must not fault
+            const double dx = px - node_pos[3 * gi], dy = py - node_pos[3 * gi + 1], dz = pz - node_pos[3 * gi + 2];
+            bd[j] = (dx * dx + dy * dy) + dz * dz;
+            bi[j] = gi;
+        }
+    } else {
+        block_knn<KS>(node_pos, cand + brick * (kCap + 1), p.N, px, py, pz, inb, bd, bi);
+        if (!inb) return;
+        if (MODE == 1) {
+            if (KS == 4 && p.k == 4) {
+                uint2 v;
+                v.x = (unsigned)bi[0] | ((unsigned)bi[1] << 16);
+                v.y = (unsigned)bi[2] | ((unsigned)bi[3] << 16);
+                *reinterpret_cast<uint2 *>(knn_cache + off * 4) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < KS; ++j) if (j < p.k) knn_cache[off * p.k + j] = (unsigned short)bi[j];
+            }
+        }
+    }
     double wi;
     const D3 q = dqb_blend_warp<KS>(node_dq, node_w, bd, bi, p.k, p.lw.q, px, py, pz, &wi, nullptr);   // fusion.py:178
     double s;
     if (!interpolate_exact(live, p.LX, p.LY, p.LZ, q.x, q.y, q.z, s)) return;
     if (!(s > -1.0 * p.tdist)) return;                                                              // :179
-    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z;
     double wt = (double)tsdf_w[off];
     if (wt == 0.0) wt = wi;                                                                         // :186-187
     const double m = s < p.tdist ? s : p.tdist;
@@ -425,17 +462,26 @@ __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__
 
 template <typename VolT, typename LiveT>
 static int launch_dqb(void *tsdf, void *tsdf_w, const void *live, const double *node_pos, const double *node_dq,
-                      const double *node_w, int *cand, const DqbParams &p, hipStream_t s) {
+                      const double *node_w, int *cand, unsigned short *knn_cache, int mode, const DqbParams &p, hipStream_t s) {
     const long nbricks = (long)p.nbx * p.nby * p.nbz;
+#define DFH_K3(KS, MODE) hipLaunchKernelGGL((fuse_volume_dqb_kernel<VolT, LiveT, KS, MODE>), dim3((unsigned)nbricks), dim3(256), 0, s, \
+                                            (VolT *)tsdf, (VolT *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, knn_cache, p)
     if (p.k <= 4) {                                   // 4 register slots suffice: half the insertion work
-        hipLaunchKernelGGL((fuse_volume_dqb_kernel<VolT, LiveT, 4>), dim3((unsigned)nbricks), dim3(256), 0, s, (VolT *)tsdf,
-                           (VolT *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, p);
+        if (mode == 0) DFH_K3(4, 0); else if (mode == 1) DFH_K3(4, 1); else DFH_K3(4, 2);
     } else {
-        hipLaunchKernelGGL((fuse_volume_dqb_kernel<VolT, LiveT, kKMax>), dim3((unsigned)nbricks), dim3(256), 0, s, (VolT *)tsdf,
-                           (VolT *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, p);
+        if (mode == 0) DFH_K3(kKMax, 0); else if (mode == 1) DFH_K3(kKMax, 1); else DFH_K3(kKMax, 2);
     }
+#undef DFH_K3
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
+}
+
+static size_t cand_bytes(const int res[3], int x0, int x1) {
+    int nbx, nby, nbz;
+    nbx = (x1 - x0 + kBX - 1) / kBX;
+    nby = (res[1] + kBY - 1) / kBY;
+    nbz = (res[2] + kBZ - 1) / kBZ;
+    return (((size_t)nbx * nby * nbz * (kCap + 1) * sizeof(int)) + 15) & ~(size_t)15;
 }
 
 static void brick_counts(const int res[3], int x0, int x1, int &nbx, int &nby, int &nbz) {
@@ -494,9 +540,14 @@ extern "C" int dfh_fuse_volume_rigid(void *tsdf, void *tsdf_w, int vol_dtype, co
 
 extern "C" size_t dfh_dqb_workspace_bytes(const int res[3], int x0, int x1) {
     if (!res || x1 <= x0) return 0;
-    int nbx, nby, nbz;
-    dfh::brick_counts(res, x0, x1, nbx, nby, nbz);
-    return (size_t)nbx * nby * nbz * (dfh::kCap + 1) * sizeof(int);
+    return dfh::cand_bytes(res, x0, x1);
+}
+
+extern "C" size_t dfh_dqb_workspace_bytes_cached(const int res[3], int x0, int x1, int knn, int n_nodes) {
+    if (!res || x1 <= x0) return 0;
+    const size_t base = dfh::cand_bytes(res, x0, x1);
+    if (knn < 1 || knn > dfh::kKMax || n_nodes > 65536) return base;         // indices are kept as 16-bit
+    return base + (size_t)(x1 - x0) * res[1] * res[2] * knn * sizeof(unsigned short);
 }
 
 extern "C" int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int x0, int x1,
@@ -528,14 +579,19 @@ extern "C" int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, cons
     DFH_REQUIRE(nbricks < (1L << 31), "dfh_fuse_volume_dqb: too many bricks");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int *cand = static_cast<int *>(workspace);
+    // a workspace of dfh_dqb_workspace_bytes_cached() also keeps every voxel's k node indices
+    const size_t cached = dfh_dqb_workspace_bytes_cached(res, x0, x1, knn, n_nodes);
+    const bool has_cache = cached > cand_bytes(res, x0, x1) && workspace_bytes >= cached && !getenv("DFH_K3_NO_CACHE");
+    unsigned short *knn_cache = has_cache ? reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + cand_bytes(res, x0, x1)) : nullptr;
+    const int mode = !has_cache ? 0 : (rebuild_candidates ? 1 : 2);
     if (rebuild_candidates) {
         hipLaunchKernelGGL(dqb_candidates_kernel, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, s, node_pos, cand, p);
         DFH_HIP_CHECK(hipGetLastError());
     }
     if (vol_dtype == DFH_F32) {
-        if (live_dtype == DFH_F32) return launch_dqb<float, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, p, s);
-        return launch_dqb<float, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, p, s);
+        if (live_dtype == DFH_F32) return launch_dqb<float, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, mode, p, s);
+        return launch_dqb<float, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, mode, p, s);
     }
-    if (live_dtype == DFH_F32) return launch_dqb<double, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, p, s);
-    return launch_dqb<double, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, p, s);
+    if (live_dtype == DFH_F32) return launch_dqb<double, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, mode, p, s);
+    return launch_dqb<double, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, mode, p, s);
 }

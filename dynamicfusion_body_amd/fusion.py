@@ -127,7 +127,7 @@ class Fusion:
         key = (res, pos.tobytes(), self._knn)
         rebuild = key != self._workspace_key
         if rebuild:
-            self._workspace = kernels.dqb_workspace(res)
+            self._workspace = kernels.dqb_workspace(res, knn=self._knn, n_nodes=len(pos))
             self._workspace_key = key
         kernels.fuse_volume_dqb(self._T, self._Wt, live, pos, dq, w, self._knn,
                                 np.asarray(self._lw, dtype=np.float64), self._tdist, wmax,

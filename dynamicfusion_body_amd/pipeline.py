@@ -132,7 +132,7 @@ class SlabFrame:
         N = len(node_pos)
         ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
         self.fs.set_graph(node_pos, ident, node_w)
-        self.ws_dqb = kernels.dqb_workspace((R, R, R), (self.a, self.b))
+        self.ws_dqb = kernels.dqb_workspace((R, R, R), (self.a, self.b), knn=knn, n_nodes=N)
         self._first = True
         self.ident_lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
 

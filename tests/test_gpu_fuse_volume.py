@@ -183,6 +183,21 @@ def test_dqb_vs_oracle(res, N, k):
                                     res=res, x_range=(a, b), workspace=ws, rebuild_candidates=rebuild)
         T2[a:b] = Ts; W2[a:b] = Ws
     assert torch.equal(T2, T) and torch.equal(W2, W)
+    # workspace that also keeps the voxels' node indices: the call after the rebuild skips the search and must give
+    # the same bits -- also when the node DQs changed in between (the nearest nodes do not depend on them)
+    T3, W3 = dev(T0, torch.float64), dev(W0, torch.float64)
+    other_dq = np.array([small_dq(rng, 0.05, 0.2, 1.0) for _ in range(N)])
+    for a, b in ((0, 5), (5, res[0])):
+        ws = kernels.dqb_workspace(res, (a, b), knn=k, n_nodes=N)
+        assert ws.numel() * 4 >= kernels.dqb_workspace(res, (a, b)).numel() * 4 + (b - a) * res[1] * res[2] * k * 2
+        Ts, Ws = dev(T0[a:b], torch.float64), dev(W0[a:b], torch.float64)
+        kernels.fuse_volume_dqb(Ts, Ws, dev(live, torch.float64), node_pos, other_dq, node_w, k, lw, tdist, 7.0,
+                                res=res, x_range=(a, b), workspace=ws, rebuild_candidates=True)
+        Ts, Ws = dev(T0[a:b], torch.float64), dev(W0[a:b], torch.float64)
+        kernels.fuse_volume_dqb(Ts, Ws, dev(live, torch.float64), node_pos, node_dq, node_w, k, lw, tdist, 7.0,
+                                res=res, x_range=(a, b), workspace=ws, rebuild_candidates=False)
+        T3[a:b] = Ts; W3[a:b] = Ws
+    assert torch.equal(T3, T) and torch.equal(W3, W)
 
 
 def test_dqb_zero_blend_and_errors():

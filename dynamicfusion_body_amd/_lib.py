@@ -29,7 +29,7 @@ _SIGNATURES = {
     "dfh_fuse_volume_rigid": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _vp, _int, _c_int_p,
                                      _c_double_p, _dbl, _dbl, _vp]),
     "dfh_dqb_workspace_bytes": (ctypes.c_size_t, [_c_int_p, _int, _int]),
-    "dfh_dqb_workspace_bytes_cached": (ctypes.c_size_t, [_c_int_p, _int, _int, _int, _int]),
+    "dfh_dqb_workspace_bytes_cached": (ctypes.c_size_t, [_c_int_p, _int, _int, _int, _int, _int]),
     "dfh_fuse_volume_dqb": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _vp, _int, _c_int_p, _vp, _vp, _vp, _int,
                                    _int, _c_double_p, _dbl, _dbl, _vp, ctypes.c_size_t, _int, _vp]),
     "dfh_residual_rigid": (_int, [_vp, _vp, _vp, _int, _c_double_p, _vp, _vp]),

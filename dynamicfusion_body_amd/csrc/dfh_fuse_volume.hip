@@ -348,22 +348,31 @@ __device__ __forceinline__ void block_knn(const double *__restrict__ node_pos, c
 // (bd, bi).  Returns the point warped by the blended DQ and then by m_lw (x1 is re-rounded to
 // float32 inside the second dqb_warp, core/util.py:69); *wi_out = mean node distance (:180-183).
 template <int KS>
-__device__ __forceinline__ D3 dqb_blend_warp(const double *__restrict__ node_dq, const double *__restrict__ node_w,
-                                             const double (&bd)[KS], const int (&bi)[KS], int k,
-                                             const double *lw, double px, double py, double pz, double *wi_out,
-                                             double *blended /* 8, optional */) {
+__device__ __forceinline__ void dqb_weights(const double *__restrict__ node_w, const double (&bd)[KS], const int (&bi)[KS], int k,
+                                            double (&wg)[KS], double &wi) {
+    wi = 0.0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        wg[j] = 0.0;
+        if (j < k) {
+            const double dist = sqrt(bd[j]);
+            const double t = dist / (2.0 * node_w[bi[j]]);
+            wg[j] = exp(-1.0 * (t * t));                                 // :537
+            wi = wi + dist / (double)k;                                  // mean node distance (:180-183)
+        }
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ D3 dqb_blend_warp(const double *__restrict__ node_dq, const double (&wg)[KS], const int (&bi)[KS], int k,
+                                             const double *lw, double px, double py, double pz) {
     double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double wi = 0.0;
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
         if (j < k) {
             const int gi = bi[j];
-            const double dist = sqrt(bd[j]);
-            const double t = dist / (2.0 * node_w[gi]);
-            const double wgt = exp(-1.0 * (t * t));                      // :537
 #pragma unroll
-            for (int c = 0; c < 8; ++c) b[c] = b[c] + wgt * node_dq[8 * gi + c];   // :538
-            wi = wi + dist / (double)k;
+            for (int c = 0; c < 8; ++c) b[c] = b[c] + wg[j] * node_dq[8 * gi + c];   // :538
         }
     }
     // 8-norm (:551), pairwise like numpy's reduction of 8 contiguous values
@@ -379,20 +388,17 @@ __device__ __forceinline__ D3 dqb_blend_warp(const double *__restrict__ node_dq,
 #pragma unroll
         for (int c = 0; c < 8; ++c) b[c] = b[c] * inv;
     }
-    if (blended) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) blended[c] = b[c];
-    }
     const D3 x1 = dqb_warp_exact(b, px, py, pz);                          // :510
-    *wi_out = wi;
     return dqb_warp_exact(lw, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));   // :512
 }
 
-// MODE 0: search the brick's candidates; 1: search and store the k indices per voxel; 2: load the stored indices.
-// The k nearest nodes of a voxel centre depend on the node positions only, which stay put while the graph is
-// unchanged (only node_dq moves from frame to frame), so every frame after the first skips the search: 2*k bytes
-// per voxel read instead of the LDS-staged scan.  Distances are recomputed from the indices with the same
-// expression, so the result is bit-identical to the search path.
+// MODE 0: search the brick's candidates; 1: search and store per voxel the k indices (and, with a weight cache, the
+// k blend weights and the integration weight wi); 2: load the stored indices; 3: load indices and weights.
+// The k nearest nodes of a voxel centre, their distances and hence the blend weights depend on the node positions
+// and radii only, which stay put while the graph is unchanged (only node_dq moves from frame to frame), so every
+// frame after the first skips the search (mode 2: 2*k bytes per voxel read instead of the LDS-staged scan) and the
+// sqrt / divide / exp chain (mode 3: another 8*(k+1) bytes).  Stored values are the ones the search path computes,
+// so the result is bit-identical.
 template <typename VolT, typename LiveT, int KS, int MODE>
 __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__ tsdf, VolT *__restrict__ tsdf_w,
                                                                const LiveT *__restrict__ live,
@@ -400,21 +406,35 @@ __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__
                                                                const double *__restrict__ node_dq,
                                                                const double *__restrict__ node_w,
                                                                const int *__restrict__ cand,
-                                                               unsigned short *__restrict__ knn_cache, const DqbParams p) {
+                                                               unsigned short *__restrict__ knn_cache,
+                                                               double *__restrict__ w_cache, const DqbParams p) {
+    const size_t nvox = (size_t)p.nx * p.Y * p.Z;
     const long brick = blockIdx.x;
-    const int bz = (int)(brick % p.nbz);
-    const int by = (int)((brick / p.nbz) % p.nby);
-    const int bx = (int)(brick / ((long)p.nbz * p.nby));
-    const int lz = threadIdx.x & (kBZ - 1);
-    const int ly = (threadIdx.x >> 4) & (kBY - 1);
-    const int lx = threadIdx.x >> 6;
-    const int xl = bx * kBX + lx, y = by * kBY + ly, z = bz * kBZ + lz;
-    const bool inb = (xl < p.nx) && (y < p.Y) && (z < p.Z);
+    int xl, y, z;
+    bool inb;
+    if (MODE >= 2) {            // no search, no bricks: threads run along z (whole 128-B lines of every per-voxel array)
+        const size_t lin = (size_t)blockIdx.x * 256 + threadIdx.x;
+        inb = lin < nvox;
+        z = (int)(lin % (size_t)p.Z);
+        y = (int)((lin / (size_t)p.Z) % (size_t)p.Y);
+        xl = (int)(lin / ((size_t)p.Z * p.Y));
+    } else {
+        const int bz = (int)(brick % p.nbz);
+        const int by = (int)((brick / p.nbz) % p.nby);
+        const int bx = (int)(brick / ((long)p.nbz * p.nby));
+        const int lz = threadIdx.x & (kBZ - 1);
+        const int ly = (threadIdx.x >> 4) & (kBY - 1);
+        const int lx = threadIdx.x >> 6;
+        xl = bx * kBX + lx; y = by * kBY + ly; z = bz * kBZ + lz;
+        inb = (xl < p.nx) && (y < p.Y) && (z < p.Z);
+    }
     const double px = (double)(p.x0 + xl), py = (double)y, pz = (double)z;
     const size_t off = ((size_t)xl * p.Y + y) * p.Z + z;
     double bd[KS];
     int bi[KS];
-    if (MODE == 2) {
+    double wg[KS];
+    double wi;
+    if (MODE >= 2) {
         if (!inb) return;
         unsigned short id[KS];
         if (KS == 4 && p.k == 4) {
@@ -426,11 +446,19 @@ __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__
             for (int j = 0; j < KS; ++j) id[j] = j < p.k ? knn_cache[off * p.k + j] : (unsigned short)0;
         }
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            const int gi = min((int)id[j], p.N - 1);          // a stale or foreign workspace must not fault
-            const double dx = px - node_pos[3 * gi], dy = py - node_pos[3 * gi + 1], dz = pz - node_pos[3 * gi + 2];
-            bd[j] = (dx * dx + dy * dy) + dz * dz;
-            bi[j] = gi;
+        for (int j = 0; j < KS; ++j) bi[j] = min((int)id[j], p.N - 1);          // a stale or foreign workspace must not fault
+        if (MODE == 3) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) wg[j] = j < p.k ? w_cache[(size_t)j * nvox + off] : 0.0;
+            wi = w_cache[(size_t)p.k * nvox + off];
+        } else {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const int gi = bi[j];
+                const double dx = px - node_pos[3 * gi], dy = py - node_pos[3 * gi + 1], dz = pz - node_pos[3 * gi + 2];
+                bd[j] = (dx * dx + dy * dy) + dz * dz;
+            }
+            dqb_weights<KS>(node_w, bd, bi, p.k, wg, wi);
         }
     } else {
         block_knn<KS>(node_pos, cand + brick * (kCap + 1), p.N, px, py, pz, inb, bd, bi);
@@ -446,9 +474,14 @@ __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__
                 for (int j = 0; j < KS; ++j) if (j < p.k) knn_cache[off * p.k + j] = (unsigned short)bi[j];
             }
         }
+        dqb_weights<KS>(node_w, bd, bi, p.k, wg, wi);
+        if (MODE == 1 && w_cache) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) if (j < p.k) w_cache[(size_t)j * nvox + off] = wg[j];
+            w_cache[(size_t)p.k * nvox + off] = wi;
+        }
     }
-    double wi;
-    const D3 q = dqb_blend_warp<KS>(node_dq, node_w, bd, bi, p.k, p.lw.q, px, py, pz, &wi, nullptr);   // fusion.py:178
+    const D3 q = dqb_blend_warp<KS>(node_dq, wg, bi, p.k, p.lw.q, px, py, pz);                          // fusion.py:178
     double s;
     if (!interpolate_exact(live, p.LX, p.LY, p.LZ, q.x, q.y, q.z, s)) return;
     if (!(s > -1.0 * p.tdist)) return;                                                              // :179
@@ -462,14 +495,16 @@ __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__
 
 template <typename VolT, typename LiveT>
 static int launch_dqb(void *tsdf, void *tsdf_w, const void *live, const double *node_pos, const double *node_dq,
-                      const double *node_w, int *cand, unsigned short *knn_cache, int mode, const DqbParams &p, hipStream_t s) {
+                      const double *node_w, int *cand, unsigned short *knn_cache, double *w_cache, int mode, const DqbParams &p,
+                      hipStream_t s) {
     const long nbricks = (long)p.nbx * p.nby * p.nbz;
-#define DFH_K3(KS, MODE) hipLaunchKernelGGL((fuse_volume_dqb_kernel<VolT, LiveT, KS, MODE>), dim3((unsigned)nbricks), dim3(256), 0, s, \
-                                            (VolT *)tsdf, (VolT *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, knn_cache, p)
+    const long nblocks = mode >= 2 ? ((long)p.nx * p.Y * p.Z + 255) / 256 : nbricks;
+#define DFH_K3(KS, MODE) hipLaunchKernelGGL((fuse_volume_dqb_kernel<VolT, LiveT, KS, MODE>), dim3((unsigned)nblocks), dim3(256), 0, s, \
+                                            (VolT *)tsdf, (VolT *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, p)
     if (p.k <= 4) {                                   // 4 register slots suffice: half the insertion work
-        if (mode == 0) DFH_K3(4, 0); else if (mode == 1) DFH_K3(4, 1); else DFH_K3(4, 2);
+        if (mode == 0) DFH_K3(4, 0); else if (mode == 1) DFH_K3(4, 1); else if (mode == 2) DFH_K3(4, 2); else DFH_K3(4, 3);
     } else {
-        if (mode == 0) DFH_K3(kKMax, 0); else if (mode == 1) DFH_K3(kKMax, 1); else DFH_K3(kKMax, 2);
+        if (mode == 0) DFH_K3(kKMax, 0); else if (mode == 1) DFH_K3(kKMax, 1); else if (mode == 2) DFH_K3(kKMax, 2); else DFH_K3(kKMax, 3);
     }
 #undef DFH_K3
     DFH_HIP_CHECK(hipGetLastError());
@@ -543,11 +578,13 @@ extern "C" size_t dfh_dqb_workspace_bytes(const int res[3], int x0, int x1) {
     return dfh::cand_bytes(res, x0, x1);
 }
 
-extern "C" size_t dfh_dqb_workspace_bytes_cached(const int res[3], int x0, int x1, int knn, int n_nodes) {
+extern "C" size_t dfh_dqb_workspace_bytes_cached(const int res[3], int x0, int x1, int knn, int n_nodes, int level) {
     if (!res || x1 <= x0) return 0;
     const size_t base = dfh::cand_bytes(res, x0, x1);
-    if (knn < 1 || knn > dfh::kKMax || n_nodes > 65536) return base;         // indices are kept as 16-bit
-    return base + (size_t)(x1 - x0) * res[1] * res[2] * knn * sizeof(unsigned short);
+    if (level < 1 || knn < 1 || knn > dfh::kKMax || n_nodes > 65536) return base;         // indices are kept as 16-bit
+    const size_t nvox = (size_t)(x1 - x0) * res[1] * res[2];
+    const size_t idx = (nvox * knn * sizeof(unsigned short) + 15) & ~(size_t)15;
+    return base + idx + (level >= 2 ? nvox * (knn + 1) * sizeof(double) : 0);
 }
 
 extern "C" int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int x0, int x1,
@@ -580,18 +617,22 @@ extern "C" int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
     int *cand = static_cast<int *>(workspace);
     // a workspace of dfh_dqb_workspace_bytes_cached() also keeps every voxel's k node indices
-    const size_t cached = dfh_dqb_workspace_bytes_cached(res, x0, x1, knn, n_nodes);
-    const bool has_cache = cached > cand_bytes(res, x0, x1) && workspace_bytes >= cached && !getenv("DFH_K3_NO_CACHE");
-    unsigned short *knn_cache = has_cache ? reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + cand_bytes(res, x0, x1)) : nullptr;
-    const int mode = !has_cache ? 0 : (rebuild_candidates ? 1 : 2);
+    const size_t base = cand_bytes(res, x0, x1);
+    const size_t cached1 = dfh_dqb_workspace_bytes_cached(res, x0, x1, knn, n_nodes, 1);
+    const size_t cached2 = dfh_dqb_workspace_bytes_cached(res, x0, x1, knn, n_nodes, 2);
+    const bool has_idx = cached1 > base && workspace_bytes >= cached1 && !getenv("DFH_K3_NO_CACHE");
+    const bool has_w = has_idx && workspace_bytes >= cached2;
+    unsigned short *knn_cache = has_idx ? reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + base) : nullptr;
+    double *w_cache = has_w ? reinterpret_cast<double *>(static_cast<char *>(workspace) + cached1) : nullptr;
+    const int mode = !has_idx ? 0 : (rebuild_candidates ? 1 : (has_w ? 3 : 2));
     if (rebuild_candidates) {
         hipLaunchKernelGGL(dqb_candidates_kernel, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, s, node_pos, cand, p);
         DFH_HIP_CHECK(hipGetLastError());
     }
     if (vol_dtype == DFH_F32) {
-        if (live_dtype == DFH_F32) return launch_dqb<float, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, mode, p, s);
-        return launch_dqb<float, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, mode, p, s);
+        if (live_dtype == DFH_F32) return launch_dqb<float, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
+        return launch_dqb<float, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
     }
-    if (live_dtype == DFH_F32) return launch_dqb<double, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, mode, p, s);
-    return launch_dqb<double, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, mode, p, s);
+    if (live_dtype == DFH_F32) return launch_dqb<double, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
+    return launch_dqb<double, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
 }

@@ -124,7 +124,7 @@ class Fusion:
         self._ensure_volumes()
         pos, dq, w, _ = self.node_arrays()
         res = tuple(self._T.shape)
-        key = (res, pos.tobytes(), self._knn)
+        key = (res, pos.tobytes(), w.tobytes(), self._knn)          # what the workspace's stored indices / weights depend on
         rebuild = key != self._workspace_key
         if rebuild:
             self._workspace = kernels.dqb_workspace(res, knn=self._knn, n_nodes=len(pos))

@@ -79,16 +79,16 @@ def fuse_volume_rigid(T, Wt, live, lw_dq, tdist, wmax=100.0, res=None, x_range=N
     return T, Wt
 
 
-def dqb_workspace(res, x_range=None, device=None, knn=None, n_nodes=None):
+def dqb_workspace(res, x_range=None, device=None, knn=None, n_nodes=None, level=2):
     """Scratch tensor for fuse_volume_dqb: the per-brick candidate node lists and, when `knn` and `n_nodes` are
-    given, every voxel's knn node indices as well (2*knn bytes per voxel; calls with rebuild_candidates=False then
-    skip the node search)."""
+    given, per voxel the knn node indices (level 1: 2*knn bytes) and blend weights (level 2: + 8*(knn+1) bytes);
+    calls with rebuild_candidates=False then skip the node search / the weight computation."""
     require_gpu()
     lib = _lib.load()
     if x_range is None:
         x_range = (0, res[0])
     if knn is not None and n_nodes is not None:
-        nbytes = lib.dfh_dqb_workspace_bytes_cached(_lib.iarr(res), int(x_range[0]), int(x_range[1]), int(knn), int(n_nodes))
+        nbytes = lib.dfh_dqb_workspace_bytes_cached(_lib.iarr(res), int(x_range[0]), int(x_range[1]), int(knn), int(n_nodes), int(level))
     else:
         nbytes = lib.dfh_dqb_workspace_bytes(_lib.iarr(res), int(x_range[0]), int(x_range[1]))
     return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.int32, device=device or "cuda")

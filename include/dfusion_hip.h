@@ -93,11 +93,13 @@ int dfh_fuse_volume_rigid(void *tsdf, void *tsdf_w, int vol_dtype, const int res
  * :116), all device fp64.  1 <= knn <= 8.  workspace: device scratch of dfh_dqb_workspace_bytes() bytes
  * holding per-brick candidate node lists; they depend only on (node_pos, knn, grid, slab) and are rebuilt
  * when rebuild_candidates != 0.  A workspace of dfh_dqb_workspace_bytes_cached() bytes (16-byte aligned; the
- * same size when n_nodes > 65536) additionally keeps every voxel's knn node indices (16-bit): the call with
- * rebuild_candidates != 0 stores them and later calls skip the node search -- same results, bit for bit,
- * since the nearest nodes of a voxel centre do not depend on node_dq. */
+ * plain size when n_nodes > 65536) additionally keeps per voxel the knn node indices (level 1: 2*knn bytes) and
+ * the blend weights exp(..) and wi (level 2: + 8*(knn+1) bytes): the call with rebuild_candidates != 0 stores
+ * them, later calls skip the node search and the sqrt/divide/exp chain -- same results, bit for bit, since
+ * these values depend on (node_pos, node_w, knn, grid, slab) and not on node_dq.  The level in use is
+ * inferred from workspace_bytes. */
 size_t dfh_dqb_workspace_bytes(const int res[3], int x0, int x1);
-size_t dfh_dqb_workspace_bytes_cached(const int res[3], int x0, int x1, int knn, int n_nodes);
+size_t dfh_dqb_workspace_bytes_cached(const int res[3], int x0, int x1, int knn, int n_nodes, int level);
 int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int x0, int x1,
                         const void *live, int live_dtype, const int live_res[3],
                         const double *node_pos, const double *node_dq, const double *node_w, int n_nodes,

@@ -187,9 +187,9 @@ def test_dqb_vs_oracle(res, N, k):
     # the same bits -- also when the node DQs changed in between (the nearest nodes do not depend on them)
     T3, W3 = dev(T0, torch.float64), dev(W0, torch.float64)
     other_dq = np.array([small_dq(rng, 0.05, 0.2, 1.0) for _ in range(N)])
-    for a, b in ((0, 5), (5, res[0])):
-        ws = kernels.dqb_workspace(res, (a, b), knn=k, n_nodes=N)
-        assert ws.numel() * 4 >= kernels.dqb_workspace(res, (a, b)).numel() * 4 + (b - a) * res[1] * res[2] * k * 2
+    for (a, b), level in (((0, 5), 1), ((5, res[0]), 2)):          # level 1: indices; level 2: indices + blend weights
+        ws = kernels.dqb_workspace(res, (a, b), knn=k, n_nodes=N, level=level)
+        assert ws.numel() * 4 >= kernels.dqb_workspace(res, (a, b)).numel() * 4 + (b - a) * res[1] * res[2] * (k * 2 + (level - 1) * 8 * (k + 1))
         Ts, Ws = dev(T0[a:b], torch.float64), dev(W0[a:b], torch.float64)
         kernels.fuse_volume_dqb(Ts, Ws, dev(live, torch.float64), node_pos, other_dq, node_w, k, lw, tdist, 7.0,
                                 res=res, x_range=(a, b), workspace=ws, rebuild_candidates=True)

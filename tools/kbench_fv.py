@@ -44,10 +44,12 @@ ms = timeit(lambda: kernels.fuse_volume_dqb(T, W, live, P, Q, Wn, k, lw, tdist, 
 cnt = ws.view(-1, 257)[:, 0]          # kCap + 1 ints per brick (csrc/dfh_fuse_volume.hip)
 print("K3 dqb    %d^3, %d nodes: %8.1f us (+%.1f us candidate rebuild)  %8.0f Mvox/s  alg %.0f GB/s (%.1f%% of 8 TB/s)"
       % (R, N, ms * 1e3, (ms_c - ms) * 1e3, R ** 3 / ms / 1e3, alg / ms / 1e6, alg / ms / 1e6 / 80))
-wsc = kernels.dqb_workspace((R, R, R), knn=k, n_nodes=N)
-ms_c = timeit(lambda: kernels.fuse_volume_dqb(T, W, live, P, Q, Wn, k, lw, tdist, workspace=wsc, rebuild_candidates=True), 3)
-ms = timeit(lambda: kernels.fuse_volume_dqb(T, W, live, P, Q, Wn, k, lw, tdist, workspace=wsc, rebuild_candidates=False), a.reps)
-alg_c = (20.0 + 2 * k) * R ** 3
-print("K3 dqb, stored node indices: %8.1f us (first call, search + store: %.1f us)  %8.0f Mvox/s  alg %.0f GB/s (%.1f%% of 8 TB/s)"
-      % (ms * 1e3, ms_c * 1e3, R ** 3 / ms / 1e3, alg_c / ms / 1e6, alg_c / ms / 1e6 / 80))
+for level, what in ((1, "node indices"), (2, "indices + weights")):
+    wsc = kernels.dqb_workspace((R, R, R), knn=k, n_nodes=N, level=level)
+    ms_c = timeit(lambda: kernels.fuse_volume_dqb(T, W, live, P, Q, Wn, k, lw, tdist, workspace=wsc, rebuild_candidates=True), 3)
+    ms = timeit(lambda: kernels.fuse_volume_dqb(T, W, live, P, Q, Wn, k, lw, tdist, workspace=wsc, rebuild_candidates=False), a.reps)
+    alg_c = (20.0 + 2 * k + (8 * (k + 1) if level == 2 else 0)) * R ** 3
+    print("K3 dqb, stored %s: %8.1f us (first call, search + store: %.1f us)  %8.0f Mvox/s  alg %.0f GB/s (%.1f%% of 8 TB/s)"
+          % (what, ms * 1e3, ms_c * 1e3, R ** 3 / ms / 1e3, alg_c / ms / 1e6, alg_c / ms / 1e6 / 80))
+    del wsc
 print("   candidates per brick: mean %.1f max %d, overflow bricks %d of %d" % (float(cnt.clamp(min=0).float().mean()), int(cnt.max()), int((cnt < 0).sum()), cnt.numel()))

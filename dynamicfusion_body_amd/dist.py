@@ -101,6 +101,17 @@ def halo_planes(local, n_planes):
     return lo, hi
 
 
+def all_ranks(flag):
+    """True iff `flag` is true on every rank (one tiny all-reduce; ranks must take collective decisions alike)."""
+    _, ws = world()
+    if ws == 1:
+        return bool(flag)
+    dev = "cuda" if (dist.get_backend() == "nccl" and torch.cuda.is_available()) else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t[0]))
+
+
 def allreduce_system(flat):
     """Sum the flat normal-equation buffer over ranks (in place, one collective)."""
     _, ws = world()

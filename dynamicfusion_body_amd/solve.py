@@ -191,6 +191,7 @@ class WarpSolver:
             raise ValueError("node arrays disagree on the number of nodes")
         self.node_nbr = None if node_nbr is None else _i32(node_nbr, (self.knn,))
         self._pattern = None
+        self._pattern_keys = None
 
     # -- samples -----------------------------------------------------------------------------
     def set_samples(self, pos, nrm, nbr=None, weights=None, sort=True):
@@ -254,21 +255,42 @@ class WarpSolver:
         return torch.stack(cols[::-1], dim=1)
 
     def _build_pattern(self):
+        """Block pattern of J^T J (diagonal, node pairs sharing a sample, regularisation pairs) and everything sized by
+        it.  The pattern only GROWS while the graph stays: if the new samples' node pairs are all in the current
+        pattern (the usual case from one frame to the next) it is kept -- blocks without contributions are exact
+        zeros and change no result -- and only the data plan is rebuilt."""
         N, k = self.N, self.knn
-        keys = [torch.arange(N, device="cuda", dtype=torch.int64) * (N + 1)]             # diagonal
+        new = []
         if self.S > 0:
             # distinct node tuples only (the pattern is a function of the tuples, not of the samples)
             if self._tuple_key is not None:
                 tup = self._unpack_tuples(torch.unique_consecutive(self._tuple_key))
             else:
                 tup = torch.unique(self.snbr, dim=0).long()
-            keys.append((tup[:, :, None] * N + tup[:, None, :]).reshape(-1))
-        if self.node_nbr is not None:
-            i = torch.arange(N, device="cuda", dtype=torch.int64)[:, None].expand(N, k)
-            j = self.node_nbr.long()
-            keys += [(i * N + j).reshape(-1), (j * N + i).reshape(-1)]
-        keys = torch.cat(keys)
+            new.append((tup[:, :, None] * N + tup[:, None, :]).reshape(-1))
+        old = getattr(self, "_pattern_keys", None)
+        if old is not None:
+            covered = True
+            if new:
+                at = torch.searchsorted(old, new[0]).clamp_(max=old.numel() - 1)
+                covered = bool((old[at] == new[0]).all())
+            if (_dist.all_ranks(covered) if self.distributed else covered):
+                nbytes = self.lib.dfh_pcg_workspace_bytes(N, self.pcg_iters)          # pcg_iters may have been raised
+                if self.pcg_ws.numel() * 8 < nbytes:
+                    self.pcg_ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device="cuda")
+                self._build_plan(old, reg=False)
+                self._pattern = True
+                return
+            new.append(old)
+        else:
+            new.append(torch.arange(N, device="cuda", dtype=torch.int64) * (N + 1))      # diagonal
+            if self.node_nbr is not None:
+                i = torch.arange(N, device="cuda", dtype=torch.int64)[:, None].expand(N, k)
+                j = self.node_nbr.long()
+                new += [(i * N + j).reshape(-1), (j * N + i).reshape(-1)]
+        keys = torch.cat(new)
         keys = _dist.union_sorted_keys(keys) if self.distributed else torch.unique(keys)   # sorted; same on every rank
+        self._pattern_keys = keys
         rows = (keys // N).to(torch.int32)
         self.col = (keys % N).to(torch.int32).contiguous()
         self.row_ptr = torch.searchsorted(rows.contiguous(), torch.arange(N + 1, device="cuda", dtype=torch.int32)).to(torch.int32).contiguous()
@@ -284,9 +306,10 @@ class WarpSolver:
         self._build_plan(keys)
         self._pattern = True
 
-    def _build_plan(self, keys):
+    def _build_plan(self, keys, reg=True):
         """Static part of the data term (dfh_gn_build_planned): rows = runs of equal node tuples inside a
-        256-sample tile, and for every block / node the rows (and tuple slots) that contribute to it."""
+        256-sample tile, and for every block / node the rows (and tuple slots) that contribute to it.
+        reg=False keeps the regularisation lists (they depend on the pattern and the graph only)."""
         N, k, S, dev = self.N, self.knn, self.S, "cuda"
         i32 = lambda t: t.to(torch.int32).contiguous()
         if S == 0:
@@ -316,8 +339,9 @@ class WarpSolver:
             return bp, i32(order), npt, i32(order2)
 
         self.blk_ptr, self.blk_ent, self.node_ptr, self.node_ent = lists(tup)
-        self.partial_reg = None
-        if self.node_nbr is not None:
+        if reg:
+            self.partial_reg = None
+        if reg and self.node_nbr is not None:
             ii = torch.arange(N, device=dev, dtype=torch.int64)[:, None].expand(N, k).reshape(-1)
             pair = torch.stack([ii, self.node_nbr.long().reshape(-1)], dim=1)          # row t = i*k + slot
             self.rblk_ptr, self.rblk_ent, self.rnode_ptr, self.rnode_ent = lists(pair)

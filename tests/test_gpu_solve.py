@@ -189,6 +189,51 @@ def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, mon
     assert float((s1 - s0).abs().max()) > 0                               # the regulariser really contributes
 
 
+def test_block_pattern_kept_across_sample_sets(golden):
+    """New samples on an unchanged graph: the block pattern is kept when it covers the new node pairs (only the data
+    plan is rebuilt) and grows otherwise; either way the system and the step equal a fresh solver's."""
+    g, verts, norms, corr, nbr, vidx, npos, ndq, nw, lw, rw = load(golden)
+    S = len(verts)
+    rng = np.random.default_rng(11)
+    sv = make_solver(npos, ndq, nw, nbr, vidx, verts, norms, corr, nbr.shape[1], pcg_iters=8)
+    sv.build(lw, rw)
+    keys_full = sv._pattern_keys.clone()
+    first = np.arange(S) < S // 3
+
+    def fresh_solver(sel):
+        f = solve.WarpSolver(knn=nbr.shape[1], pcg_iters=8)
+        f.set_graph(npos, ndq, nw, node_nbr=nbr[vidx])
+        f.set_samples(verts[sel], norms[sel], nbr=nbr[sel])
+        f.set_correspondences(corr[sel])
+        return f
+    for sel, grows in ((rng.random(S) < 0.5, False), (first, False)):
+        sv.set_samples(verts[sel], norms[sel], nbr=nbr[sel])
+        sv.set_correspondences(corr[sel])
+        sv.build(lw, rw)
+        assert torch.equal(sv._pattern_keys, keys_full)                       # covered: same pattern object contents
+        fresh = fresh_solver(sel)
+        fresh.build(lw, rw)
+        A, b = sv.dense_normal_equations()
+        Af, bf = fresh.dense_normal_equations()
+        assert np.array_equal(A, Af) and np.array_equal(b, bf)
+        assert sv.cost() == fresh.cost()
+        sv.solve_linear(1e-3, 0.0); fresh.solve_linear(1e-3, 0.0)
+        dxs, dxf = sv.dx.cpu().numpy(), fresh.dx.cpu().numpy()
+        assert np.abs(dxs - dxf).max() <= 1e-12 * np.abs(dxf).max()           # extra all-zero blocks only reorder nothing
+    # start from the small set, then hand over the full one: the pattern has to grow
+    small = fresh_solver(first)
+    small.build(lw, rw)
+    b_small = small.B
+    small.set_samples(verts, norms, nbr=nbr)
+    small.set_correspondences(corr)
+    small.build(lw, rw)
+    assert small.B >= b_small and torch.equal(small._pattern_keys, keys_full)
+    A, b = small.dense_normal_equations()
+    sv.set_samples(verts, norms, nbr=nbr); sv.set_correspondences(corr); sv.build(lw, rw)
+    Af, bf = sv.dense_normal_equations()
+    assert np.array_equal(A, Af) and np.array_equal(b, bf)
+
+
 def test_huber_weights_vs_oracle(golden):
     """huber > 0: every data row and its residual scaled by sqrt(min(1, huber / |r|)) -- the IRLS form of the loss the
     reference's solver uses (least_squares(loss='huber'), core/fusion.py:389) -- against the oracle's J, r with the

@@ -39,9 +39,10 @@ ms, _ = t(lambda: sv._build_pattern()); print("pattern+plan   %.3f ms" % ms)
 ms, _ = t(lambda: sf.refresh_samples()); print("refresh total  %.3f ms" % ms)
 keys_holder = {}
 orig_plan = sv._build_plan
-def fake_plan(keys):
+def fake_plan(keys, reg=True):
     keys_holder["k"] = keys
 sv._build_plan = fake_plan
-ms, _ = t(lambda: sv._build_pattern()); print("  pattern only %.3f ms (B=%d)" % (ms, sv.B))
+ms, _ = t(lambda: sv._build_pattern()); print("  pattern check (kept) %.3f ms (B=%d)" % (ms, sv.B))
 sv._build_plan = orig_plan
-ms, _ = t(lambda: sv._build_plan(keys_holder["k"])); print("  plan only    %.3f ms (rows=%d)" % (ms, sv.n_rows))
+ms, _ = t(lambda: sv._build_plan(keys_holder["k"], reg=False)); print("  data plan    %.3f ms (rows=%d)" % (ms, sv.n_rows))
+ms, _ = t(lambda: sv._build_plan(keys_holder["k"])); print("  data + regulariser plan %.3f ms" % ms)

@@ -181,7 +181,7 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
     sf.refresh_samples()
     lws = [scene.view_extrinsic(a) for a in (0.0, 40.0, -40.0)]
     lw_cam = lws
-    nframes = 6
+    nframes = 8
     depths = []
     for f in range(nframes):                      # the sphere drifts and breathes a little every frame; three views per frame
         off = np.array([0.10, -0.07, 0.05]) * (f + 1) * scale
@@ -201,21 +201,23 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
                 torch.cuda.synchronize()
                 stages["mesh"] = stages.get("mesh", 0.0) + (_t.perf_counter() - t1) * 1e3
 
-    frame(0)                                      # warm-up (allocations, block pattern, candidate lists)
-    barrier()
-    t0 = _t.perf_counter()
-    for f in range(1, nframes):
+    nwarm = 2                                     # warm-up: frame 0 allocates, builds the block pattern and K3's stored
+    for f in range(nwarm):                        # neighbourhoods; frame 1 is the first to take the steady-state paths
         frame(f)
     barrier()
-    dt = D.max_over_ranks([(_t.perf_counter() - t0) / (nframes - 1)])[0]
-    for f in range(1, nframes):                   # second, untimed-for-throughput pass with a sync after every stage
+    t0 = _t.perf_counter()
+    for f in range(nwarm, nframes):
+        frame(f)
+    barrier()
+    dt = D.max_over_ranks([(_t.perf_counter() - t0) / (nframes - nwarm)])[0]
+    for f in range(nwarm, nframes):               # second, untimed-for-throughput pass with a sync after every stage
         frame(f, timed=True)
     cost, cnt = sf.fs.solver.cost()
     tot = torch.tensor([float(info["samples"])], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tot)
-    return {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "frames_timed": nframes - 1, "scaling": "strong" if world > 1 else "n/a",
-            "stage_ms_with_syncs": {kk: vv / (nframes - 1) for kk, vv in stages.items()},
+    return {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "frames_timed": nframes - nwarm, "scaling": "strong" if world > 1 else "n/a",
+            "stage_ms_with_syncs": {kk: vv / (nframes - nwarm) for kk, vv in stages.items()},
             "gn_iters_per_frame": iters, "nodes": N, "samples": int(tot.item()), "mesh_vertices": info["vertices"],
             "mesh_faces": info["faces"], "final_cost": cost,
             "exchange": "none" if world == 1 else "per frame: all-gather of the live volume (%.0f MB) + face-plane halo; per GN "

@@ -288,6 +288,17 @@ class WarpSolver:
                 i = torch.arange(N, device="cuda", dtype=torch.int64)[:, None].expand(N, k)
                 j = self.node_nbr.long()
                 new += [(i * N + j).reshape(-1), (j * N + i).reshape(-1)]
+        if self.S > 0 and N <= 4096 and old is not None:
+            # the pattern had to grow, so the sample set is moving: add head-room once, so that the next sets are
+            # covered and the pattern is kept -- every node pair no further apart than 1.15 x the widest pair that
+            # shares a sample (all-zero blocks change no result and cost the PCG ~1 us per 1000 blocks and iteration;
+            # rebuilding pattern and plans costs 0.5 ms per frame).  A solver that is set up once never comes here.
+            pk = new[0]
+            pi, pj = pk // N, pk % N
+            lim = ((self.node_pos[pi] - self.node_pos[pj]) ** 2).sum(dim=1).max() * (1.15 * 1.15)
+            dd = ((self.node_pos[:, None, :] - self.node_pos[None, :, :]) ** 2).sum(dim=2)
+            near = torch.nonzero(dd <= lim)
+            new.append(near[:, 0] * N + near[:, 1])
         keys = torch.cat(new)
         keys = _dist.union_sorted_keys(keys) if self.distributed else torch.unique(keys)   # sorted; same on every rank
         self._pattern_keys = keys

@@ -261,28 +261,28 @@ class WarpSolver:
         zeros and change no result -- and only the data plan is rebuilt."""
         N, k = self.N, self.knn
         new = []
-        if self.S > 0:
+        old = getattr(self, "_pattern_keys", None)
+        if old is not None:
+            # the data plan looks every row's node pairs up in the pattern anyway: build it against the current
+            # pattern and learn from the look-up whether all pairs were there (one flag, one synchronisation)
+            nbytes = self.lib.dfh_pcg_workspace_bytes(N, self.pcg_iters)          # pcg_iters may have been raised
+            if self.pcg_ws.numel() * 8 < nbytes:
+                self.pcg_ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device="cuda")
+            covered = self._build_plan(old, reg=False)
+            if (_dist.all_ranks(covered) if self.distributed else covered):
+                self._pattern = True
+                return
+            if self.S > 0:
+                new.append(self._pair_keys)
+            new.append(old)
+        elif self.S > 0:
             # distinct node tuples only (the pattern is a function of the tuples, not of the samples)
             if self._tuple_key is not None:
                 tup = self._unpack_tuples(torch.unique_consecutive(self._tuple_key))
             else:
                 tup = torch.unique(self.snbr, dim=0).long()
             new.append((tup[:, :, None] * N + tup[:, None, :]).reshape(-1))
-        old = getattr(self, "_pattern_keys", None)
-        if old is not None:
-            covered = True
-            if new:
-                at = torch.searchsorted(old, new[0]).clamp_(max=old.numel() - 1)
-                covered = bool((old[at] == new[0]).all())
-            if (_dist.all_ranks(covered) if self.distributed else covered):
-                nbytes = self.lib.dfh_pcg_workspace_bytes(N, self.pcg_iters)          # pcg_iters may have been raised
-                if self.pcg_ws.numel() * 8 < nbytes:
-                    self.pcg_ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device="cuda")
-                self._build_plan(old, reg=False)
-                self._pattern = True
-                return
-            new.append(old)
-        else:
+        if old is None:
             new.append(torch.arange(N, device="cuda", dtype=torch.int64) * (N + 1))      # diagonal
             if self.node_nbr is not None:
                 i = torch.arange(N, device="cuda", dtype=torch.int64)[:, None].expand(N, k)
@@ -338,10 +338,13 @@ class WarpSolver:
             self.n_rows = int(tup.shape[0])
         R = self.n_rows
 
+        found = []
+
         def lists(tup):
             """CSR lists for the gather: per block the entries row*K^2 + sa*K + sb, per node the entries row*K + slot."""
             key = (tup[:, :, None] * N + tup[:, None, :]).reshape(-1)
             blk = torch.searchsorted(keys, key)
+            found.append((key, (keys[blk.clamp(max=keys.numel() - 1)] == key).all()))     # every pair is a block of the pattern?
             order = torch.argsort(blk, stable=True)
             bp = i32(torch.searchsorted(blk[order].contiguous(), torch.arange(self.B + 1, device=dev)))
             node = tup.reshape(-1)
@@ -350,6 +353,7 @@ class WarpSolver:
             return bp, i32(order), npt, i32(order2)
 
         self.blk_ptr, self.blk_ent, self.node_ptr, self.node_ent = lists(tup)
+        self._pair_keys, covered = found[0]
         if reg:
             self.partial_reg = None
         if reg and self.node_nbr is not None:
@@ -361,6 +365,7 @@ class WarpSolver:
         self.partial = torch.empty(max(1, R * ne) + 2 * ((S + 255) // 256), dtype=torch.float64, device=dev)   # rows | {cost, count} per tile
         if R * k * k >= 2 ** 31:
             raise ValueError("too many sample runs for 32-bit plan entries")
+        return bool(covered) if not reg else True          # (reg=True is the call that follows a pattern build: covered by construction)
 
     # -- correspondences ---------------------------------------------------------------------
     def set_correspondences(self, corr, valid=None):

@@ -37,12 +37,6 @@ ms, (nbr, wts) = t(lambda: sample_knn(pos, sv.node_pos, sv.node_w, 4)); print("s
 ms, _ = t(lambda: sv.set_samples(pos, nrm, nbr=nbr, weights=wts)); print("set_samples    %.3f ms (sort by tuple + gathers)" % ms)
 ms, _ = t(lambda: sv._build_pattern()); print("pattern+plan   %.3f ms" % ms)
 ms, _ = t(lambda: sf.refresh_samples()); print("refresh total  %.3f ms" % ms)
-keys_holder = {}
-orig_plan = sv._build_plan
-def fake_plan(keys, reg=True):
-    keys_holder["k"] = keys
-sv._build_plan = fake_plan
-ms, _ = t(lambda: sv._build_pattern()); print("  pattern check (kept) %.3f ms (B=%d)" % (ms, sv.B))
-sv._build_plan = orig_plan
-ms, _ = t(lambda: sv._build_plan(keys_holder["k"], reg=False)); print("  data plan    %.3f ms (rows=%d)" % (ms, sv.n_rows))
-ms, _ = t(lambda: sv._build_plan(keys_holder["k"])); print("  data + regulariser plan %.3f ms" % ms)
+keys = sv._pattern_keys
+ms, _ = t(lambda: sv._build_plan(keys, reg=False)); print("  data plan (+ coverage flag) %.3f ms (rows=%d)" % (ms, sv.n_rows))
+ms, _ = t(lambda: sv._build_plan(keys)); print("  data + regulariser plan %.3f ms" % ms)

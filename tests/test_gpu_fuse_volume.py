@@ -150,6 +150,36 @@ def test_g4_dqb_golden(golden, vol_dtype):
     assert np.all(np.abs(fu._tsdf - g["T_after3"]) <= tol * (1 + np.abs(g["T_after3"])))
 
 
+def test_fusion_update_stored_neighbourhoods_follow_the_graph():
+    """Fusion.updateTSDF keeps every voxel's node indices / blend weights between calls: new node DQs must reuse
+    them, new node radii or positions must not (each call is checked against the oracle)."""
+    rng = np.random.default_rng(23)
+    res, N, k, tdist = (12, 10, 18), 14, 4, 2.0
+    node_pos = rng.uniform(0, np.array(res) - 1, size=(N, 3))
+    node_w = rng.uniform(2.0, 5.0, size=N)
+    lw = small_dq(rng, 0.03, 0.2, 1.0)
+    T0 = sphere_volume(res, np.array(res) / 2.0, min(res) / 3.0, tdist)
+    fu = Fusion(T0, tdist, knn=k, volume_dtype=np.float64)
+    fu._lw = lw
+    To, Wo = T0.copy(), np.zeros(res)
+    for step in range(4):
+        node_dq = np.array([small_dq(rng, 0.06, 0.3, 1.0) for _ in range(N)])
+        if step == 2:
+            node_w = node_w * 1.3                          # same positions, other radii: the stored weights are stale
+        if step == 3:
+            node_pos = node_pos[::-1].copy()               # other positions: indices are stale as well
+        fu._nodes = [(0, node_pos[i], node_dq[i], float(node_w[i])) for i in range(N)]
+        live = sphere_volume(res, np.array(res) / 2.0 + 0.3 * step, min(res) / 3.1, tdist)
+        ws_before = fu._workspace if hasattr(fu, "_workspace") else None
+        fu.updateTSDF(live, wmax=20.0)
+        if step == 1:
+            assert fu._workspace is ws_before              # step 1 reused step 0's workspace ...
+        if step in (2, 3):
+            assert fu._workspace is not ws_before          # ... steps 2 and 3 rebuilt it
+        O.update_tsdf_dqb(To, Wo, live, node_pos, node_dq, node_w, k, lw, tdist, wmax=20.0)
+        assert np.abs(fu._tsdfw - Wo).max() <= 1e-12 and np.abs(fu._tsdf - To).max() <= 1e-12
+
+
 @pytest.mark.parametrize("res,N,k", [((24, 20, 40), 60, 4), ((16, 16, 16), 9, 3), ((12, 28, 33), 420, 8), ((8, 8, 16), 5, 1)])
 def test_dqb_vs_oracle(res, N, k):
     """Random graphs, ragged grids, knn 1..8; includes bricks far from every node (large candidate

@@ -39,6 +39,8 @@ _SIGNATURES = {
     "dfh_warp_points": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _int, _c_double_p, _vp, _vp, _vp]),
     "dfh_closest_correspondences": (_int, [_vp, _vp, _int, _vp, _int, _int, _dbl, _vp, _vp, _vp, _vp]),
     "dfh_sample_knn": (_int, [_vp, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
+    "dfh_dqb_build_candidates": (_int, [_c_int_p, _int, _int, _vp, _int, _int, _vp, ctypes.c_size_t, _vp]),
+    "dfh_sample_knn_bricks": (_int, [_vp, _int, _vp, _vp, _int, _int, _c_int_p, _int, _int, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
     "dfh_gn_associate": (_int, [_vp, _vp, _vp, _int, _int, _vp, _c_double_p, _vp, _int, _int, _int, _c_double_p,
                                 _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, _vp, _vp]),
     "dfh_gn_build": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _c_double_p, _dbl,

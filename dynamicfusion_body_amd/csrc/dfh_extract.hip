@@ -42,8 +42,10 @@ __device__ __forceinline__ bool band_sample(const VolT *__restrict__ T, const Vo
         const double nx = gx / n, ny = gy / n, nz = gz / n;
         nrm[0] = nx; nrm[1] = ny; nrm[2] = nz;
         // one Newton step onto the zero level set: centre - T grad / |grad|^2  (a projective TSDF has |grad| > 1 on
-        // surfaces oblique to the camera; stepping by T along the unit normal would overshoot there)
-        const double st = t / n;
+        // surfaces oblique to the camera; stepping by T along the unit normal would overshoot there).  Where the
+        // gradient is flatter than a distance field's (|grad| < 1: borders of the observed region, noise) the step is
+        // |T| and no more, so that a sample never leaves its voxel's band neighbourhood
+        const double st = t / fmax(n, 1.0);
         pos[0] = (double)(x + p.x0) - st * nx;
         pos[1] = (double)y - st * ny;
         pos[2] = (double)z - st * nz;

@@ -234,6 +234,10 @@ constexpr int kCap = 256;                       // candidate nodes kept per bric
 constexpr int kKMax = 8;                        // knn <= 8
 // half diagonal of the voxel-centre span of a brick
 #define DFH_BRICK_RADIUS 7.7942286340599480     /* sqrt(1.5^2 + 1.5^2 + 7.5^2) */
+// head-room for off-lattice points (dfh_sample_knn_bricks): a point p belongs to the brick of its nearest voxel centre
+// v, |p - v| <= sqrt(3)/2, so D_k(p) <= D_k(v) + sqrt(3)/2 and a node among p's k nearest is within
+// D_k(p) + sqrt(3)/2 of v, hence of the brick's box
+#define DFH_SAMPLE_MARGIN 1.7320508075688774
 
 struct DqbParams {
     DQ lw;
@@ -272,7 +276,8 @@ __device__ __forceinline__ double select_k(const double (&bd)[KS], int k) {
 
 // Per brick: the nodes that can be among the k nearest of ANY voxel centre p of the brick.
 // With c the brick centre and r its radius, D_k(p) <= d_k(c) + r for every p in the brick, so a
-// node q can only matter if its distance to the brick's box of voxel centres is <= d_k(c) + r.
+// node q can only matter if its distance to the brick's box of voxel centres is <= d_k(c) + r
+// (+ DFH_SAMPLE_MARGIN, so that the lists also serve the off-lattice surface samples).
 // cand[brick*(kCap+1)] = count (or -1: too many -> scan all nodes).
 __global__ __launch_bounds__(256) void dqb_candidates_kernel(const double *__restrict__ node_pos, int *__restrict__ cand,
                                                               const DqbParams p) {
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256) void dqb_candidates_kernel(const double *__res
         const double d2 = (dx * dx + dy * dy) + dz * dz;
         if (d2 < bd[kKMax - 1]) topk_insert<kKMax>(bd, bi, d2, n);
     }
-    const double R = sqrt(select_k<kKMax>(bd, p.k)) + DFH_BRICK_RADIUS + 1e-6;
+    const double R = sqrt(select_k<kKMax>(bd, p.k)) + DFH_BRICK_RADIUS + DFH_SAMPLE_MARGIN + 1e-6;
     const double R2 = R * R;
     int *c = cand + brick * (kCap + 1);
     int cnt = 0;
@@ -519,6 +524,62 @@ static size_t cand_bytes(const int res[3], int x0, int x1) {
     return (((size_t)nbx * nby * nbz * (kCap + 1) * sizeof(int)) + 15) & ~(size_t)15;
 }
 
+// k nearest nodes + blend weights of arbitrary points through the bricks' candidate lists (what sample_knn_kernel of
+// dfh_solve.hip computes, same expressions, same tie order: candidates are kept in node order and the insertion is
+// stable).  A point outside the slab's lattice, or in a brick whose list overflowed, scans every node.
+template <int KS>
+__global__ __launch_bounds__(256) void sample_knn_bricks_kernel(const double *__restrict__ spos, int S,
+                                                                 const double *__restrict__ node_pos,
+                                                                 const double *__restrict__ node_w,
+                                                                 const int *__restrict__ cand, const DqbParams p,
+                                                                 int *__restrict__ nbr, double *__restrict__ wts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    const double px = spos[3 * (size_t)i], py = spos[3 * (size_t)i + 1], pz = spos[3 * (size_t)i + 2];
+    const double rx = rint(px), ry = rint(py), rz = rint(pz);
+    const bool inside = rx >= (double)p.x0 && rx < (double)(p.x0 + p.nx) && ry >= 0.0 && ry < (double)p.Y && rz >= 0.0 &&
+                        rz < (double)p.Z;                                        // (false for NaN)
+    const int *c = nullptr;
+    int cnt = -1;
+    if (inside) {
+        const long brick = ((long)(((int)rx - p.x0) / kBX) * p.nby + (int)ry / kBY) * p.nbz + (int)rz / kBZ;
+        c = cand + brick * (kCap + 1);
+        cnt = c[0];
+    }
+    double bd[KS];
+    int bi[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) { bd[j] = __builtin_huge_val(); bi[j] = -1; }
+    const int total = cnt >= 0 ? cnt : p.N;
+    constexpr int U = 8;                          // the loop is a chain of dependent loads (list entry -> node position):
+    for (int j0 = 0; j0 < total; j0 += U) {       // issue U of them before the first use
+        int g[U];
+        double x[U], y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jj = min(j0 + u, total - 1);
+            g[u] = cnt >= 0 ? c[1 + jj] : jj;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { x[u] = node_pos[3 * g[u]]; y[u] = node_pos[3 * g[u] + 1]; z[u] = node_pos[3 * g[u] + 2]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double dx = px - x[u], dy = py - y[u], dz = pz - z[u];
+            const double d2 = (dx * dx + dy * dy) + dz * dz;
+            if (j0 + u < total && d2 < bd[KS - 1]) topk_insert<KS>(bd, bi, d2, g[u]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        if (j < p.k) {
+            const int gi = bi[j];
+            nbr[(size_t)i * p.k + j] = gi;
+            const double t = sqrt(bd[j]) / (2.0 * node_w[gi]);
+            wts[(size_t)i * p.k + j] = exp(-1.0 * (t * t));
+        }
+    }
+}
+
 static void brick_counts(const int res[3], int x0, int x1, int &nbx, int &nby, int &nbz) {
     nbx = (x1 - x0 + kBX - 1) / kBX;
     nby = (res[1] + kBY - 1) / kBY;
@@ -635,4 +696,53 @@ extern "C" int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, cons
     }
     if (live_dtype == DFH_F32) return launch_dqb<double, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
     return launch_dqb<double, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
+}
+
+extern "C" int dfh_dqb_build_candidates(const int res[3], int x0, int x1, const double *node_pos, int n_nodes, int knn,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(res && node_pos, "dfh_dqb_build_candidates: null pointer");
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0, "dfh_dqb_build_candidates: bad grid");
+    DFH_REQUIRE(0 <= x0 && x0 <= x1 && x1 <= res[0], "dfh_dqb_build_candidates: slab [%d,%d) outside [0,%d)", x0, x1, res[0]);
+    DFH_REQUIRE(knn >= 1 && knn <= kKMax && n_nodes >= knn, "dfh_dqb_build_candidates: knn=%d, %d nodes", knn, n_nodes);
+    if (x1 == x0) return DFH_OK;
+    DFH_REQUIRE(workspace && workspace_bytes >= dfh_dqb_workspace_bytes(res, x0, x1),
+                "dfh_dqb_build_candidates: workspace too small (need %zu bytes)", dfh_dqb_workspace_bytes(res, x0, x1));
+    DqbParams p = {};
+    p.X = res[0]; p.Y = res[1]; p.Z = res[2];
+    p.x0 = x0; p.nx = x1 - x0; p.N = n_nodes; p.k = knn;
+    brick_counts(res, x0, x1, p.nbx, p.nby, p.nbz);
+    const long nbricks = (long)p.nbx * p.nby * p.nbz;
+    DFH_REQUIRE(nbricks < (1L << 31), "dfh_dqb_build_candidates: too many bricks");
+    hipLaunchKernelGGL(dqb_candidates_kernel, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       node_pos, static_cast<int *>(workspace), p);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+extern "C" int dfh_sample_knn_bricks(const double *sample_pos, int n_samples, const double *node_pos, const double *node_w,
+                                     int n_nodes, int knn, const int res[3], int x0, int x1, const void *workspace,
+                                     size_t workspace_bytes, int *nbr_out, double *weights_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_samples >= 0, "dfh_sample_knn_bricks: negative sample count");
+    if (n_samples == 0) return DFH_OK;
+    DFH_REQUIRE(sample_pos && node_pos && node_w && res && nbr_out && weights_out, "dfh_sample_knn_bricks: null pointer");
+    DFH_REQUIRE(knn >= 1 && knn <= kKMax && n_nodes >= knn, "dfh_sample_knn_bricks: knn=%d, %d nodes", knn, n_nodes);
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0 && 0 <= x0 && x0 < x1 && x1 <= res[0], "dfh_sample_knn_bricks: bad grid / slab");
+    DFH_REQUIRE(workspace && workspace_bytes >= dfh_dqb_workspace_bytes(res, x0, x1),
+                "dfh_sample_knn_bricks: workspace too small (need %zu bytes)", dfh_dqb_workspace_bytes(res, x0, x1));
+    DqbParams p = {};
+    p.X = res[0]; p.Y = res[1]; p.Z = res[2];
+    p.x0 = x0; p.nx = x1 - x0; p.N = n_nodes; p.k = knn;
+    brick_counts(res, x0, x1, p.nbx, p.nby, p.nbz);
+    dim3 grid((unsigned)((n_samples + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (knn <= 4)
+        hipLaunchKernelGGL(sample_knn_bricks_kernel<4>, grid, block, 0, s, sample_pos, n_samples, node_pos, node_w,
+                           static_cast<const int *>(workspace), p, nbr_out, weights_out);
+    else
+        hipLaunchKernelGGL(sample_knn_bricks_kernel<kKMax>, grid, block, 0, s, sample_pos, n_samples, node_pos, node_w,
+                           static_cast<const int *>(workspace), p, nbr_out, weights_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
 }

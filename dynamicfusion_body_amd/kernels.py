@@ -94,6 +94,20 @@ def dqb_workspace(res, x_range=None, device=None, knn=None, n_nodes=None, level=
     return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.int32, device=device or "cuda")
 
 
+def dqb_build_candidates(workspace, res, node_pos, knn, x_range=None):
+    """Fill the per-brick candidate node lists of a dqb_workspace (what fuse_volume_dqb does itself on a call with
+    rebuild_candidates=True); needed up front only by solve.sample_knn(..., bricks=...)."""
+    require_gpu()
+    lib = _lib.load()
+    if x_range is None:
+        x_range = (0, res[0])
+    P = node_pos if isinstance(node_pos, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(node_pos, dtype=np.float64)))
+    P = P.to(device="cuda", dtype=torch.float64).contiguous()
+    _lib.check(lib.dfh_dqb_build_candidates(_lib.iarr(res), int(x_range[0]), int(x_range[1]), P.data_ptr(), int(P.shape[0]), int(knn),
+                                            workspace.data_ptr(), workspace.numel() * 4, current_stream_ptr()), "dfh_dqb_build_candidates")
+    return workspace
+
+
 def _node_tensors(node_pos, node_dq, node_w):
     def prep(a, shape_tail):
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64)))

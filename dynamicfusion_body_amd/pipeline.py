@@ -43,7 +43,7 @@ def extract_surface_samples_torch(T, Wt, band, x0=0, max_samples=None):
     """Same samples on torch ops (works on CPU tensors).  Band voxels of a slab
     starting at global plane x0 -> (surface points (S,3) in global index space, unit normals).
     Normals are central differences of T inside the slab (one-sided at its faces); points are the
-    voxel centres moved onto the zero level set by one Newton step, centre - T grad / |grad|^2."""
+    voxel centres moved onto the zero level set by one Newton step, centre - T grad / |grad|^2, of length <= |T|."""
     Tf = T.to(torch.float64)
     mask = (Wt > 0) & (Tf.abs() < band)
     idx = mask.nonzero(as_tuple=False)
@@ -65,7 +65,7 @@ def extract_surface_samples_torch(T, Wt, band, x0=0, max_samples=None):
     n = g / nrm
     pos = idx.to(torch.float64)
     pos[:, 0] += x0
-    pos = pos - (Tf[idx[:, 0], idx[:, 1], idx[:, 2]][:, None] / nrm) * n          # one Newton step: T grad / |grad|^2
+    pos = pos - (Tf[idx[:, 0], idx[:, 1], idx[:, 2]][:, None] / nrm.clamp(min=1.0)) * n   # one Newton step: T grad / |grad|^2, no longer than |T|
     return pos.contiguous(), n.contiguous()
 
 
@@ -84,9 +84,11 @@ class FrameSolver:
         node_nbr, _ = sample_knn(node_pos, node_pos, node_w, self.knn)        # a node's own k nearest nodes
         self.solver.set_graph(node_pos, node_dq, node_w, node_nbr=node_nbr)
 
-    def set_canonical(self, T, Wt, band=1.0, x0=0, max_samples=None):
+    def set_canonical(self, T, Wt, band=1.0, x0=0, max_samples=None, knn_bricks=None):
+        """knn_bricks: see solve.sample_knn (candidate lists of the K3 workspace: the samples' node search skips its
+        per-workgroup bounding-box pass)."""
         pos, nrm = extract_surface_samples(T, Wt, band, x0=x0, max_samples=max_samples)
-        self.solver.set_samples(pos, nrm)
+        self.solver.set_samples(pos, nrm, knn_bricks=knn_bricks)
         return pos.shape[0]
 
     def gn_iteration(self, depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.0):
@@ -133,6 +135,10 @@ class SlabFrame:
         ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
         self.fs.set_graph(node_pos, ident, node_w)
         self.ws_dqb = kernels.dqb_workspace((R, R, R), (self.a, self.b), knn=knn, n_nodes=N)
+        self.knn_bricks = None
+        if self.b > self.a:
+            kernels.dqb_build_candidates(self.ws_dqb, (R, R, R), node_pos, knn, (self.a, self.b))
+            self.knn_bricks = ((R, R, R), (self.a, self.b), self.ws_dqb)       # the samples' node search uses the same lists
         self._first = True
         self.ident_lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
 
@@ -147,14 +153,14 @@ class SlabFrame:
         neighbours' face planes come as a halo whose weight is 0 (they feed gradients, never samples), so the
         union over ranks is exactly the whole-grid sample set."""
         if self.ws == 1:
-            return self.fs.set_canonical(self.T, self.Wt, band=self.band, x0=self.a)
+            return self.fs.set_canonical(self.T, self.Wt, band=self.band, x0=self.a, knn_bricks=self.knn_bricks)
         lo, hi = self.D.halo_planes(self.T, self.R)
         Tp, Wp, x0 = [self.T], [self.Wt], self.a
         if lo is not None:
             Tp.insert(0, lo[None]); Wp.insert(0, torch.zeros_like(lo)[None]); x0 -= 1
         if hi is not None:
             Tp.append(hi[None]); Wp.append(torch.zeros_like(hi)[None])
-        return self.fs.set_canonical(torch.cat(Tp).contiguous(), torch.cat(Wp).contiguous(), band=self.band, x0=x0)
+        return self.fs.set_canonical(torch.cat(Tp).contiguous(), torch.cat(Wp).contiguous(), band=self.band, x0=x0, knn_bricks=self.knn_bricks)
 
     def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5, stage_ms=None):
         """Defaults (regulariser weight, LM damping, association gate and Huber threshold in voxels) are the ones under which the loop tracks

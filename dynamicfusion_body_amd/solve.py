@@ -124,14 +124,22 @@ def closest_correspondences(warped_pos, warped_nrm, live_verts, knn, tolerance):
     return corr, cost, keep
 
 
-def sample_knn(sample_pos, node_pos, node_w, knn):
-    """(nbr (S,k) int32, weights (S,k) fp64) of arbitrary points: k nearest nodes, nearest first."""
+def sample_knn(sample_pos, node_pos, node_w, knn, bricks=None):
+    """(nbr (S,k) int32, weights (S,k) fp64) of arbitrary points: k nearest nodes, nearest first.
+    bricks = (res, (x0, x1), workspace): look the candidates up in the per-brick lists of a fuse_volume_dqb workspace
+    whose lists were built for these node positions and this knn (kernels.dqb_build_candidates); same result."""
     require_gpu()
     lib = _lib.load()
     Sp, P, Wn = _f64(sample_pos, (3,)), _f64(node_pos, (3,)), _f64(node_w, ())
     S = Sp.shape[0]
     nbr = torch.empty((S, knn), dtype=torch.int32, device="cuda")
     wts = torch.empty((S, knn), dtype=torch.float64, device="cuda")
+    if bricks is not None:
+        res, (x0, x1), ws = bricks
+        _lib.check(lib.dfh_sample_knn_bricks(Sp.data_ptr(), S, P.data_ptr(), Wn.data_ptr(), P.shape[0], int(knn), _lib.iarr(res),
+                                             int(x0), int(x1), ws.data_ptr(), ws.numel() * ws.element_size(), nbr.data_ptr(),
+                                             wts.data_ptr(), current_stream_ptr()), "dfh_sample_knn_bricks")
+        return nbr, wts
     _lib.check(lib.dfh_sample_knn(Sp.data_ptr(), S, P.data_ptr(), Wn.data_ptr(), P.shape[0], int(knn), nbr.data_ptr(),
                                   wts.data_ptr(), current_stream_ptr()), "dfh_sample_knn")
     return nbr, wts
@@ -194,12 +202,12 @@ class WarpSolver:
         self._pattern_keys = None
 
     # -- samples -----------------------------------------------------------------------------
-    def set_samples(self, pos, nrm, nbr=None, weights=None, sort=True):
+    def set_samples(self, pos, nrm, nbr=None, weights=None, sort=True, knn_bricks=None):
         pos, nrm = _f64(pos, (3,)), _f64(nrm, (3,))
         if pos.shape[0] != nrm.shape[0]:
             raise ValueError("sample positions and normals disagree in length")
         if nbr is None:
-            nbr, weights = sample_knn(pos, self.node_pos, self.node_w, self.knn)
+            nbr, weights = sample_knn(pos, self.node_pos, self.node_w, self.knn, bricks=knn_bricks)
         else:
             nbr = _i32(nbr, (self.knn,))
             if weights is None:

@@ -154,6 +154,16 @@ int dfh_closest_correspondences(const double *warped_pos, const double *warped_n
  * graph is unchanged.  nbr_out: n_samples x knn int32; weights_out: n_samples x knn. */
 int dfh_sample_knn(const double *sample_pos, int n_samples, const double *node_pos, const double *node_w, int n_nodes,
                    int knn, int *nbr_out, double *weights_out, void *stream);
+/* The same through the per-brick candidate lists of a dfh_fuse_volume_dqb workspace (built for the same node_pos, knn,
+ * grid and slab by dfh_dqb_build_candidates or by a dfh_fuse_volume_dqb call with rebuild_candidates != 0): a point
+ * scans the list of the brick of its nearest voxel centre (the lists carry the head-room that makes this exact for
+ * off-lattice points); points outside the slab's lattice and bricks whose list overflowed scan every node.
+ * Same output as dfh_sample_knn, bit for bit. */
+int dfh_dqb_build_candidates(const int res[3], int x0, int x1, const double *node_pos, int n_nodes, int knn,
+                             void *workspace, size_t workspace_bytes, void *stream);
+int dfh_sample_knn_bricks(const double *sample_pos, int n_samples, const double *node_pos, const double *node_w,
+                          int n_nodes, int knn, const int res[3], int x0, int x1, const void *workspace,
+                          size_t workspace_bytes, int *nbr_out, double *weights_out, void *stream);
 
 /* Projective data association (not in the reference, which matches marching-cubes vertices through a
  * KD-tree, core/fusion.py:255-276): warp each sample with the current field (Fusion.warp), map index ->
@@ -229,7 +239,7 @@ int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step,
 /* ---- surface samples for the solve (stand-in for marching cubes, core/fusion.py:554-568) -----------
  * Every band voxel (w > 0, |T| < band; T in voxel units as fuseDepths stores it) whose TSDF gradient
  * (central differences inside the slab, one-sided at its faces) is non-zero yields one sample: position
- * = voxel centre - T * gradient / |gradient|^2 (one Newton step; global index space, plane 0 of the buffer is global plane x0), normal n =
+ * = voxel centre - T * gradient / (|gradient| * max(|gradient|, 1)) (one Newton step, never longer than |T|; global index space, plane 0 of the buffer is global plane x0), normal n =
  * gradient / |gradient|.  Samples come out in voxel order, deterministically.
  *   dfh_surface_count : per-block counts + exclusive scan into `workspace`, *total_out (device) = count
  *   dfh_surface_emit  : writes min(total, capacity) samples (n x 3 fp64 each); uses the same workspace. */

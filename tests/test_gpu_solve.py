@@ -76,6 +76,43 @@ def test_sample_knn_vs_oracle():
         assert np.abs(wts.cpu().numpy() - G.blend_weights(pts, npos[loc], nw[loc])).max() <= 1e-15 * 4
 
 
+@pytest.mark.parametrize("res,slab,N,k", [((32, 24, 40), (0, 32), 80, 4), ((20, 20, 36), (6, 15), 300, 4), ((16, 16, 16), (0, 16), 9, 8),
+                                          ((24, 24, 48), (0, 24), 40, 1)])
+def test_sample_knn_through_brick_lists(res, slab, N, k):
+    """dfh_sample_knn_bricks (candidate lists of the K3 workspace) == dfh_sample_knn, bit for bit: off-lattice points
+    (up to sqrt(3)/2 from a voxel centre), points outside the slab / grid (full scan), duplicate nodes (ties by node
+    index), a node cluster that overflows a brick's list."""
+    from dynamicfusion_body_amd import kernels
+    rng = np.random.default_rng(N + k)
+    hi = np.array(res) - 1.0
+    node_pos = rng.uniform(0, hi, size=(N, 3))
+    if N >= 300:
+        node_pos[:280] = np.array(res) / 2.0 + rng.normal(size=(280, 3)) * 1.2          # > 256 candidates around one brick
+    node_pos[N // 2] = node_pos[N // 3]                                                    # exact tie
+    node_w = rng.uniform(2.0, 5.0, size=N)
+    pts = [rng.uniform(-0.49, hi + 0.49, size=(6000, 3)),                                 # anywhere in the lattice's cells
+           np.rint(rng.uniform(0, hi, size=(500, 3))) + rng.choice([-0.5, 0.5], size=(500, 3)),   # cell corners: rounding edge
+           rng.uniform(-6, hi + 6, size=(500, 3)),                                         # partly outside the grid
+           node_pos[:50] + 0.0]                                                            # on nodes: zero distance
+    pts = np.concatenate(pts)
+    ws = kernels.dqb_workspace(res, slab, knn=k, n_nodes=N)
+    kernels.dqb_build_candidates(ws, res, node_pos, k, slab)
+    nbr0, w0 = solve.sample_knn(pts, node_pos, node_w, k)
+    nbr1, w1 = solve.sample_knn(pts, node_pos, node_w, k, bricks=(res, slab, ws))
+    assert torch.equal(nbr0, nbr1) and torch.equal(w0, w1)
+    inside = np.all((np.rint(pts) >= [slab[0], 0, 0]) & (np.rint(pts) <= [slab[1] - 1, hi[1], hi[2]]), axis=1)
+    assert inside.any() and (~inside).any()
+    # the lists really are used: they are short compared with N on most bricks
+    cnt = ws.view(torch.int32)[:(ws.numel())].cpu().numpy()
+    nb = (-(-(slab[1] - slab[0]) // 4)) * (-(-res[1] // 4)) * (-(-res[2] // 16))
+    counts = cnt[:nb * 257].reshape(nb, 257)[:, 0]
+    assert counts.max() <= 256
+    if N >= 300:
+        assert (counts < 0).any()                                                          # the overflow path was exercised
+    else:
+        assert (counts >= 0).all() and (counts < N).any() or N <= 2 * k
+
+
 def make_solver(npos, ndq, nw, nbr, vidx, verts, norms, corr, knn, pcg_iters=400, sort=True, valid=None):
     sv = solve.WarpSolver(knn=knn, pcg_iters=pcg_iters)
     sv.set_graph(npos, ndq, nw, node_nbr=nbr[vidx])

@@ -34,6 +34,7 @@ def t(fn, n=5):
     return (time.perf_counter() - t0) / n * 1e3, r
 ms, (pos, nrm) = t(lambda: extract_surface_samples(sf.T, sf.Wt, 4.0)); print("extract        %.3f ms  (%d samples)" % (ms, pos.shape[0]))
 ms, (nbr, wts) = t(lambda: sample_knn(pos, sv.node_pos, sv.node_w, 4)); print("sample_knn     %.3f ms" % ms)
+ms, _ = t(lambda: sample_knn(pos, sv.node_pos, sv.node_w, 4, bricks=sf.knn_bricks)); print("sample_knn via brick lists %.3f ms" % ms)
 ms, _ = t(lambda: sv.set_samples(pos, nrm, nbr=nbr, weights=wts)); print("set_samples    %.3f ms (sort by tuple + gathers)" % ms)
 ms, _ = t(lambda: sv._build_pattern()); print("pattern+plan   %.3f ms" % ms)
 ms, _ = t(lambda: sf.refresh_samples()); print("refresh total  %.3f ms" % ms)

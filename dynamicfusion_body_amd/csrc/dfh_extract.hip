@@ -68,32 +68,62 @@ __global__ __launch_bounds__(256) void surface_count_kernel(const VolT *__restri
     if (threadIdx.x == 0) block_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// exclusive scan of the block counts in place (single block), total -> *total_out
+// exclusive scan of the block counts in place (single workgroup), total -> *total_out.  16 K counts per round: every
+// thread takes 16 of them 1024 apart (coalesced, all loads in flight at once), waves scan by shuffles, wave 0 scans the
+// 256 wave totals, three barriers per round.
+constexpr int kScanE = 16;
 __global__ __launch_bounds__(1024) void surface_scan_kernel(int *__restrict__ block_count, int nblocks, long *__restrict__ total_out) {
-    __shared__ long part[1024];
-    const int t = threadIdx.x;
-    const int per = (nblocks + 1023) / 1024;
-    const int b0 = t * per, b1 = min(nblocks, b0 + per);
-    long s = 0;
-    for (int b = b0; b < b1; ++b) s += block_count[b];
-    part[t] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int o = 1; o < 1024; o <<= 1) {
-        const long add = t >= o ? part[t - o] : 0;
+    __shared__ long wtot[kScanE * 16];          // [chunk e][wave w] inclusive totals, chunk-major = scan order
+    __shared__ long woff[kScanE * 16 + 1];      // exclusive offsets of the same, [256] = the round's total
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    long carry = 0;
+    for (long base = 0; base < nblocks; base += 1024 * kScanE) {
+        int v[kScanE];
+        long inc[kScanE];
+#pragma unroll
+        for (int e = 0; e < kScanE; ++e) {
+            const long idx = base + (long)e * 1024 + t;
+            v[e] = idx < nblocks ? block_count[idx] : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < kScanE; ++e) {
+            long x = v[e];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const long y = __shfl_up(x, o, 64);
+                if (lane >= o) x += y;
+            }
+            inc[e] = x;
+            if (lane == 63) wtot[e * 16 + wv] = x;
+        }
         __syncthreads();
-        part[t] += add;
+        if (wv == 0) {                            // 256 partials, 4 consecutive ones per lane
+            long p0 = wtot[4 * lane], p1 = wtot[4 * lane + 1], p2 = wtot[4 * lane + 2], p3 = wtot[4 * lane + 3];
+            long x = p0 + p1 + p2 + p3;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const long y = __shfl_up(x, o, 64);
+                if (lane >= o) x += y;
+            }
+            const long ex = x - (p0 + p1 + p2 + p3);
+            woff[4 * lane] = ex;
+            woff[4 * lane + 1] = ex + p0;
+            woff[4 * lane + 2] = ex + p0 + p1;
+            woff[4 * lane + 3] = ex + p0 + p1 + p2;
+            if (lane == 63) woff[kScanE * 16] = x;
+        }
         __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kScanE; ++e) {
+            const long idx = base + (long)e * 1024 + t;
+            if (idx < nblocks) block_count[idx] = (int)(carry + woff[e * 16 + wv] + inc[e] - v[e]);   // capacity is checked by the host against the total
+        }
+        carry += woff[kScanE * 16];
+        __syncthreads();                          // wtot / woff are rewritten in the next round
     }
-    long run = t > 0 ? part[t - 1] : 0;
-    for (int b = b0; b < b1; ++b) {
-        const int c = block_count[b];
-        block_count[b] = (int)run;            // capacity is checked by the host against the total
-        run += c;
-    }
-    if (t == 1023) {
-        *total_out = part[1023];
-        block_count[nblocks] = (int)part[1023];          // sentinel: block b emits offset[b+1] - offset[b] samples
+    if (t == 0) {
+        *total_out = carry;
+        block_count[nblocks] = (int)carry;        // sentinel: block b emits offset[b+1] - offset[b] samples
     }
 }
 

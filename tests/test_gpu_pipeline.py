@@ -129,6 +129,21 @@ def test_device_extraction_matches_torch_definition(dtype):
         extract_surface_samples(Td, Wd[:2], 1.5)
 
 
+def test_device_extraction_more_than_one_scan_round():
+    """> 16 384 blocks of 1 024 voxels: the in-workgroup scan of the block counts takes a second (partial) round."""
+    from dynamicfusion_body_amd.pipeline import extract_surface_samples_torch
+    shape = (258, 256, 260)
+    ax = [torch.arange(s, device="cuda", dtype=torch.float64) for s in shape]
+    d = torch.sqrt((ax[0][:, None, None] - 130.3) ** 2 + (ax[1][None, :, None] - 127.6) ** 2 + (ax[2][None, None, :] - 131.1) ** 2)
+    Td = (d - 90.0).to(torch.float32).contiguous()
+    Wd = ((ax[0][:, None, None] + ax[1][None, :, None] * 3 + ax[2][None, None, :] * 7) % 5 != 0).to(torch.float32).contiguous()
+    pos, nrm = extract_surface_samples(Td, Wd, 1.5)
+    pt, nt = extract_surface_samples_torch(Td, Wd, 1.5)
+    assert pos.shape == pt.shape and pos.shape[0] > 100000
+    assert float((pos - pt).abs().max()) <= 1e-12 and float((nrm - nt).abs().max()) <= 1e-12
+    assert float(pos[-1, 0]) > 200.0                                     # samples behind the first 16 384 blocks are there
+
+
 def test_composed_frame_loop_tracks_without_drift():
     """pipeline.SlabFrame over 60 frames of a +-0.6 voxel oscillation (three-view live volumes, default damping /
     gate): the warp field follows the motion and does not drift, the band-sample count stays put.  (With a 4-voxel

@@ -336,12 +336,11 @@ class WarpSolver:
             self.n_rows = 0
             tup = torch.zeros((0, k), dtype=torch.int64, device=dev)
         else:
-            idx = torch.arange(S, device=dev)
-            head = torch.ones(S, dtype=torch.bool, device=dev)
-            differs = (self._tuple_key[1:] != self._tuple_key[:-1]) if self._tuple_key is not None else \
+            head = torch.empty(S, dtype=torch.bool, device=dev)
+            head[1:] = (self._tuple_key[1:] != self._tuple_key[:-1]) if self._tuple_key is not None else \
                 (self.snbr[1:] != self.snbr[:-1]).any(dim=1)
-            head[1:] = differs | ((idx[1:] // 256) != (idx[:-1] // 256))
-            self.run_id = i32(torch.cumsum(head, 0) - 1)
+            head[::256] = True                                        # a row never spans two 256-sample tiles
+            self.run_id = torch.cumsum(head, 0, dtype=torch.int32).sub_(1)
             tup = self.snbr[head].long()
             self.n_rows = int(tup.shape[0])
         R = self.n_rows
@@ -353,11 +352,10 @@ class WarpSolver:
             key = (tup[:, :, None] * N + tup[:, None, :]).reshape(-1)
             blk = torch.searchsorted(keys, key)
             found.append((key, (keys[blk.clamp(max=keys.numel() - 1)] == key).all()))     # every pair is a block of the pattern?
-            order = torch.argsort(blk, stable=True)
-            bp = i32(torch.searchsorted(blk[order].contiguous(), torch.arange(self.B + 1, device=dev)))
-            node = tup.reshape(-1)
-            order2 = torch.argsort(node, stable=True)
-            npt = i32(torch.searchsorted(node[order2].contiguous(), torch.arange(N + 1, device=dev)))
+            sblk, order = torch.sort(blk.to(torch.int32), stable=True)                     # 32-bit keys: half the sort traffic
+            bp = torch.searchsorted(sblk, torch.arange(self.B + 1, device=dev, dtype=torch.int32), out_int32=True)
+            snode, order2 = torch.sort(tup.reshape(-1).to(torch.int32), stable=True)
+            npt = torch.searchsorted(snode, torch.arange(N + 1, device=dev, dtype=torch.int32), out_int32=True)
             return bp, i32(order), npt, i32(order2)
 
         self.blk_ptr, self.blk_ent, self.node_ptr, self.node_ent = lists(tup)

@@ -31,6 +31,7 @@ def test_slab_range_covers_exactly():
     assert torch.equal(D.union_sorted_keys(torch.tensor([5, 1, 5, 3])), torch.tensor([1, 3, 5]))
     v = torch.zeros(4, 2, 2)
     assert D.allgather_planes(v, 4) is v and D.halo_planes(v, 4) == (None, None)
+    assert D.all_ranks(True) is True and D.all_ranks(False) is False
 
 
 def _free_port():
@@ -60,6 +61,8 @@ def _worker(rank, ws, port, out):
         assert torch.equal(part, full)
         mx = D.max_over_ranks([float(rank), 1.0 - rank])
         assert mx == [float(ws - 1), 1.0]
+        # collective decisions (keep / rebuild the block pattern): true only if true on every rank
+        assert D.all_ranks(True) is True and D.all_ranks(rank == 0) is False and D.all_ranks(False) is False
         # live volume: slabs -> whole volume on every rank (even and uneven plane counts)
         for planes in (10, 7):
             vol = torch.arange(planes * 3 * 2, dtype=torch.float32).reshape(planes, 3, 2)

@@ -128,23 +128,16 @@ __device__ __forceinline__ void pack_coords(const IntegrateParams &p, int &y, in
 // STRIDED: the 4 voxels of a lane are z, z+64, z+128, z+192 of its wave's 256-voxel run instead of
 // 4 consecutive ones, so that in every depth gather and every T/w access consecutive lanes touch
 // consecutive voxels (a gather instruction then spans ~6-12 cache lines instead of ~50).
+//
+// view_pack: one depth view's contribution to the VEC voxels (x, y, z0 + j*ZS): ms[j] = min(tdist, sd) / scale and
+// upd[j] = the reference's update condition; returns whether any voxel of the pack is updated.
 template <typename DepthT, int VEC, bool PINHOLE, bool STRIDED>
-__global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict__ tsdf,
-                                                               float *__restrict__ tsdf_w,
-                                                               const DepthT *__restrict__ depth,
-                                                               const IntegrateParams p) {
-    int y, zp;
-    pack_coords(p, y, zp);
-    if (y >= p.Y) return;
-    const int lane = threadIdx.x & 63;
-    const int z0 = STRIDED ? (zp - lane) * VEC + lane : zp * VEC;
+__device__ __forceinline__ bool view_pack(const IntegrateParams &p, const DepthT *__restrict__ depth, int x, int y, int z0,
+                                          float (&ms)[VEC], bool (&upd)[VEC]) {
     constexpr int ZS = STRIDED ? 64 : 1;                 // z step between a lane's voxels
     constexpr int NC = PINHOLE ? 3 : 4;
     const unsigned ulim = (unsigned)(p.W - 1) << kFixShift;
     const unsigned vlim = (unsigned)(p.H - 1) << kFixShift;
-    const int xl_end = min(p.nx, (int)(blockIdx.y + 1) * p.planes_per_block);
-  for (int xl = blockIdx.y * p.planes_per_block; xl < xl_end; ++xl) {
-    const int x = p.x0 + xl;
     double base[NC];
     {
         const double xf = (double)x, yf = (double)y, zf = (double)z0;
@@ -187,8 +180,6 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
 #pragma unroll
     for (int j = 0; j < VEC; ++j) dval[j] = depth[pix[j]];
     // phase 3: sd > -tdist on float32 differences; guard-banded voxels re-run exactly
-    float ms[VEC];              // min(tdist, sd) / scale
-    bool upd[VEC];
     bool any = false;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -234,21 +225,15 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
         upd[j] = ok;
         any = any | ok;
     }
-    if (!any) continue;
+    return any;
+}
 
-    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
-    using P = Pack<float, VEC>;
-    P t, w;
-    if (STRIDED) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) { t.v[j] = tsdf[off + j * ZS]; w.v[j] = tsdf_w[off + j * ZS]; }
-    } else {
-        t = *reinterpret_cast<const P *>(tsdf + off);
-        w = *reinterpret_cast<const P *>(tsdf_w + off);
-    }
+// T <- (T*w + m/scale)/(1+w);  w <- min(1+w, wmax)          (fusion_dm.py:209-210)
+template <int VEC>
+__device__ __forceinline__ void apply_pack(Pack<float, VEC> &t, Pack<float, VEC> &w, const float (&ms)[VEC], const bool (&upd)[VEC],
+                                           float wmax_f) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        // T <- (T*w + m/scale)/(1+w);  w <- min(1+w, wmax)          (fusion_dm.py:209-210)
         const float wt = w.v[j];
         const float d = wt + 1.0f;
         const float n = fmaf(t.v[j], wt, ms[j]);
@@ -256,18 +241,90 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
         float q = n * r;
         q = fmaf(fmaf(-d, q, n), r, q);
         t.v[j] = upd[j] ? q : t.v[j];
-        w.v[j] = upd[j] ? fminf(d, p.wmax_f) : wt;
+        w.v[j] = upd[j] ? fminf(d, wmax_f) : wt;
     }
-    if (STRIDED) {
+}
+
+template <typename DepthT, int VEC, bool PINHOLE, bool STRIDED>
+__global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict__ tsdf,
+                                                               float *__restrict__ tsdf_w,
+                                                               const DepthT *__restrict__ depth,
+                                                               const IntegrateParams p) {
+    int y, zp;
+    pack_coords(p, y, zp);
+    if (y >= p.Y) return;
+    const int lane = threadIdx.x & 63;
+    const int z0 = STRIDED ? (zp - lane) * VEC + lane : zp * VEC;
+    constexpr int ZS = STRIDED ? 64 : 1;
+    const int xl_end = min(p.nx, (int)(blockIdx.y + 1) * p.planes_per_block);
+    for (int xl = blockIdx.y * p.planes_per_block; xl < xl_end; ++xl) {
+        float ms[VEC];              // min(tdist, sd) / scale
+        bool upd[VEC];
+        if (!view_pack<DepthT, VEC, PINHOLE, STRIDED>(p, depth, p.x0 + xl, y, z0, ms, upd)) continue;
+        const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
+        using P = Pack<float, VEC>;
+        P t, w;
+        if (STRIDED) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            if (upd[j]) { tsdf[off + j * ZS] = t.v[j]; tsdf_w[off + j * ZS] = w.v[j]; }
+            for (int j = 0; j < VEC; ++j) { t.v[j] = tsdf[off + j * ZS]; w.v[j] = tsdf_w[off + j * ZS]; }
+        } else {
+            t = *reinterpret_cast<const P *>(tsdf + off);
+            w = *reinterpret_cast<const P *>(tsdf_w + off);
         }
-    } else {
-        *reinterpret_cast<P *>(tsdf + off) = t;
-        *reinterpret_cast<P *>(tsdf_w + off) = w;
+        apply_pack<VEC>(t, w, ms, upd, p.wmax_f);
+        if (STRIDED) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                if (upd[j]) { tsdf[off + j * ZS] = t.v[j]; tsdf_w[off + j * ZS] = w.v[j]; }
+            }
+        } else {
+            *reinterpret_cast<P *>(tsdf + off) = t;
+            *reinterpret_cast<P *>(tsdf_w + off) = w;
+        }
     }
-  }
+}
+
+// Several depth views in ONE sweep of the volume (FusionDM.compute_live_tsdf / the initial fusion loop call fuseDepths
+// once per view, core/fusion_dm.py:152-154,166-170): a voxel's T and w are read once, take the views' updates in view
+// order in registers -- the same float32 operations as consecutive single-view sweeps, hence the same bits -- and are
+// written once.  HBM traffic per view drops from 16 B/voxel to 16/V; the projection work per view stays.
+constexpr int kMaxViews = 16;
+struct ViewPtrs {
+    const void *depth[kMaxViews];
+    int n;
+};
+
+template <typename DepthT, int VEC, bool PINHOLE>
+__global__ __launch_bounds__(256) void integrate_depth_multi_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                     const IntegrateParams *__restrict__ views, const ViewPtrs vp) {
+    int y, zp;
+    pack_coords(views[0], y, zp);                        // grid geometry is the same for every view
+    if (y >= views[0].Y) return;
+    const int z0 = zp * VEC;
+    const int nx = views[0].nx, ppb = views[0].planes_per_block;
+    const int xl_end = min(nx, (int)(blockIdx.y + 1) * ppb);
+    for (int xl = blockIdx.y * ppb; xl < xl_end; ++xl) {
+        using P = Pack<float, VEC>;
+        P t, w;
+        bool loaded = false;
+        const size_t off = ((size_t)xl * views[0].Y + y) * views[0].Z + z0;
+        for (int v = 0; v < vp.n; ++v) {
+            const IntegrateParams &p = views[v];         // uniform address: scalar loads
+            float ms[VEC];
+            bool upd[VEC];
+            if (!view_pack<DepthT, VEC, PINHOLE, false>(p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd)) continue;
+            if (!loaded) {
+                t = *reinterpret_cast<const P *>(tsdf + off);
+                w = *reinterpret_cast<const P *>(tsdf_w + off);
+                loaded = true;
+            }
+            apply_pack<VEC>(t, w, ms, upd, p.wmax_f);
+        }
+        if (loaded) {
+            *reinterpret_cast<P *>(tsdf + off) = t;
+            *reinterpret_cast<P *>(tsdf_w + off) = w;
+        }
+    }
 }
 
 // Any volume dtype: the reference's chain evaluated exactly for every voxel.
@@ -382,6 +439,34 @@ static void fold_affine(IntegrateParams &p) {
     p.wmax_f = (float)p.wmax;
 }
 
+// One view's parameters (shared by the single- and the multi-view entry points); returns whether K is a pinhole matrix.
+static bool fill_params(IntegrateParams &p, const int res[3], int tsdf_res, int x0, int x1, int H, int W, const double K[9],
+                        const double Kinv[9], const double lw[12], double scale, const double center[3], double tdist,
+                        double wmax, bool vec4) {
+    for (int i = 0; i < 9; ++i) { p.K.m[i] = K[i]; p.Kinv.m[i] = Kinv[i]; }
+    for (int i = 0; i < 12; ++i) p.lw.m[i] = lw[i];
+    p.scale = scale; p.cx = center[0]; p.cy = center[1]; p.cz = center[2];
+    p.half = (double)tsdf_res / 2.0;                    // np.zeros(3) + tsdf_res/2 (:183)
+    p.tdist = tdist; p.wmax = wmax;
+    p.X = res[0]; p.Y = res[1]; p.Z = res[2];
+    p.x0 = x0; p.nx = x1 - x0; p.H = H; p.W = W;
+    p.zpacks = vec4 ? res[2] / 4 : res[2];
+    p.zp_shift = -1;
+    for (int b = 0; b < 31; ++b) if (p.zpacks == (1 << b)) p.zp_shift = b;
+    fold_affine(p);
+    {   // ~kTargetBlocks blocks in total, each looping over consecutive x planes
+        const long per_plane_blocks = ((long)p.Y * p.zpacks + 255) / 256;
+        long chunks = (kTargetBlocks + per_plane_blocks - 1) / per_plane_blocks;
+        if (chunks < 1) chunks = 1;
+        if (chunks > p.nx) chunks = p.nx;
+        p.planes_per_block = (int)((p.nx + chunks - 1) / chunks);
+        const char *env = getenv("DFH_PLANES_PER_BLOCK");       // tuning knob for kbench sweeps
+        if (env && atoi(env) > 0) p.planes_per_block = atoi(env);
+    }
+    return K[1] == 0.0 && K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0 && K[8] == 1.0 && Kinv[6] == 0.0 && Kinv[7] == 0.0 &&
+           Kinv[8] == 1.0;
+}
+
 }  // namespace dfh
 
 extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3],
@@ -401,31 +486,10 @@ extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, cons
     if (x1 == x0) return DFH_OK;
 
     IntegrateParams p;
-    for (int i = 0; i < 9; ++i) { p.K.m[i] = K[i]; p.Kinv.m[i] = Kinv[i]; }
-    for (int i = 0; i < 12; ++i) p.lw.m[i] = lw[i];
-    p.scale = scale; p.cx = center[0]; p.cy = center[1]; p.cz = center[2];
-    p.half = (double)tsdf_res / 2.0;                    // np.zeros(3) + tsdf_res/2 (:183)
-    p.tdist = tdist; p.wmax = wmax;
-    p.X = res[0]; p.Y = res[1]; p.Z = res[2];
-    p.x0 = x0; p.nx = x1 - x0; p.H = H; p.W = W;
-    const bool pinhole = K[1] == 0.0 && K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0 && K[8] == 1.0 &&
-                         Kinv[6] == 0.0 && Kinv[7] == 0.0 && Kinv[8] == 1.0;
     const size_t esz = vol_dtype == DFH_F32 ? 4 : 8;
     const bool vec4 = (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) && ((uintptr_t)tsdf_w % (4 * esz) == 0) &&
                       !getenv("DFH_FORCE_SCALAR");
-    p.zpacks = vec4 ? res[2] / 4 : res[2];
-    p.zp_shift = -1;
-    for (int b = 0; b < 31; ++b) if (p.zpacks == (1 << b)) p.zp_shift = b;
-    fold_affine(p);
-    {   // ~kTargetBlocks blocks in total, each looping over consecutive x planes
-        const long per_plane_blocks = ((long)p.Y * p.zpacks + 255) / 256;
-        long chunks = (kTargetBlocks + per_plane_blocks - 1) / per_plane_blocks;
-        if (chunks < 1) chunks = 1;
-        if (chunks > p.nx) chunks = p.nx;
-        p.planes_per_block = (int)((p.nx + chunks - 1) / chunks);
-        const char *env = getenv("DFH_PLANES_PER_BLOCK");       // tuning knob for kbench sweeps
-        if (env && atoi(env) > 0) p.planes_per_block = atoi(env);
-    }
+    const bool pinhole = fill_params(p, res, tsdf_res, x0, x1, H, W, K, Kinv, lw, scale, center, tdist, wmax, vec4);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // fixed-point pixel coordinates need (dim-1) << 20 to fit in int32
     const bool fast_ok = H <= kFastMaxDim && W <= kFastMaxDim && scale > 0.0 && tdist > 0.0;
@@ -444,4 +508,64 @@ extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, cons
     if (depth_dtype == DFH_F32) { DFH_DISPATCH(double, float, false); }
     DFH_DISPATCH(double, double, false);
 #undef DFH_DISPATCH
+}
+
+extern "C" size_t dfh_integrate_multi_workspace_bytes(int n_views) {
+    return n_views > 0 ? (size_t)n_views * sizeof(dfh::IntegrateParams) : 0;
+}
+
+extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
+                                         int n_views, const void *const *depth, int depth_dtype, int H, int W,
+                                         const double K[9], const double Kinv[9], const double *lw, double scale,
+                                         const double center[3], double tdist, double wmax, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_views >= 0 && n_views <= kMaxViews, "dfh_integrate_depth_multi: %d views (at most %d per call)", n_views, kMaxViews);
+    if (n_views == 0) return DFH_OK;
+    DFH_REQUIRE(tsdf && tsdf_w && depth && res && K && Kinv && lw && center, "dfh_integrate_depth_multi: null pointer");
+    for (int v = 0; v < n_views; ++v) DFH_REQUIRE(depth[v], "dfh_integrate_depth_multi: depth map %d is null", v);
+    DFH_REQUIRE(vol_dtype == DFH_F32 || vol_dtype == DFH_F64, "dfh_integrate_depth_multi: bad vol_dtype %d", vol_dtype);
+    DFH_REQUIRE(depth_dtype == DFH_F32 || depth_dtype == DFH_F64, "dfh_integrate_depth_multi: bad depth_dtype %d", depth_dtype);
+    const size_t esz = vol_dtype == DFH_F32 ? 4 : 8;
+    const bool vec4 = res[0] > 0 && res[1] > 0 && res[2] > 0 && (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) &&
+                      ((uintptr_t)tsdf_w % (4 * esz) == 0) && !getenv("DFH_FORCE_SCALAR");
+    const bool fast_ok = vol_dtype == DFH_F32 && H <= kFastMaxDim && W <= kFastMaxDim && scale > 0.0 && tdist > 0.0 &&
+                         workspace && workspace_bytes >= dfh_integrate_multi_workspace_bytes(n_views) && !getenv("DFH_K1_NO_MULTI");
+    if (!fast_ok || n_views == 1 || x1 <= x0) {
+        // one sweep per view: the same results (every argument is checked there)
+        for (int v = 0; v < n_views; ++v) {
+            const int rc = dfh_integrate_depth(tsdf, tsdf_w, vol_dtype, res, tsdf_res, x0, x1, depth[v], depth_dtype, H, W, K, Kinv,
+                                               lw + 12 * v, scale, center, tdist, wmax, stream);
+            if (rc != DFH_OK) return rc;
+        }
+        return DFH_OK;
+    }
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0, "dfh_integrate_depth_multi: bad grid %dx%dx%d", res[0], res[1], res[2]);
+    DFH_REQUIRE(0 <= x0 && x0 <= x1 && x1 <= res[0], "dfh_integrate_depth_multi: slab [%d,%d) outside [0,%d)", x0, x1, res[0]);
+    DFH_REQUIRE(H >= 2 && W >= 2 && (long)H * W < (1L << 31), "dfh_integrate_depth_multi: bad depth map size %dx%d", H, W);
+    DFH_REQUIRE(x1 - x0 <= 65535, "dfh_integrate_depth_multi: slab has more than 65535 planes");
+    IntegrateParams hp[kMaxViews];
+    ViewPtrs vp;
+    bool pinhole = true;
+    for (int v = 0; v < n_views; ++v) {
+        pinhole = fill_params(hp[v], res, tsdf_res, x0, x1, H, W, K, Kinv, lw + 12 * v, scale, center, tdist, wmax, vec4) && pinhole;
+        vp.depth[v] = depth[v];
+    }
+    vp.n = n_views;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DFH_HIP_CHECK(hipMemcpyAsync(workspace, hp, sizeof(IntegrateParams) * n_views, hipMemcpyHostToDevice, s));   // pageable source: staged before the call returns
+    const IntegrateParams &p = hp[0];
+    dim3 grid((unsigned)(((long)p.Y * p.zpacks + 255) / 256), (unsigned)((p.nx + p.planes_per_block - 1) / p.planes_per_block)), block(256);
+    const IntegrateParams *dv = static_cast<const IntegrateParams *>(workspace);
+#define DFH_MULTI(DT, VEC, PH) hipLaunchKernelGGL((integrate_depth_multi_kernel<DT, VEC, PH>), grid, block, 0, s, (float *)tsdf, (float *)tsdf_w, dv, vp)
+    if (depth_dtype == DFH_F32) {
+        if (vec4) { if (pinhole) DFH_MULTI(float, 4, true); else DFH_MULTI(float, 4, false); }
+        else { if (pinhole) DFH_MULTI(float, 1, true); else DFH_MULTI(float, 1, false); }
+    } else {
+        if (vec4) { if (pinhole) DFH_MULTI(double, 4, true); else DFH_MULTI(double, 4, false); }
+        else { if (pinhole) DFH_MULTI(double, 1, true); else DFH_MULTI(double, 1, false); }
+    }
+#undef DFH_MULTI
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
 }

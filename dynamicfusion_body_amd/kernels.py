@@ -1,6 +1,7 @@
 """Tensor-level entry points: device tensors in, updated in place, asynchronous on the
 current HIP stream.  Each function is one call through the C ABI (include/dfusion_hip.h);
 the reference-shaped classes in fusion_dm.py / fusion.py are built on these."""
+import ctypes
 import numpy as np
 import torch
 
@@ -51,6 +52,49 @@ def integrate_depth(T, Wt, depth, K, Kinv, lw, scale, center, tdist, wmax=100.0,
                                  float(scale), _lib.darr(np.asarray(center, dtype=np.float64), 3),
                                  float(tdist), float(wmax), current_stream_ptr())
     _lib.check(rc, "dfh_integrate_depth")
+    return T, Wt
+
+
+def integrate_depth_views(T, Wt, depths, K, Kinv, lws, scale, center, tdist, wmax=100.0, tsdf_res=None, res=None,
+                          x_range=None, workspace=None):
+    """Several views in one sweep of the volume (dfh_integrate_depth_multi): same result, bit for bit, as
+    integrate_depth called once per view in this order (what the reference's loops over fuseDepths do,
+    core/fusion_dm.py:152-154,166-170), with T and w read and written once.  depths: list of (H, W) CUDA tensors of one
+    shape and dtype; lws: list of 3x4 extrinsics.  More than 16 views are taken 16 at a time."""
+    require_gpu()
+    lib = _lib.load()
+    depths, lws = list(depths), list(lws)
+    if len(depths) != len(lws):
+        raise ValueError('length of camera matrix array must equal that of depth maps')        # core/fusion_dm.py:96-97
+    if res is None:
+        res = tuple(T.shape)
+    if x_range is None:
+        x_range = (0, res[0])
+    if tsdf_res is None:
+        tsdf_res = res[0]
+    _check_volume_pair(T, Wt, res, x_range)
+    if x_range[1] == x_range[0] or not depths:
+        return T, Wt
+    for d in depths:
+        if not (isinstance(d, torch.Tensor) and d.is_cuda and d.dim() == 2 and d.is_contiguous()):
+            raise ValueError("depth must be a contiguous 2-D CUDA tensor")
+        if d.shape != depths[0].shape or d.dtype != depths[0].dtype:
+            raise ValueError("all depth maps of one call must have the same shape and dtype")
+    H, W = depths[0].shape
+    for i in range(0, len(depths), 16):
+        dd, ll = depths[i:i + 16], lws[i:i + 16]
+        n = len(dd)
+        nbytes = lib.dfh_integrate_multi_workspace_bytes(n)
+        ws = workspace if (workspace is not None and workspace.numel() * workspace.element_size() >= nbytes) else \
+            torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=T.device)
+        ptrs = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dd])
+        lw_flat = np.concatenate([np.asarray(l, dtype=np.float64).reshape(12) for l in ll])
+        rc = lib.dfh_integrate_depth_multi(T.data_ptr(), Wt.data_ptr(), dtype_code(T), _lib.iarr(res), int(tsdf_res), int(x_range[0]),
+                                           int(x_range[1]), n, ptrs, dtype_code(dd[0]), int(H), int(W), _lib.darr(K, 9),
+                                           _lib.darr(Kinv, 9), _lib.darr(lw_flat, 12 * n), float(scale),
+                                           _lib.darr(np.asarray(center, dtype=np.float64), 3), float(tdist), float(wmax),
+                                           ws.data_ptr(), ws.numel() * ws.element_size(), current_stream_ptr())
+        _lib.check(rc, "dfh_integrate_depth_multi")
     return T, Wt
 
 

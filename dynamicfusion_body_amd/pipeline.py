@@ -135,6 +135,7 @@ class SlabFrame:
         ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
         self.fs.set_graph(node_pos, ident, node_w)
         self.ws_dqb = kernels.dqb_workspace((R, R, R), (self.a, self.b), knn=knn, n_nodes=N)
+        self.ws_views = torch.empty(16 * 128, dtype=torch.int64, device="cuda")        # dfh_integrate_depth_multi's per-view parameters
         self.knn_bricks = None
         if self.b > self.a:
             kernels.dqb_build_candidates(self.ws_dqb, (R, R, R), node_pos, knn, (self.a, self.b))
@@ -187,9 +188,8 @@ class SlabFrame:
         depth, lw_cam = depth_list[0], lw_list[0]
         self.live.fill_(self.tvox)
         self.live_w.zero_()
-        for d_, l_ in zip(depth_list, lw_list):
-            kernels.integrate_depth(self.live, self.live_w, d_, self.K, self.Kinv, l_, self.scale, self.center, self.tdist_world,
-                                    tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b))
+        kernels.integrate_depth_views(self.live, self.live_w, depth_list, self.K, self.Kinv, lw_list, self.scale, self.center,
+                                      self.tdist_world, tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_views)
         mark("live_tsdf")
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
         mark("allgather")

@@ -68,6 +68,20 @@ int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3
                         double scale, const double center[3], double tdist, double wmax,
                         void *stream);
 
+/* The same for n_views depth maps in ONE sweep of the volume: what the reference's loops over fuseDepths do
+ * (core/fusion_dm.py:152-154 initial fusion, :166-170 compute_live_tsdf), with every voxel's T and w read once, updated
+ * view by view in registers -- the float32 operations of consecutive dfh_integrate_depth calls, so the same bits --
+ * and written once.  depth: HOST array of n_views device pointers (all H x W, depth_dtype); lw: n_views x 12.
+ * n_views <= 16.  workspace: device scratch of dfh_integrate_multi_workspace_bytes(n_views) bytes (the views'
+ * folded projection parameters); without it, for float64 volumes and for depth maps beyond 2048 pixels a side the call
+ * runs one sweep per view. */
+size_t dfh_integrate_multi_workspace_bytes(int n_views);
+int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
+                              int n_views, const void *const *depth, int depth_dtype, int H, int W,
+                              const double K[9], const double Kinv[9], const double *lw, double scale,
+                              const double center[3], double tdist, double wmax, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
 /* A3  FusionDM.updateTSDF(curr_tsdf, wmax)                     core/fusion_dm.py:300-316
  * For every canonical voxel i, x in [x0,x1):
  *   q = dqb_warp(lw_dq, float32(i))          (core/util.py:68-72; lw_dq = `_lw`, 8 doubles, voxel-index

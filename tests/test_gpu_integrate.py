@@ -128,6 +128,75 @@ def test_random_views_vs_oracle(res, hw, pinhole, ddt, wmax, reps, vol_dtype):
     assert (Wt > 0).any() and (Wt == 0).any()
 
 
+@pytest.mark.parametrize("vol_dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("res,hw,pinhole,ddt,wmax,reps", CASES)
+def test_multi_view_sweep_equals_consecutive_sweeps(res, hw, pinhole, ddt, wmax, reps, vol_dtype):
+    """dfh_integrate_depth_multi: all views in one sweep of the volume = one dfh_integrate_depth per view in the same
+    order, bit for bit (fp32 volumes: the fused kernel; fp64 volumes: the documented per-view fallback); whole grid
+    and slabs; with and without the caller's workspace."""
+    rng = np.random.default_rng(hash((res, hw, pinhole, 7)) % (2 ** 31))
+    H, W_ = hw
+    fx = 0.93 * W_ + 0.137
+    K = scene.intrinsics(fx, W_ / 2 - 0.2713, H / 2 + 0.1371)
+    if not pinhole:
+        K[0, 1] = 0.31
+        K[1, 1] = fx * 1.07
+    Kinv = np.linalg.inv(K)
+    scale = scene.GRID_SIDE / max(res)
+    center = scene.SPHERE_C + rng.normal(size=3) * 0.01
+    tdist = 3.3 * scale
+    nv = reps + 2
+    lws, dms = [], []
+    for r in range(nv):
+        lw = scene.view_extrinsic(float(rng.uniform(-60, 60)))
+        lw[:, 3] += rng.normal(size=3) * 0.02
+        lws.append(lw)
+        dms.append(torch.from_numpy(scene.render_depth(K, lw, H, W_, invalid_frac=0.05, seed=r)).to("cuda", dtype=ddt).contiguous())
+    T0 = torch.full(res, tdist / scale, dtype=vol_dtype, device="cuda")
+    W0 = torch.zeros(res, dtype=vol_dtype, device="cuda")
+    Ts, Ws = T0.clone(), W0.clone()
+    for d, lw in zip(dms, lws):
+        kernels.integrate_depth(Ts, Ws, d, K, Kinv, lw, scale, center, tdist, wmax=wmax)
+    assert float(Ws.max()) > 1.0                                         # voxels seen by several views exist
+    Tm, Wm = T0.clone(), W0.clone()
+    kernels.integrate_depth_views(Tm, Wm, dms, K, Kinv, lws, scale, center, tdist, wmax=wmax)
+    assert torch.equal(Tm, Ts) and torch.equal(Wm, Ws)
+    ws = torch.empty(4096, dtype=torch.int64, device="cuda")
+    T2, W2 = T0.clone(), W0.clone()
+    for a, b in ((0, 3), (3, res[0])):                                   # slabs, caller's workspace
+        Ta, Wa = T2[a:b].clone(), W2[a:b].clone()
+        kernels.integrate_depth_views(Ta, Wa, dms, K, Kinv, lws, scale, center, tdist, wmax=wmax, res=res, x_range=(a, b), workspace=ws)
+        T2[a:b] = Ta; W2[a:b] = Wa
+    assert torch.equal(T2, Ts) and torch.equal(W2, Ws)
+
+
+def test_multi_view_sweep_many_views_and_errors():
+    res, (H, W_) = (8, 12, 16), (32, 40)
+    K = scene.intrinsics(37.0, 19.7, 16.2)
+    Kinv = np.linalg.inv(K)
+    scale, center = scene.GRID_SIDE / 16, scene.SPHERE_C
+    tdist = 3.0 * scale
+    rng = np.random.default_rng(5)
+    lws = [scene.view_extrinsic(float(a)) for a in rng.uniform(-50, 50, size=19)]           # > 16: two calls inside
+    dms = [torch.from_numpy(scene.render_depth(K, lw, H, W_, dtype=np.float32)).cuda() for lw in lws]
+    T0 = torch.full(res, tdist / scale, dtype=torch.float32, device="cuda"); W0 = torch.zeros_like(T0)
+    Ts, Ws = T0.clone(), W0.clone()
+    for d, lw in zip(dms, lws):
+        kernels.integrate_depth(Ts, Ws, d, K, Kinv, lw, scale, center, tdist, wmax=5.0)
+    Tm, Wm = T0.clone(), W0.clone()
+    kernels.integrate_depth_views(Tm, Wm, dms, K, Kinv, lws, scale, center, tdist, wmax=5.0)
+    assert torch.equal(Tm, Ts) and torch.equal(Wm, Ws)
+    Te, We = T0.clone(), W0.clone()
+    kernels.integrate_depth_views(Te, We, [], K, Kinv, [], scale, center, tdist)            # no views: nothing happens
+    assert torch.equal(Te, T0) and torch.equal(We, W0)
+    with pytest.raises(ValueError):
+        kernels.integrate_depth_views(Te, We, dms[:2], K, Kinv, lws[:3], scale, center, tdist)      # fusion_dm.py:96-97
+    with pytest.raises(ValueError):
+        kernels.integrate_depth_views(Te, We, [dms[0], dms[1][:, :30].contiguous()], K, Kinv, lws[:2], scale, center, tdist)
+    with pytest.raises(ValueError):
+        kernels.integrate_depth_views(Te, We, [dms[0], dms[1].double()], K, Kinv, lws[:2], scale, center, tdist)
+
+
 def test_slab_sweeps_equal_full_sweep():
     """Slab partition along axis 0 (multi-GPU layout): per-slab buffers with global indices
     reproduce the full sweep bit for bit."""

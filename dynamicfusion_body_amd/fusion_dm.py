@@ -310,9 +310,17 @@ class FusionDM:
             T, Wt = self._T, self._Wt
         else:
             T, Wt = self._new_volume_pair()
-            for idx in range(len(depths)):                          # :166-170
-                self._depthidx = idx
-                self.fuseDepths(depths[idx], lws[idx], T, Wt, scale=12 * std / res, center=avg)
+            dev = [self._depth_to_device(d) for d in depths]
+            if len(dev) > 1 and len({(tuple(d.shape), d.dtype) for d in dev}) == 1 and \
+                    all(np.asarray(l).shape == (3, 4) for l in lws):
+                # the loop below as ONE sweep of the volume (same bits: kernels.integrate_depth_views)
+                kernels.integrate_depth_views(T, Wt, dev, self._K, self._Kinv, [np.asarray(l, dtype=np.float64) for l in lws],
+                                              12 * std / res, avg, self._tdist, 100.0, tsdf_res=self._tsdf_res)
+                self._depthidx = len(depths) - 1
+            else:
+                for idx in range(len(depths)):                      # :166-170
+                    self._depthidx = idx
+                    self.fuseDepths(dev[idx], lws[idx], T, Wt, scale=12 * std / res, center=avg)
             self._T, self._Wt = T, Wt
         if outputMesh:                                              # :174-176 (the reference also dumps tsdf_temp.npy; not done)
             self.write_canonical_mesh(mesh_path, 'test.obj')

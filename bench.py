@@ -357,6 +357,29 @@ def main():
     del src, dst
     out["roofline"]["copy_ceiling_GBps"] = ceil_gbs
     out["roofline"]["frac_of_copy_ceiling"] = achieved / ceil_gbs
+    # secondary number: the same views fused in ONE sweep of the volume (dfh_integrate_depth_multi; bit-identical to the
+    # consecutive sweeps timed above, compute-bound on the per-view projection -- never the headline `value`)
+    try:
+        Tm, Wm = torch.full_like(T, tdist), torch.zeros_like(Wt)
+        wsv = torch.empty(4096, dtype=torch.int64, device="cuda")
+
+        def sweep():
+            kernels.integrate_depth_views(Tm, Wm, depths, K, Kinv, lws, scale, center, tdist, 100.0, tsdf_res=tsdf_res, res=res,
+                                          x_range=x_range, workspace=wsv)
+        sweep(); torch.cuda.synchronize()
+        m0 = torch.cuda.Event(enable_timing=True); m1 = torch.cuda.Event(enable_timing=True)
+        reps = max(1, min(20, args.steps // len(lws)))
+        m0.record()
+        for _ in range(reps):
+            sweep()
+        m1.record(); torch.cuda.synchronize()
+        ms_sweep = m0.elapsed_time(m1) / reps
+        out["multi_view_sweep"] = {"views": len(lws), "ms_per_sweep": ms_sweep, "us_per_view": ms_sweep * 1e3 / len(lws),
+                                   "mvox_per_s_per_gpu": R * R * R * len(lws) / ms_sweep / 1e3,
+                                   "hbm_GBps_algorithmic": (16.0 * R * R * R + 4.0 * H * W * len(lws)) / (ms_sweep * 1e-3) / 1e9}
+        del Tm, Wm
+    except Exception as e:                                                   # a secondary figure must not lose the line
+        out["multi_view_sweep"] = {"error": repr(e)}
     tr = pmc_traffic("integrate_depth_kernel", R)
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]

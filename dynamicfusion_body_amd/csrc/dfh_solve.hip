@@ -584,6 +584,20 @@ __device__ __forceinline__ double data_row(const double *__restrict__ node_dq, c
 // ({upper triangle of its (6K)^2 Gram matrix | J^T r | 0.5 r^2 | count}, row = run_id[first sample]) and the
 // sums are STORED there; gn_gather_kernel then adds the rows into the blocks through a precomputed incidence
 // list: no floating-point atomics, same bits every run, about half the memory operations.
+// The regulariser's pair rows (gn_reg_pairs, below) are independent of the data rows: in the planned build they are
+// computed by extra workgroups appended to the data-row launch (blockIdx.x >= n_tiles) instead of a launch of their own.
+struct RegTail {
+    const int *node_nbr;        // NULL: no regulariser workgroups
+    const double *node_pos, *node_w;
+    double *partial_reg;
+    double rw;
+    int N, k, n_tiles;
+};
+__device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N, int k, const double *__restrict__ node_dq,
+                             const double *__restrict__ node_pos, const double *__restrict__ node_w, double rw,
+                             const int *__restrict__ row_ptr, const int *__restrict__ col, double *__restrict__ vals,
+                             double *__restrict__ rhs, double *__restrict__ cost_count, double *__restrict__ partial_reg);
+
 template <int K, bool PLANNED>
 __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
                                                              const int *__restrict__ nbr, const double *__restrict__ wts,
@@ -593,7 +607,13 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
                                                              const int *__restrict__ row_ptr, const int *__restrict__ col,
                                                              double *__restrict__ vals, double *__restrict__ rhs,
                                                              double *__restrict__ cost_count, const int *__restrict__ run_id,
-                                                             double *__restrict__ partial, double *__restrict__ tile_cost) {
+                                                             double *__restrict__ partial, double *__restrict__ tile_cost,
+                                                             const RegTail rt) {
+    if (PLANNED && (int)blockIdx.x >= rt.n_tiles) {      // (workgroup-uniform) the regulariser's share of this launch
+        gn_reg_pairs((int)blockIdx.x - rt.n_tiles, rt.node_nbr, rt.N, rt.k, node_dq, rt.node_pos, rt.node_w, rt.rw, row_ptr, col, vals,
+                     rhs, cost_count, rt.partial_reg);
+        return;
+    }
     constexpr int NJ = 6 * K;                   // Jacobian entries per sample
     constexpr int LD = NJ + 1;                  // + residual
     __shared__ double sJ[kTile * LD];
@@ -897,18 +917,15 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
 // Regularisation rows rho_ij = c_ij (W(q_i,v_j) - W(q_j,v_j)): one WAVE per (i, slot); lanes 0..35
 // own one entry (a,b) of the four 6x6 blocks (ii, jj, ij, ji), lanes 0..5 also the gradient, so the
 // ~150 fp64 atomics of a pair are issued side by side instead of one after the other.
-__global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict__ node_nbr, int N, int k,
-                                                            const double *__restrict__ node_dq,
-                                                            const double *__restrict__ node_pos,
-                                                            const double *__restrict__ node_w, double rw,
-                                                            const int *__restrict__ row_ptr, const int *__restrict__ col,
-                                                            double *__restrict__ vals, double *__restrict__ rhs,
-                                                            double *__restrict__ cost_count, double *__restrict__ partial_reg) {
+__device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N, int k, const double *__restrict__ node_dq,
+                             const double *__restrict__ node_pos, const double *__restrict__ node_w, double rw,
+                             const int *__restrict__ row_ptr, const int *__restrict__ col, double *__restrict__ vals,
+                             double *__restrict__ rhs, double *__restrict__ cost_count, double *__restrict__ partial_reg) {
     // partial_reg != NULL (planned build): the pair's {upper triangle of the 12x12 Gram matrix of [J_i | J_j] |
     // J^T rho | 0.5 rho^2 | 0} is STORED in row t (92 doubles) and gathered like a 2-node data row: no atomics.
     constexpr int NE2 = gn_row_stride(2), kLive2 = gn_row_entries(2);      // 96-double rows, live flag at [92]
     auto up = [](int pa, int pb) { return pa * 12 - (pa * (pa - 1)) / 2 + (pb - pa); };
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int t = block * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= N * k) return;
     const int i = t / k;
@@ -973,6 +990,16 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
         }
         if (lane == 0) atomicAdd(cost_count, 0.5 * ((rho[0] * rho[0] + rho[1] * rho[1]) + rho[2] * rho[2]));
     }
+}
+
+__global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict__ node_nbr, int N, int k,
+                                                            const double *__restrict__ node_dq,
+                                                            const double *__restrict__ node_pos,
+                                                            const double *__restrict__ node_w, double rw,
+                                                            const int *__restrict__ row_ptr, const int *__restrict__ col,
+                                                            double *__restrict__ vals, double *__restrict__ rhs,
+                                                            double *__restrict__ cost_count, double *__restrict__ partial_reg) {
+    gn_reg_pairs((int)blockIdx.x, node_nbr, N, k, node_dq, node_pos, node_w, rw, row_ptr, col, vals, rhs, cost_count, partial_reg);
 }
 
 // ------------------------------------------------------------------------------- PCG
@@ -1618,6 +1645,8 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
     }
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = (n_samples + kTile - 1) / kTile;
+    // planned build: the regulariser's pair rows ride along in the data-row launch (they only write partial_reg)
+    const bool reg_in_data_launch = planned_reg && node_nbr && rw != 0.0 && n_samples > 0 && !getenv("DFH_GN_REG_OWN_LAUNCH");
     double *tile_cost = planned && partial ? partial + (size_t)n_rows * gn_row_stride(knn) : nullptr;   // 2 doubles per tile, behind the rows
     if (planned) {
         // every block / rhs entry / cost is written by the gather, and every row of `partial` by the tile pass (rows
@@ -1635,15 +1664,21 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
         BuildParams p;
         for (int i = 0; i < 8; ++i) p.lw.q[i] = lw_dq[i];
         p.S = n_samples; p.k = knn; p.N = n_nodes; p.huber = huber_delta;
-        dim3 grid((n_samples + kTile - 1) / kTile), block(256);
+        RegTail rt = {};
+        rt.n_tiles = n_tiles;
+        if (reg_in_data_launch) {
+            rt.node_nbr = node_nbr; rt.node_pos = node_pos; rt.node_w = node_w; rt.partial_reg = partial_reg;
+            rt.rw = rw; rt.N = n_nodes; rt.k = knn;
+        }
+        dim3 grid((unsigned)(n_tiles + (reg_in_data_launch ? (n_nodes * knn + 3) / 4 : 0))), block(256);
 #define DFH_BUILD(KK)                                                                                               \
     case KK:                                                                                                        \
         if (planned)                                                                                                \
             hipLaunchKernelGGL((gn_build_data_kernel<KK, true>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
-                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost); \
+                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost, rt); \
         else                                                                                                        \
             hipLaunchKernelGGL((gn_build_data_kernel<KK, false>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
-                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost); \
+                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost, rt); \
         break
         switch (knn) {
             DFH_BUILD(1); DFH_BUILD(2); DFH_BUILD(3); DFH_BUILD(4); DFH_BUILD(5); DFH_BUILD(6); DFH_BUILD(7); DFH_BUILD(8);
@@ -1667,8 +1702,9 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
     }
     if (node_nbr && rw != 0.0) {
         const int n = n_nodes * knn;
-        hipLaunchKernelGGL(gn_build_reg_kernel, dim3((n + 3) / 4), dim3(256), 0, s, node_nbr, n_nodes, knn, node_dq, node_pos,
-                           node_w, rw, row_ptr, col, vals, rhs, cost_count, planned_reg ? partial_reg : nullptr);
+        if (!reg_in_data_launch)
+            hipLaunchKernelGGL(gn_build_reg_kernel, dim3((n + 3) / 4), dim3(256), 0, s, node_nbr, n_nodes, knn, node_dq, node_pos,
+                               node_w, rw, row_ptr, col, vals, rhs, cost_count, planned_reg ? partial_reg : nullptr);
         if (planned_reg) {
             dim3 grid((unsigned)((n_blocks + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
             hipLaunchKernelGGL(gn_gather_kernel<2>, grid, block, 0, s, partial_reg, n, rblk_ptr, rblk_ent, n_blocks, rnode_ptr,

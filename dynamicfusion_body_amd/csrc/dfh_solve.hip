@@ -781,23 +781,141 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     }
 }
 
-// Second half of the planned build.  Workgroups [0, n_blocks): one per 6x6 block (a,b); its four waves take
-// every fourth entry of the block's list (blk_ent = row * K^2 + sa * K + sb), lanes 0..35 own entry (ia, ib) of the
-// block, and the four partial sums are added in a fixed order.  Next workgroups: J^T r, one wave per node, lane
-// (j, i) takes every tenth entry of the node's list (node_ent = row * K + slot) for unknown i.  Last workgroup:
-// cost and valid count, a fixed-order tree over the rows.  Lists are walked two entries at a time so that the
-// dependent index -> value loads of consecutive entries overlap.
+// Second half of the planned build.  Workgroups [0, ceil(n_blocks/4)): one WAVE per 6x6 block (a,b), lanes 0..35 own
+// entry (ia, ib) of the block and add the block's list (blk_ent = row * K^2 + sa * K + sb) in list order.  Next
+// workgroups: J^T r, one wave per node, lane (j, i) takes every tenth entry of the node's list (node_ent = row * K +
+// slot) for unknown i.  Last workgroup: cost and valid count, a fixed-order tree over the {cost, count} pairs.
+// The regulariser's pair rows (K = 2 layout, own lists) are a second set of lists walked by the same wave right after
+// the data rows': value = data sum + regulariser sum, the two roundings of "store, then add in a second launch".
+
+// one wave: sum over block b's list of entry (ia, ib) of the rows' Gram matrices (lanes 0..35; others return 0)
+template <int K>
+__device__ __forceinline__ double gather_block_list(const double *__restrict__ partial, const int *__restrict__ blk_ptr,
+                                                    const int *__restrict__ blk_ent, int b, int lane, int wv) {
+    constexpr int NJ = 6 * K, NE = gn_row_stride(K), kLive = gn_row_entries(K);
+    const int beg = blk_ptr[b], end = blk_ptr[b + 1];
+    const int ia = (lane % 36) / 6, ib = lane % 6;
+    auto value = [&](int ent) {
+        const int row = ent / (K * K), pr = ent - row * (K * K);
+        int pa = (pr / K) * 6 + ia, pb = (pr % K) * 6 + ib;
+        if (pa > pb) { const int t = pa; pa = pb; pb = t; }
+        return partial[(size_t)row * NE + (pa * NJ - (pa * (pa - 1)) / 2 + (pb - pa))];
+    };
+    // The walk is a chain of dependent loads (entry -> live flag -> values), so it is organised by hops, not by
+    // entries: up to 256 entries and then their flags are fetched together (two hops), the live ones are compacted
+    // in list order into LDS, and lanes 0..35 (one per block entry) add them with 16 value loads in flight.
+    __shared__ int sLiveB[4][256];
+    double acc = 0.0;
+    for (int base = beg; base < end; base += 256) {
+        int ent[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ent[u] = base + 64 * u + lane < end ? blk_ent[base + 64 * u + lane] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) on[u] = ent[u] >= 0 && partial[(size_t)(ent[u] / (K * K)) * NE + kLive] != 0.0;
+        int nl = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long m = __ballot(on[u]);
+            if (on[u]) sLiveB[wv][nl + __popcll(m & ((1ull << lane) - 1ull))] = ent[u];
+            nl += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 36) {
+            int q = 0;
+            for (; q + 15 < nl; q += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = value(sLiveB[wv][q + u]);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += v[u];
+            }
+            for (; q + 3 < nl; q += 4) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = value(sLiveB[wv][q + u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += v[u];
+            }
+            for (; q < nl; ++q) acc += value(sLiveB[wv][q]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return acc;
+}
+
+// one wave: J^T r of node a from its list; the total for unknown i ends up in lanes 0..5
+template <int K>
+__device__ __forceinline__ double gather_node_list(const double *__restrict__ partial, const int *__restrict__ node_ptr,
+                                                   const int *__restrict__ node_ent, int a, int lane, int wv) {
+    constexpr int NJ = 6 * K, NUP = NJ * (NJ + 1) / 2, NE = gn_row_stride(K), kLive = gn_row_entries(K);
+    double acc = 0.0;
+    const int j = lane / 6, i = lane - 6 * j;                  // lanes 60..63 idle
+    __shared__ int sLive[4][64];
+    const int beg = node_ptr[a], end = node_ptr[a + 1];
+    for (int base = beg; base < end; base += 64) {
+        // 64 entries and their rows' live flags at once; the live ones, compacted in list order, are then taken
+        // ten at a time (lane group j takes the j-th of each ten) -- one value hop per ten entries
+        const int n = min(64, end - base);
+        int mine = lane < n ? node_ent[base + lane] : -1;
+        if (mine >= 0 && partial[(size_t)(mine / K) * NE + kLive] == 0.0) mine = -1;
+        const unsigned long long live = __ballot(mine >= 0);
+        if (mine >= 0) sLive[wv][__popcll(live & ((1ull << lane) - 1ull))] = mine;
+        __builtin_amdgcn_wave_barrier();
+        const int nl = __popcll(live);
+        if (j < 10) {
+            for (int m = j; m < nl; m += 10) {
+                const int ent = sLive[wv][m];
+                const int row = ent / K, slot = ent - row * K;
+                acc += partial[(size_t)row * NE + NUP + slot * 6 + i];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    double tot = acc;
+#pragma unroll
+    for (int k = 1; k < 10; ++k) {
+        const double o = __shfl(acc, lane + 6 * k, 64);
+        tot += (lane + 6 * k < 60) ? o : 0.0;
+    }
+    return tot;
+}
+
+// one workgroup: fixed-order sum of n_cc {cost, count} pairs cc_stride doubles apart; valid in thread 0
+__device__ __forceinline__ void gather_cost(const double *__restrict__ cc, int n_cc, int cc_stride, double (*red)[64], double &c0,
+                                            double &c1) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double c = 0.0, n = 0.0;
+    for (int r = (int)threadIdx.x; r < n_cc; r += 256) {
+        c += cc[(size_t)r * cc_stride];
+        n += cc[(size_t)r * cc_stride + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); n += __shfl_xor(n, o, 64); }
+    __syncthreads();                                   // `red` may still be read from a previous call
+    if (lane == 0) { red[0][wv] = c; red[1][wv] = n; }
+    __syncthreads();
+    c0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    c1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+}
+
+// the regulariser's lists for the same launch (partial == NULL: none)
+struct RegLists {
+    const double *partial;
+    const int *blk_ptr, *blk_ent, *node_ptr, *node_ent;
+    int n_rows;
+};
+
 template <int K>
 __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict__ partial, int n_rows, const int *__restrict__ blk_ptr,
                                                         const int *__restrict__ blk_ent, int n_blocks,
                                                         const int *__restrict__ node_ptr, const int *__restrict__ node_ent,
                                                         int n_nodes, double *__restrict__ vals, double *__restrict__ rhs,
                                                         double *__restrict__ cost_count, const double *__restrict__ cc, int n_cc,
-                                                        int cc_stride, bool accumulate, int only_part) {
+                                                        int cc_stride, bool accumulate, int only_part, const RegLists rl) {
     // cc: n_cc {cost, count} pairs, cc_stride doubles apart (per tile for the data term, per pair row for the regulariser)
     // only_part (debug timing): 0 = all, 1 = blocks, 2 = J^T r, 3 = cost
-    // accumulate: add to what is there (second gather of the same build: the regulariser rows) instead of storing
-    constexpr int NJ = 6 * K, NUP = NJ * (NJ + 1) / 2, NE = gn_row_stride(K), kLive = gn_row_entries(K);   // NE = row stride
+    // accumulate: add to what is there (a gather of its own for the regulariser rows) instead of storing
     const int nrw = (n_nodes + 3) / 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ double red[4][64];
@@ -807,107 +925,29 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
         if (part_of != only_part) return;
     }
     if ((int)blockIdx.x < nbw) {
-        // one wave per block: entries fetched 64 at a time (coalesced), traded by shuffle, eight value loads in flight
         const int b = (int)blockIdx.x * 4 + wv;
         if (b >= n_blocks) return;
-        const int beg = blk_ptr[b], end = blk_ptr[b + 1];
-        const int ia = (lane % 36) / 6, ib = lane % 6;
-        auto value = [&](int ent) {
-            const int row = ent / (K * K), pr = ent - row * (K * K);
-            int pa = (pr / K) * 6 + ia, pb = (pr % K) * 6 + ib;
-            if (pa > pb) { const int t = pa; pa = pb; pb = t; }
-            return partial[(size_t)row * NE + (pa * NJ - (pa * (pa - 1)) / 2 + (pb - pa))];
-        };
-        // The walk is a chain of dependent loads (entry -> live flag -> values), so it is organised by hops, not by
-        // entries: up to 256 entries and then their flags are fetched together (two hops), the live ones are compacted
-        // in list order into LDS, and lanes 0..35 (one per block entry) add them with 16 value loads in flight.
-        __shared__ int sLiveB[4][256];
-        double acc = 0.0;
-        for (int base = beg; base < end; base += 256) {
-            int ent[4];
-            bool on[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ent[u] = base + 64 * u + lane < end ? blk_ent[base + 64 * u + lane] : -1;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) on[u] = ent[u] >= 0 && partial[(size_t)(ent[u] / (K * K)) * NE + kLive] != 0.0;
-            int nl = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned long long m = __ballot(on[u]);
-                if (on[u]) sLiveB[wv][nl + __popcll(m & ((1ull << lane) - 1ull))] = ent[u];
-                nl += __popcll(m);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 36) {
-                int q = 0;
-                for (; q + 15 < nl; q += 16) {
-                    double v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = value(sLiveB[wv][q + u]);
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) acc += v[u];
-                }
-                for (; q + 3 < nl; q += 4) {
-                    double v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = value(sLiveB[wv][q + u]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc += v[u];
-                }
-                for (; q < nl; ++q) acc += value(sLiveB[wv][q]);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        double acc = gather_block_list<K>(partial, blk_ptr, blk_ent, b, lane, wv);
+        if (rl.partial) acc = acc + gather_block_list<2>(rl.partial, rl.blk_ptr, rl.blk_ent, b, lane, wv);
         if (lane < 36) {
             double *dst = vals + 36 * (size_t)b + lane;
             *dst = accumulate ? *dst + acc : acc;
         }
     } else if ((int)blockIdx.x < nbw + nrw) {
         const int a = ((int)blockIdx.x - nbw) * 4 + wv;
-        double acc = 0.0;
-        const int j = lane / 6, i = lane - 6 * j;                  // lanes 60..63 idle
-        __shared__ int sLive[4][64];
-        if (a < n_nodes) {
-            const int beg = node_ptr[a], end = node_ptr[a + 1];
-            for (int base = beg; base < end; base += 64) {
-                // 64 entries and their rows' live flags at once; the live ones, compacted in list order, are then taken
-                // ten at a time (lane group j takes the j-th of each ten) -- one value hop per ten entries
-                const int n = min(64, end - base);
-                int mine = lane < n ? node_ent[base + lane] : -1;
-                if (mine >= 0 && partial[(size_t)(mine / K) * NE + kLive] == 0.0) mine = -1;
-                const unsigned long long live = __ballot(mine >= 0);
-                if (mine >= 0) sLive[wv][__popcll(live & ((1ull << lane) - 1ull))] = mine;
-                __builtin_amdgcn_wave_barrier();
-                const int nl = __popcll(live);
-                if (j < 10) {
-                    for (int m = j; m < nl; m += 10) {
-                        const int ent = sLive[wv][m];
-                        const int row = ent / K, slot = ent - row * K;
-                        acc += partial[(size_t)row * NE + NUP + slot * 6 + i];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        double tot = acc;
-#pragma unroll
-        for (int k = 1; k < 10; ++k) {
-            const double o = __shfl(acc, lane + 6 * k, 64);
-            tot += (lane + 6 * k < 60) ? o : 0.0;
-        }
-        if (a < n_nodes && lane < 6) rhs[6 * a + lane] = accumulate ? rhs[6 * a + lane] + tot : tot;
+        if (a >= n_nodes) return;
+        double tot = gather_node_list<K>(partial, node_ptr, node_ent, a, lane, wv);
+        if (rl.partial) tot = tot + gather_node_list<2>(rl.partial, rl.node_ptr, rl.node_ent, a, lane, wv);
+        if (lane < 6) rhs[6 * a + lane] = accumulate ? rhs[6 * a + lane] + tot : tot;
     } else {
-        double c = 0.0, n = 0.0;
-        for (int r = (int)threadIdx.x; r < n_cc; r += 256) {
-            c += cc[(size_t)r * cc_stride];
-            n += cc[(size_t)r * cc_stride + 1];
+        double c0, c1;
+        gather_cost(cc, n_cc, cc_stride, red, c0, c1);
+        if (rl.partial) {
+            double r0, r1;
+            gather_cost(rl.partial + 90, rl.n_rows, gn_row_stride(2), red, r0, r1);
+            c0 = c0 + r0; c1 = c1 + r1;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); n += __shfl_xor(n, o, 64); }
-        if (lane == 0) { red[0][wv] = c; red[1][wv] = n; }
-        __syncthreads();
         if (threadIdx.x == 0) {
-            const double c0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3], c1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
             cost_count[0] = accumulate ? cost_count[0] + c0 : c0;
             cost_count[1] = accumulate ? cost_count[1] + c1 : c1;
         }
@@ -1687,12 +1727,19 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
         DFH_HIP_CHECK(hipGetLastError());
     }
     const int dbg_part = getenv("DFH_DBG_GATHER_PART") ? atoi(getenv("DFH_DBG_GATHER_PART")) : 0;
+    // the regulariser's lists ride along in the data rows' gather when its rows were built in the data-row launch
+    RegLists rl = {};
+    const bool reg_in_gather = reg_in_data_launch && !getenv("DFH_GN_REG_OWN_GATHER");
+    if (reg_in_gather) {
+        rl.partial = partial_reg; rl.blk_ptr = rblk_ptr; rl.blk_ent = rblk_ent; rl.node_ptr = rnode_ptr; rl.node_ent = rnode_ent;
+        rl.n_rows = n_nodes * knn;
+    }
     if (planned) {
         dim3 grid((unsigned)((n_blocks + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
 #define DFH_GATHER(KK)                                                                                              \
     case KK:                                                                                                        \
         hipLaunchKernelGGL(gn_gather_kernel<KK>, grid, block, 0, s, partial, n_rows, blk_ptr, blk_ent, n_blocks, node_ptr,  \
-                           node_ent, n_nodes, vals, rhs, cost_count, tile_cost, n_tiles, 2, false, dbg_part);       \
+                           node_ent, n_nodes, vals, rhs, cost_count, tile_cost, n_tiles, 2, false, dbg_part, rl);   \
         break
         switch (knn) {
             DFH_GATHER(1); DFH_GATHER(2); DFH_GATHER(3); DFH_GATHER(4); DFH_GATHER(5); DFH_GATHER(6); DFH_GATHER(7); DFH_GATHER(8);
@@ -1705,10 +1752,11 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
         if (!reg_in_data_launch)
             hipLaunchKernelGGL(gn_build_reg_kernel, dim3((n + 3) / 4), dim3(256), 0, s, node_nbr, n_nodes, knn, node_dq, node_pos,
                                node_w, rw, row_ptr, col, vals, rhs, cost_count, planned_reg ? partial_reg : nullptr);
-        if (planned_reg) {
+        if (planned_reg && !reg_in_gather) {
             dim3 grid((unsigned)((n_blocks + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
             hipLaunchKernelGGL(gn_gather_kernel<2>, grid, block, 0, s, partial_reg, n, rblk_ptr, rblk_ent, n_blocks, rnode_ptr,
-                               rnode_ent, n_nodes, vals, rhs, cost_count, partial_reg + 90, n, gn_row_stride(2), true, dbg_part);
+                               rnode_ent, n_nodes, vals, rhs, cost_count, partial_reg + 90, n, gn_row_stride(2), true, dbg_part,
+                               RegLists{});
         }
         DFH_HIP_CHECK(hipGetLastError());
     }

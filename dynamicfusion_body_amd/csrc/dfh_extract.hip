@@ -57,10 +57,11 @@ template <typename VolT>
 __global__ __launch_bounds__(256) void surface_count_kernel(const VolT *__restrict__ T, const VolT *__restrict__ W,
                                                              const ExtractParams p, int *__restrict__ block_count) {
     __shared__ int red[4];
-    const long v0 = (long)blockIdx.x * kExVox + threadIdx.x * 4;
+    // thread t takes voxels t, t+256, t+512, t+768 of the block's 1024: consecutive lanes read consecutive voxels
+    const long v0 = (long)blockIdx.x * kExVox + threadIdx.x;
     int c = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c += band_sample<VolT>(T, W, p, v0 + j, nullptr, nullptr) ? 1 : 0;
+    for (int j = 0; j < 4; ++j) c += band_sample<VolT>(T, W, p, v0 + j * 256, nullptr, nullptr) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
@@ -132,34 +133,33 @@ __global__ __launch_bounds__(256) void surface_emit_kernel(const VolT *__restric
                                                             const ExtractParams p, const int *__restrict__ block_offset,
                                                             double *__restrict__ pos_out, double *__restrict__ nrm_out,
                                                             long capacity) {
-    __shared__ int wave_cnt[4];
+    __shared__ int wave_cnt[4][4];               // [chunk j][wave]: samples of voxels j*256 + 64*wave .. +63
     if (block_offset[blockIdx.x + 1] == block_offset[blockIdx.x]) return;       // nothing to emit: do not re-read the voxels
-    const long v0 = (long)blockIdx.x * kExVox + threadIdx.x * 4;
+    // thread t takes voxels t, t+256, t+512, t+768 of the block (coalesced); samples keep voxel order: chunk j, then thread
+    const long v0 = (long)blockIdx.x * kExVox + threadIdx.x;
     double pos[4][3], nrm[4][3];
     bool ok[4];
-    int c = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ok[j] = band_sample<VolT>(T, W, p, v0 + j, pos[j], nrm[j]); c += ok[j] ? 1 : 0; }
-    // exclusive prefix of c over the block, in thread order (= voxel order)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int incl = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-    if (lane == 63) wave_cnt[wv] = incl;
-    __syncthreads();
-    long at = (long)block_offset[blockIdx.x] + (incl - c);
-    for (int w_ = 0; w_ < wv; ++w_) at += wave_cnt[w_];
+    int before[4];                               // samples of lower lanes of this wave in chunk j
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (ok[j]) {
-            if (at < capacity) {
+        ok[j] = band_sample<VolT>(T, W, p, v0 + j * 256, pos[j], nrm[j]);
+        const unsigned long long m = __ballot(ok[j]);
+        before[j] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[j][wv] = __popcll(m);
+    }
+    __syncthreads();
+    long at = (long)block_offset[blockIdx.x];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { pos_out[3 * at + a] = pos[j][a]; nrm_out[3 * at + a] = nrm[j][a]; }
-            }
-            ++at;
+    for (int j = 0; j < 4; ++j) {
+        long mine = at + before[j];
+        for (int w_ = 0; w_ < 4; ++w_) {
+            if (w_ < wv) mine += wave_cnt[j][w_];
+            at += wave_cnt[j][w_];               // after the loop: start of chunk j+1
+        }
+        if (ok[j] && mine < capacity) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { pos_out[3 * mine + a] = pos[j][a]; nrm_out[3 * mine + a] = nrm[j][a]; }
         }
     }
 }

@@ -212,6 +212,12 @@ def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, mon
     s1 = sv.system.clone()
     sv.build(lw, rw)
     assert torch.equal(s1, sv.system)
+    # the regulariser's rows / lists ride along in the data rows' launches; in launches of their own: the same bits
+    for switch in ("DFH_GN_REG_OWN_GATHER", "DFH_GN_REG_OWN_LAUNCH"):
+        monkeypatch.setenv(switch, "1")
+        sv.build(lw, rw)
+        assert torch.equal(s1, sv.system), switch
+        monkeypatch.delenv(switch)
     sv.build(lw, 0.0)                                   # without the regulariser rows
     s0 = sv.system.clone()
     monkeypatch.setenv("DFH_GN_ATOMIC", "1")

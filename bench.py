@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- TSDF fusion throughput of the HIP hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (starts its own N ranks; also runs under torch.distributed.run)
 
-A "step" is one depth view integrated into every rank's resident 256^3 slab (BASELINE
-config 2: 256^3 grid, 640x480 synthetic depth, rigid TSDF integration).  At N>1 the grid is
-(256*N) x 256 x 256, sharded by axis-0 slab with no data-path collective (weak scaling);
-`value` = all ranks' voxels swept / max-over-ranks time.  Inputs are resident in HBM before
-the timed region.  Rank 0 prints ONE JSON line.
+A "step" is one depth view integrated into the resident 256^3 grid (BASELINE config 2: 256^3 grid,
+640x480 synthetic depth, rigid TSDF integration).  At N>1 the SAME grid is cut into N axis-0 slabs, one per
+rank, with no data-path collective (strong scaling, BASELINE config 4's partition; `--scaling weak` stacks N
+cubes instead); `value` = grid voxels swept per step x steps / max-over-ranks time.  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     -- dominant kernel (integrate_depth_kernel): algorithmic bytes per launch
-                  (16 B/voxel fp32 T+w read-modify-write + 4*H*W depth) over
-                  the kernel's mean launch duration measured with HIP events on the launch
-                  stream, against the 8 TB/s HBM peak.
-  cpu_baseline -- the fp64 numpy oracle (a port of the reference's CPU path, validated
-                  against the reference's outputs) timed on this box's host cores over the
-                  same views; the reference itself is a Python interpreter loop measured at
-                  0.0835 Mvox/s.
+  roofline     -- dominant kernel (integrate_depth_kernel): `achieved` = bytes the launch really loads and stores
+                  (64 B per 4-voxel pack that has an updated voxel + the depth map; counted exactly per view,
+                  cross-checked by the PMC `traffic`) over the kernel's mean launch duration measured with HIP
+                  events on the launch stream, against the 8 TB/s HBM peak.  The SURVEY.md section 8(d) figure
+                  (16 B/voxel over the whole grid + 4*H*W) is reported beside it as `algorithmic_*`: it credits
+                  packs the kernel never touches, so it is an effective rate, not an HBM fraction.
+  k1_512       -- the same kernel at 512^3 / 1280x720 (out of the Infinity Cache): the 0-degree view and a view
+                  that updates every voxel.
+  cpu_baseline -- the C restatement of the reference's CPU path (oracle/oracle_c.c, validated against the
+                  reference's outputs) timed on this box's host cores over the same views; the reference itself
+                  is a Python interpreter loop measured at 0.0835 Mvox/s.
+  gn, frame    -- BASELINE config 3 (10 GN iterations at 256^3 / 512 nodes) and the composed per-frame loop.
 """
 import argparse
 import json
@@ -43,8 +47,14 @@ def parse():
     ap.add_argument("--res", type=int, default=RES, help="per-rank slab is res^3 (default = BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gn", action="store_true", help="skip the warp-solve (GN-iters/s) leg")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
-                                                      "rehearsing >1 rank on a single GPU)")
+    ap.add_argument("--backend", default="auto", help="torch.distributed backend: nccl (= RCCL), gloo (only for rehearsing "
+                                                      ">1 rank on a single GPU), auto = nccl when every rank has its own GPU")
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="strong (default): the SAME res^3 grid cut into --gpus axis-0 slabs (BASELINE configs 2/4); "
+                         "weak: --gpus cubes stacked along axis 0")
+    ap.add_argument("--launch", default="auto", choices=("auto", "eager", "graph"),
+                    help="how the timed K1 steps are issued: eager ctypes calls, one hipGraph replay, auto = the faster")
+    ap.add_argument("--no-k1-512", action="store_true", help="skip the 512^3 K1 roofline leg (1 GPU only)")
     ap.add_argument("--no-frame", action="store_true", help="skip the end-to-end per-frame leg")
     ap.add_argument("--gn-nodes", type=int, default=512)
     ap.add_argument("--gn-solves", type=int, default=5, help="timed solves of 10 GN iterations each")
@@ -229,14 +239,15 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
 def pmc_traffic(kernel_substr, res):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     of this same command (profiles/<tag>_summary.json, written by tools/summarize_profile.py:
-    2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md §HBM).  None when no matching profile."""
+    2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md §HBM).  The newest matching profile wins
+    (files are named per round: r1x_..., r2x_...).  None when no matching profile."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
             line = json.loads(d["bench_line"])
-            if line["config"]["grid"][1] != res:
+            if line["config"]["grid"][1] != res or line.get("n_gpus", 1) != 1:
                 continue
             for name, t in d["traffic"].items():
                 if kernel_substr in name:
@@ -246,26 +257,99 @@ def pmc_traffic(kernel_substr, res):
     return best
 
 
+def touched_bytes(torch, kernels, depth, K, Kinv, lw, scale, center, tdist, tsdf_res, res, x_range, H, W):
+    """Bytes one launch of integrate_depth_kernel really loads and stores for this view: the kernel reads and writes
+    T and w of a 16-byte pack (4 voxels along z) iff the view updates one of its voxels, 64 B per such pack, plus the
+    depth map once.  Counted exactly, outside any timed region: the view is integrated into a fresh volume pair and
+    the packs with a non-zero weight are counted (torch plumbing; the PMC `traffic` figure cross-checks it)."""
+    nx = x_range[1] - x_range[0]
+    Tt = torch.full((nx, res[1], res[2]), float(tdist), dtype=torch.float32, device="cuda")
+    Wt = torch.zeros_like(Tt)
+    kernels.integrate_depth(Tt, Wt, depth, K, Kinv, lw, scale, center, tdist, 100.0, tsdf_res=tsdf_res, res=res, x_range=x_range)
+    upd = Wt > 0
+    vox = int(upd.sum().item())
+    if res[2] % 4 == 0:
+        packs = int(upd.view(-1, 4).any(dim=1).sum().item())
+    else:
+        packs = vox                                   # scalar kernel: one voxel per "pack" (16 B each)
+    del Tt, Wt, upd
+    per_pack = 64.0 if res[2] % 4 == 0 else 16.0
+    return per_pack * packs + 4.0 * H * W, vox
+
+
+def time_launches(torch, fn, n, warm=2):
+    """Mean duration (ms) of n back-to-back calls of fn on torch's current stream (HIP events on that stream)."""
+    for _ in range(warm):
+        fn()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def k1_512_leg(torch, kernels, scene):
+    """K1 at 512^3 with 1280x720 depth (BASELINE configs 4/5): the working set (1.07 GB) is far beyond the 256 MiB
+    Infinity Cache.  Two views: the bench's 0-degree view (updates about half the voxels) and a view that updates every
+    voxel (camera moved back so that the frustum contains the whole grid, a wall far behind it: all free space), for which
+    touched bytes = algorithmic bytes."""
+    R = 512
+    H, W, fx, cx, cy = scene.CAMERAS["C5"]
+    K = scene.intrinsics(fx, cx, cy)
+    Kinv = np.linalg.inv(K)
+    scale, center, tdist = scene.grid_params(R)
+    T = torch.full((R, R, R), tdist, dtype=torch.float32, device="cuda")
+    Wt = torch.zeros_like(T)
+    out = {}
+    lw0 = scene.view_extrinsic(0.0)
+    d0 = torch.from_numpy(scene.render_depth(K, lw0, H, W, dtype=np.float32)).cuda()
+    lw_full = lw0.copy()
+    lw_full[2, 3] += 1.5                                    # camera 1.5 m further back: the whole cube is in view
+    d_full = torch.full((H, W), -8.0, dtype=torch.float32, device="cuda")
+    for name, lw, d in (("view_0deg", lw0, d0), ("view_all_voxels", lw_full, d_full)):
+        tb, vox = touched_bytes(torch, kernels, d, K, Kinv, lw, scale, center, tdist, R, (R, R, R), (0, R), H, W)
+        ms = time_launches(torch, lambda: kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist, 100.0), 10)
+        alg = 16.0 * R ** 3 + 4.0 * H * W
+        out[name] = {"kernel_ms": ms, "updated_fraction": vox / float(R ** 3), "touched_bytes": tb,
+                     "touched_GBps": tb / (ms * 1e-3) / 1e9, "frac_touched": tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes": alg, "algorithmic_GBps": alg / (ms * 1e-3) / 1e9,
+                     "frac_algorithmic": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mvox_per_s": R ** 3 / ms / 1e3}
+    out["workload"] = "512^3 grid, 1280x720 depth, one rigid fuseDepths sweep per launch, 1 GPU"
+    del T, Wt
+    return out
+
+
 def main():
     args = parse()
+    from dynamicfusion_body_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # `python bench.py --gpus N`: start the N ranks ourselves.  This parent never touches the GPU (no HIP call, no
+        # torch.cuda query) and never re-execs; it relays rank 0's JSON line and the worst exit code.
+        sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, json_only=True))
     import torch
     import torch.distributed as dist
     from dynamicfusion_body_amd import kernels, scene
+    from dynamicfusion_body_amd import dist as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    dev = local_rank % max(1, torch.cuda.device_count())      # == local_rank on a real node
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    n_dev = torch.cuda.device_count()
+    backend = args.backend
+    if backend == "auto":                                  # RCCL needs one GPU per rank; fewer GPUs = a rehearsal over gloo
+        backend = "nccl" if n_dev >= world else "gloo"
+    dev = local_rank % max(1, n_dev)                       # == local_rank on a real node
     torch.cuda.set_device(dev)
     distributed = world > 1
     if distributed:
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(backend)
 
     R = args.res
     cam = "C2" if R <= 256 else "C5"
@@ -273,19 +357,29 @@ def main():
     K = scene.intrinsics(fx, cx, cy)
     Kinv = np.linalg.inv(K)
     scale, center, tdist = scene.grid_params(R)
-    # global grid: `world` cubes stacked along axis 0, centred on the sphere; rank owns one cube
-    res = (R * world, R, R)
     tsdf_res = R
     center = center.copy()
-    x_range = (R * rank, R * (rank + 1))
-    # keep the stacked grid centred: shift so that global plane R*world/2 sits at the sphere
-    center[0] -= scale * (R * world / 2 - R / 2)
+    if args.scaling == "strong":
+        # BASELINE configs 2 and 4: ONE res^3 grid cut into `world` axis-0 slabs, no data-path collective
+        res = (R, R, R)
+        x_range = D.slab_range(R, rank, world)
+        vox_per_step = R * R * R
+        workload = "%d^3 grid in %d axis-0 slab(s) (%d planes per GPU)" % (R, world, -(-R // world))
+    else:
+        # weak: `world` cubes stacked along axis 0, centred on the sphere; rank owns one cube.  Most of the outer cubes
+        # lie outside every frustum and skip their loads -- this mode flatters and is not the default
+        res = (R * world, R, R)
+        x_range = (R * rank, R * (rank + 1))
+        center[0] -= scale * (R * world / 2 - R / 2)
+        vox_per_step = R * R * R * world
+        workload = "%d^3 voxels per GPU (grid %dx%dx%d, axis-0 slabs)" % (R, res[0], res[1], res[2])
+    nx = x_range[1] - x_range[0]
 
     lws = [scene.view_extrinsic(a) for a in VIEW_ANGLES]
     depths_np = [scene.render_depth(K, lw, H, W, dtype=np.float32) for lw in lws]
     depths = [torch.from_numpy(d).cuda() for d in depths_np]
-    T = torch.full((R, R, R), tdist, dtype=torch.float32, device="cuda")
-    Wt = torch.zeros((R, R, R), dtype=torch.float32, device="cuda")
+    T = torch.full((nx, R, R), tdist, dtype=torch.float32, device="cuda")
+    Wt = torch.zeros((nx, R, R), dtype=torch.float32, device="cuda")
 
     def step(i):
         v = i % len(lws)
@@ -297,28 +391,71 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The timed region is the same K launches either way; with `--launch graph` (default where it is faster: a slab of
+    # 256^3 / 8 is a 6 us kernel, shorter than one Python call through ctypes) they are captured once, after the warm-up,
+    # into a HIP graph on a side stream and the timed region replays it.  HIP events bracket the work on the stream it
+    # runs on in both cases.
     for i in range(args.warmup):
         step(i)
     barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                       # same stream the kernels are launched on (torch current stream)
-    for i in range(args.steps):
-        step(i)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
-    if distributed:
-        tt = torch.tensor([dt, kern_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, kern_ms = float(tt[0]), float(tt[1])
+    graph = None
+    side = None
+    if args.launch in ("graph", "auto") and not os.environ.get("DFH_NO_GRAPH"):
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    for i in range(args.steps):
+                        step(args.warmup + i)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = g
+        except Exception as e:                                # capture is an optimisation; eager numbers stay valid
+            graph = None
+            sys.stderr.write("graph capture failed, timing eager launches: %s\n" % str(e)[:200])
+            torch.cuda.synchronize()
 
-    vox_per_step = R * R * R * world
+    def timed(run):
+        barrier()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                       # same stream the kernels run on (torch current stream)
+        run()
+        ev1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        kern_ms = ev0.elapsed_time(ev1) / args.steps
+        if distributed:
+            tt = torch.tensor([dt, kern_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt, kern_ms = float(tt[0]), float(tt[1])
+        return dt, kern_ms
+
+    def eager_run():
+        for i in range(args.steps):
+            step(args.warmup + i)
+    dt_eager, kern_ms_eager = timed(eager_run)
+    dt, kern_ms, launch_mode = dt_eager, kern_ms_eager, "eager (one ctypes call per step)"
+    dt_graph = None
+    if graph is not None:
+        dt_graph, kern_ms_graph = timed(graph.replay)
+        if args.launch == "graph" or dt_graph < dt_eager:
+            dt, kern_ms, launch_mode = dt_graph, kern_ms_graph, "hipGraph replay of the %d steps" % args.steps
+
     value = vox_per_step * args.steps / dt / 1e6
-    alg_bytes = 16.0 * R * R * R + 4.0 * H * W               # per launch (one rank's slab)
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    # ---- roofline of the dominant kernel (this rank's slab).  `achieved` counts the bytes the launch really moves
+    # (touched packs, see touched_bytes; cross-checked by the PMC `traffic`), not the 16 B/voxel of SURVEY section 8(d):
+    # that figure credits packs no view updates, which the kernel never loads, and is kept as `algorithmic_*`.
+    tb = [touched_bytes(torch, kernels, depths[v], K, Kinv, lws[v], scale, center, tdist, tsdf_res, res, x_range, H, W)
+          for v in range(len(lws))]
+    touched = sum(t[0] for t in tb) / len(tb)
+    upd_frac = sum(t[1] for t in tb) / len(tb) / float(max(1, nx) * R * R)
+    alg_bytes = 16.0 * nx * R * R + 4.0 * H * W               # per launch (one rank's slab), SURVEY section 8(d)
+    achieved = touched / (kern_ms * 1e-3) / 1e9
+    alg_gbps = alg_bytes / (kern_ms * 1e-3) / 1e9
     out = {
         "metric": "Mvoxels/s TSDF fusion + GN-iters/s warp solve, 256³ grid, 1/2/4/8 GPU",
         "value": value,
@@ -328,18 +465,26 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64 geometry / f32 volume",
         "data": "synthetic",
-        "config": {"workload": "%d^3 voxels per GPU (grid %dx%dx%d, axis-0 slabs), %dx%d synthetic depth, "
-                               "rigid TSDF integration (fuseDepths), %d views cycled"
-                               % (R, res[0], res[1], res[2], W, H, len(lws)),
-                   "grid": list(res), "depth": [H, W], "views": len(lws), "partition": "slab%d" % world},
+        "config": {"workload": "%s, %dx%d synthetic depth, rigid TSDF integration (fuseDepths), %d views cycled"
+                               % (workload, W, H, len(lws)),
+                   "grid": list(res), "depth": [H, W], "views": len(lws), "partition": "slab%d" % world,
+                   "backend": backend if distributed else "none", "launch": launch_mode},
+        "launch": {"mode": launch_mode, "eager_ms_per_step": dt_eager / args.steps * 1e3,
+                   "graph_ms_per_step": None if dt_graph is None else dt_graph / args.steps * 1e3},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "integrate_depth_kernel", "kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                     "achieved_is": "bytes the launch loads and stores (64 B per 4-voxel pack with an updated voxel + the "
+                                    "depth map), mean over the cycled views, / mean launch duration",
+                     "touched_bytes_per_launch": touched, "updated_voxel_fraction": upd_frac,
+                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_gbps,
+                     "frac_algorithmic": alg_gbps / HBM_PEAK_GBS,
+                     "limiter": "VALU (fp64 projection) and L1 tag look-ups of the depth gathers, not HBM: "
+                                "profiles/r1d_k1_experiments.txt, DESIGN.md section 3"},
     }
 
     # measured device-copy ceiling (float4 copy of 1 GiB, far beyond the 256 MiB Infinity Cache)
@@ -366,24 +511,18 @@ def main():
         def sweep():
             kernels.integrate_depth_views(Tm, Wm, depths, K, Kinv, lws, scale, center, tdist, 100.0, tsdf_res=tsdf_res, res=res,
                                           x_range=x_range, workspace=wsv)
-        sweep(); torch.cuda.synchronize()
-        m0 = torch.cuda.Event(enable_timing=True); m1 = torch.cuda.Event(enable_timing=True)
-        reps = max(1, min(20, args.steps // len(lws)))
-        m0.record()
-        for _ in range(reps):
-            sweep()
-        m1.record(); torch.cuda.synchronize()
-        ms_sweep = m0.elapsed_time(m1) / reps
+        ms_sweep = time_launches(torch, sweep, max(1, min(20, args.steps // len(lws))), warm=1)
         out["multi_view_sweep"] = {"views": len(lws), "ms_per_sweep": ms_sweep, "us_per_view": ms_sweep * 1e3 / len(lws),
-                                   "mvox_per_s_per_gpu": R * R * R * len(lws) / ms_sweep / 1e3,
-                                   "hbm_GBps_algorithmic": (16.0 * R * R * R + 4.0 * H * W * len(lws)) / (ms_sweep * 1e-3) / 1e9}
+                                   "mvox_per_s_per_gpu": nx * R * R * len(lws) / ms_sweep / 1e3,
+                                   "hbm_GBps_algorithmic": (16.0 * nx * R * R + 4.0 * H * W * len(lws)) / (ms_sweep * 1e-3) / 1e9}
         del Tm, Wm
     except Exception as e:                                                   # a secondary figure must not lose the line
         out["multi_view_sweep"] = {"error": repr(e)}
-    tr = pmc_traffic("integrate_depth_kernel", R)
-    if tr is not None:
-        out["roofline"]["traffic"] = tr[0]
-        out["roofline"]["traffic_source"] = "profiles/" + tr[1]
+    if world == 1:
+        tr = pmc_traffic("integrate_depth_kernel", R)
+        if tr is not None:
+            out["roofline"]["traffic"] = tr[0]
+            out["roofline"]["traffic_source"] = "profiles/" + tr[1]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # checker timed as the CPU baseline, never the product: the C restatement (OpenMP, all host
@@ -395,6 +534,8 @@ def main():
         To = np.zeros((R, R, R)) + tdist
         Wo = np.zeros((R, R, R))
         cycles = 5 if R <= 256 else 1
+        # the GPU volume has seen warmup + steps (eager) [+ steps (graph)] sweeps; the mask after one cycle of the
+        # views is the same as after any number of them
         t0 = time.perf_counter()
         for _ in range(cycles):
             for v in range(len(lws)):
@@ -415,9 +556,14 @@ def main():
                                                                           R ** 3 / ndt / 1e6),
                                # parity spot check: same update mask as the GPU volume after the same views
                                "mask_match": bool(np.array_equal(Wo > 0, (Wt > 0).cpu().numpy()))}
+    del T, Wt
+    if world == 1 and not args.no_k1_512:
+        try:
+            out["k1_512"] = k1_512_leg(torch, kernels, scene)
+        except Exception as e:
+            out["k1_512"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     if not args.no_gn:
-        del T, Wt
         try:
             out["gn"] = gn_leg(args, torch, dist, scene, rank, world, barrier)
         except Exception as e:                        # a failure here must not cost the headline line
@@ -433,6 +579,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

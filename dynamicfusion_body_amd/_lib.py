@@ -57,6 +57,8 @@ _SIGNATURES = {
     "dfh_pcg_workspace_bytes": (ctypes.c_size_t, [_int, _int]),
     "dfh_pcg_solve": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp]),
     "dfh_pcg_solve_update": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp, _dbl, _vp]),
+    "dfh_pcg_set_mode": (_int, [_int]),
+    "dfh_pcg_status": (_int, [_vp, ctypes.POINTER(ctypes.c_long)]),
     "dfh_apply_twist": (_int, [_vp, _vp, _int, _dbl, _vp]),
     "dfh_surface_workspace_bytes": (ctypes.c_size_t, [_c_int_p]),
     "dfh_surface_count": (_int, [_vp, _vp, _int, _c_int_p, _dbl, _vp, ctypes.c_size_t, _vp, _vp]),
@@ -74,6 +76,10 @@ _lib = None
 
 class DfhError(RuntimeError):
     pass
+
+
+class DfhTimeout(DfhError):
+    """A persistent kernel gave up waiting in a grid barrier (DFH_E_TIMEOUT)."""
 
 
 def declared_symbols(header=HEADER_PATH):
@@ -107,6 +113,8 @@ def check(rc, what):
         msg = load().dfh_last_error().decode("utf-8", "replace")
         if rc == -1:
             raise ValueError("%s: %s" % (what, msg))
+        if rc == -4:
+            raise DfhTimeout("%s: %s" % (what, msg))
         raise DfhError("%s failed (%d): %s" % (what, rc, msg))
 
 

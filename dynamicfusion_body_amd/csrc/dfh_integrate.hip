@@ -113,6 +113,15 @@ __device__ __forceinline__ double rcp_nr1(double d) {      // relative error <= 
     return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
 }
 
+// double -> int32 with the HARDWARE's conversion semantics (v_cvt_i32_f64: truncate, saturate at INT32_MIN/MAX, NaN -> 0).
+// A C++ cast of an out-of-range or NaN double is undefined behaviour, and the guard-band logic below relies on
+// saturation: voxels far outside the frustum or next to the camera plane produce such values.
+__device__ __forceinline__ int cvt_i32_sat(double x) {
+    int r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ void pack_coords(const IntegrateParams &p, int &y, int &zp) {
     const int lin = blockIdx.x * 256 + threadIdx.x;      // (y, zpack) inside one x plane
     if (p.zp_shift >= 0) {
@@ -164,8 +173,8 @@ __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const DepthT
         l2v[j] = PINHOLE ? p2 : __builtin_fma(p.Az[NC - 1], jf, base[NC - 1]);
         l2f[j] = (float)l2v[j];
         const double r = rcp_nr1(p2);
-        const int qu = (int)(p0 * r);                    // trunc, saturating; NaN -> 0 (inside the band)
-        const int qv = (int)(p1 * r);
+        const int qu = cvt_i32_sat(p0 * r);              // trunc, saturating; NaN -> 0 (inside the band)
+        const int qv = cvt_i32_sat(p1 * r);
         // distance to the nearest multiple of 0.5 px: pixel ties AND the integer frustum edges
         const unsigned du = (unsigned)((qu + kFixBand) & (kFixHalf - 1));
         const unsigned dv = (unsigned)((qv + kFixBand) & (kFixHalf - 1));

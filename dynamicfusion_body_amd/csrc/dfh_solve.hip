@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double 
 // as -0.0, so "bits != 0" is the arrival flag); wave 0 polls all slots and adds them in a fixed order: same bits
 // every run and on every rank, no floating-point atomics, no counters, no cache-wide fences.
 constexpr int kRowCache = 3;               // blocks per lane slot held in registers (rows <= 30 blocks)
-constexpr unsigned kSpinLimit = 1u << 22;  // ~seconds
+constexpr unsigned kSpinLimit = 1u << 22;  // default bound of a barrier's spin (~seconds); DFH_PCG_SPIN_LIMIT overrides (tests)
 constexpr int kMaxPcgBlocks = 512;         // persistent path only for grids up to this many workgroups
 
 __device__ __forceinline__ double ld_agent(const double *p) {
@@ -1256,8 +1256,8 @@ struct BarrierLds2 {
 };
 
 // two grid-wide sums in one pass; slots = 2 * gridDim.x doubles (workgroup b: 2b, 2b+1), zero before the launch
-__device__ __forceinline__ bool grid_sum2(double *slots, unsigned *abort_flag, BarrierLds2 *lds, double v0, double v1 /* lane 0 */,
-                                          double *s0, double *s1) {
+__device__ __forceinline__ bool grid_sum2(double *slots, unsigned *abort_flag, unsigned spin_limit, BarrierLds2 *lds, double v0,
+                                          double v1 /* lane 0 */, double *s0, double *s1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     __builtin_amdgcn_s_waitcnt(0);                      // this wave's published vectors have reached the coherence point
     if (lane == 0) { lds->wave_part[0][wave] = v0; lds->wave_part[1][wave] = v1; }
@@ -1287,7 +1287,7 @@ __device__ __forceinline__ bool grid_sum2(double *slots, unsigned *abort_flag, B
                 tot = v;
                 break;
             }
-            if (++spins > kSpinLimit || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (++spins > spin_limit || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -1309,8 +1309,11 @@ template <int MAXT>
 __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col, double *vals,
                                                         const double *__restrict__ rhs, const PcgParams prm, int iters,
                                                         double *__restrict__ x, double *pub /* 2 x {u, v, t} x 6N */, double *part,
-                                                        unsigned *abort_flag, double *__restrict__ update_dq, double update_step) {
+                                                        unsigned *abort_flag, unsigned spin_limit, unsigned long long *abort_count,
+                                                        double *__restrict__ update_dq, double update_step) {
     // update_dq != NULL: the row's wave also applies its twist, update_dq[a] <- exp(update_step * x_a) (x) update_dq[a]
+    // abort_flag: this solve's flag (zero before the launch); abort_count: the library's sticky per-device counter of
+    // timed-out solves, read by dfh_pcg_status() at the caller's next synchronisation point
     __shared__ BarrierLds2 lds;
     const int N = prm.N;
     const size_t N6 = 6 * (size_t)N;
@@ -1428,7 +1431,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
     double ui = minv(ri);
     if (lead) st_agent(set[0] + 6 * a + lane, ui);
     double g, d, gamma = 0.0, delta = 0.0;
-    bool ok = grid_sum2(part, abort_flag, &lds, 0.0, 0.0, &g, &d);          // plain barrier: u0 is out
+    bool ok = grid_sum2(part, abort_flag, spin_limit, &lds, 0.0, 0.0, &g, &d);          // plain barrier: u0 is out
     part += 2 * gridDim.x;
     double wi = 0.0, vi = 0.0;
     if (ok) {
@@ -1443,7 +1446,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
     }
     double gamma_prev = 0.0, alpha_prev = 0.0;
     for (int it = 0; it < iters && ok; ++it) {
-        ok = grid_sum2(part + (size_t)it * 2 * gridDim.x, abort_flag, &lds, g, d, &gamma, &delta);
+        ok = grid_sum2(part + (size_t)it * 2 * gridDim.x, abort_flag, spin_limit, &lds, g, d, &gamma, &delta);
         if (!ok) break;
         const double beta = gamma_prev != 0.0 ? gamma / gamma_prev : 0.0;
         const double denom = alpha_prev != 0.0 ? delta - (beta * gamma) / alpha_prev : delta;
@@ -1471,6 +1474,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
         alpha_prev = alpha;
     }
     if (lead) x[6 * a + lane] = ok ? xi : __builtin_nan("");
+    if (!ok && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(abort_count, 1ull);     // one count per timed-out solve
     if (update_dq && ok) {
         const double xs = update_step * xi;
         const double t0 = __shfl(xs, 0, 64), t1 = __shfl(xs, 1, 64), t2 = __shfl(xs, 2, 64);
@@ -1800,6 +1804,49 @@ size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
                              2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4));
 }
 
+// ---- persistent-PCG bookkeeping ---------------------------------------------------------------------------------
+// g_pcg_mode: 0 = auto (persistent kernel when co-residency holds, see pcg_solve_impl), 2 = always the two-launches-per-
+// iteration path.  g_abort_count[dev]: device counter the persistent kernel bumps when a barrier times out.
+namespace dfh { int g_pcg_mode = 0; unsigned long long *g_abort_count[64] = {nullptr}; }
+using dfh::g_abort_count;
+
+static int pcg_abort_counter(unsigned long long **out) {
+    int dev = 0;
+    DFH_HIP_CHECK(hipGetDevice(&dev));
+    DFH_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!g_abort_count[dev]) {
+        unsigned long long *p = nullptr;
+        DFH_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), sizeof(unsigned long long)));
+        DFH_HIP_CHECK(hipMemset(p, 0, sizeof(unsigned long long)));
+        g_abort_count[dev] = p;
+    }
+    *out = g_abort_count[dev];
+    return DFH_OK;
+}
+
+int dfh_pcg_set_mode(int mode) {
+    DFH_REQUIRE(mode == 0 || mode == 2, "dfh_pcg_set_mode: mode %d (0 = auto, 2 = multi-launch)", mode);
+    dfh::g_pcg_mode = mode;
+    return DFH_OK;
+}
+
+int dfh_pcg_status(void *stream, long *aborted_solves_out) {
+    using namespace dfh;
+    DFH_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    int dev = 0;
+    DFH_HIP_CHECK(hipGetDevice(&dev));
+    unsigned long long n = 0;
+    if (dev >= 0 && dev < 64 && g_abort_count[dev]) {
+        DFH_HIP_CHECK(hipMemcpy(&n, g_abort_count[dev], sizeof(n), hipMemcpyDeviceToHost));
+        if (n) DFH_HIP_CHECK(hipMemset(g_abort_count[dev], 0, sizeof(n)));
+    }
+    if (aborted_solves_out) *aborted_solves_out = (long)n;
+    if (n)
+        return fail(DFH_E_TIMEOUT, "persistent PCG: %llu solve(s) timed out in a grid barrier (workgroups not co-resident?); x = NaN, "
+                                   "node_dq was left unchanged", n);
+    return DFH_OK;
+}
+
 static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
                           double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, double *update_dq,
                           double update_step, void *stream) {
@@ -1830,17 +1877,52 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
     int wpb = n_nodes <= 8 * 64 ? 8 : 16;             // fat workgroups: <= 64 partial sums per reduction where possible
     if (const char *e = getenv("DFH_PCG_WPB")) { const int v = atoi(e); if (v == 4 || v == 8) wpb = v; }
     const int nblk = (n_nodes + wpb - 1) / wpb;
-    // at most half the CUs: two processes sharing the GPU can both be fully resident (no mutual starvation)
-    if (2 * nblk <= n_cu && nblk <= kMaxPcgBlocks && !getenv("DFH_PCG_MULTILAUNCH")) {
+    // Persistent path only when its grid barrier cannot starve: (1) the occupancy query says a workgroup of this size
+    // fits on a CU, (2) the grid takes at most half the CUs (a second stream's or process's solve fits beside it),
+    // (3) the caller has not declared co-residency unsafe (dfh_pcg_set_mode(2): several processes time-sharing one GPU),
+    // (4) the abort counter exists (it cannot be allocated while the stream is being captured).  Otherwise: two launches
+    // per iteration, no spinning.
+    bool persistent = 2 * nblk <= n_cu && nblk <= kMaxPcgBlocks && dfh::g_pcg_mode != 2 && !getenv("DFH_PCG_MULTILAUNCH");
+    unsigned long long *abort_count = nullptr;
+    if (persistent) {
+        static int occ512 = -1, occ1024 = -1;
+        int &occ = wpb <= 8 ? occ512 : occ1024;
+        if (occ < 0) {
+            int nb = 0;
+            const hipError_t e = wpb <= 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcg_cg1_kernel<512>, 64 * 8, 0)
+                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcg_cg1_kernel<1024>, 64 * 16, 0);
+            occ = e == hipSuccess ? nb : 0;
+        }
+        persistent = occ >= 1;
+    }
+    if (persistent) {
+        int dev = 0;
+        DFH_HIP_CHECK(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && g_abort_count[dev]) {
+            abort_count = g_abort_count[dev];
+        } else {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+            if (cs == hipStreamCaptureStatusNone) {
+                const int rc = pcg_abort_counter(&abort_count);
+                if (rc != DFH_OK) return rc;
+            } else {
+                persistent = false;
+            }
+        }
+    }
+    if (persistent) {
+        unsigned spin_limit = kSpinLimit;
+        if (const char *e = getenv("DFH_PCG_SPIN_LIMIT")) spin_limit = (unsigned)strtoul(e, nullptr, 10);
         unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
         double *part = scal + 3 * ((size_t)iters + 2);                                    // (2 per iteration + 1) reductions x nblk slots
         // Minv's 36 N doubles hold the two sets of published {u, v, t}
         if (wpb <= 8)
             hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
-                               flag, update_dq, update_step);
+                               flag, spin_limit, abort_count, update_dq, update_step);
         else
             hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
-                               flag, update_dq, update_step);
+                               flag, spin_limit, abort_count, update_dq, update_step);
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }

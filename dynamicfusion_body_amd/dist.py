@@ -18,6 +18,16 @@ def world():
     return 0, 1
 
 
+def ranks_share_a_gpu():
+    """True when this node runs more ranks than it has GPUs (several processes time-sharing one card)."""
+    import os
+    _, ws = world()
+    if ws == 1 or not torch.cuda.is_available():
+        return False
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
+    return local > torch.cuda.device_count()
+
+
 def slab_range(n_planes, rank, world_size):
     """Planes [a, b) of axis 0 owned by `rank`: contiguous, covering, sizes differ by at most 1."""
     if world_size < 1 or not (0 <= rank < world_size):

@@ -203,4 +203,5 @@ class SlabFrame:
         mark("tsdf_update")
         n = self.refresh_samples()
         mark("samples")
+        self.fs.solver.check_status()          # the sample count's read-back has synchronised: a timed-out PCG raises here
         return n

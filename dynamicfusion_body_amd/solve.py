@@ -188,6 +188,21 @@ class WarpSolver:
         self.distributed = bool(distributed)      # False: ignore an initialised process group
         self.node_nbr = None
         self.S = 0
+        if self.distributed and _dist.ranks_share_a_gpu():
+            # several processes time-share this GPU (a rehearsal of the multi-GPU job on one card): co-residency of the
+            # persistent PCG's workgroups is not guaranteed across processes -> two launches per iteration, no grid barrier
+            _lib.check(self.lib.dfh_pcg_set_mode(2), "dfh_pcg_set_mode")
+
+    def check_status(self):
+        """Raise DfhError if a persistent PCG solve since the last check timed out in its grid barrier (x = NaN, node_dq
+        left as it was).  Synchronises; called where the host synchronises anyway (cost(), the end of SlabFrame.step).
+        After a time-out this process takes the multi-launch PCG path."""
+        import ctypes
+        n = ctypes.c_long(0)
+        rc = self.lib.dfh_pcg_status(current_stream_ptr(), ctypes.byref(n))
+        if rc != 0:
+            self.lib.dfh_pcg_set_mode(2)
+            _lib.check(rc, "dfh_pcg_status")
 
     # -- graph -------------------------------------------------------------------------------
     def set_graph(self, node_pos, node_dq, node_w, node_nbr=None):
@@ -448,7 +463,8 @@ class WarpSolver:
                                                  current_stream_ptr()), "dfh_pcg_solve_update")
 
     def cost(self):
-        """(0.5*|r|^2, valid sample count) of the last build (synchronises)."""
+        """(0.5*|r|^2, valid sample count) of the last build (synchronises; raises if a PCG solve timed out)."""
+        self.check_status()
         h = self.cost_count.cpu().numpy()
         return float(h[0]), int(h[1])
 

@@ -40,6 +40,7 @@ extern "C" {
 #define DFH_E_BADARG (-1)
 #define DFH_E_HIP (-2)
 #define DFH_E_UNSUPPORTED (-3)
+#define DFH_E_TIMEOUT (-4)
 
 /* ABI version of the loaded library (== DFH_ABI_VERSION of the header it was built from). */
 int dfh_version(void);
@@ -246,6 +247,17 @@ int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double
 int dfh_pcg_solve_update(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
                          double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, double *node_dq,
                          double step, void *stream);
+
+/* The persistent PCG kernel (one launch per solve; its workgroups synchronise through grid-wide reductions) is used
+ * when all its workgroups are co-resident: the occupancy query admits a workgroup per CU and the grid needs at most
+ * half the CUs.  That cannot be known when several PROCESSES time-share one GPU: such callers declare it with
+ * dfh_pcg_set_mode(2) and every solve then takes the two-launches-per-iteration path (0 = auto, the default).
+ * A barrier of the persistent kernel that does not complete within its spin bound (seconds) makes every workgroup
+ * leave: x_out = NaN, node_dq untouched, and a per-device counter is bumped.  dfh_pcg_status() synchronises `stream`,
+ * reads and clears that counter: DFH_OK, or DFH_E_TIMEOUT when a solve since the last call timed out
+ * (*aborted_solves_out = how many; may be NULL).  Call it wherever the host synchronises anyway. */
+int dfh_pcg_set_mode(int mode);
+int dfh_pcg_status(void *stream, long *aborted_solves_out);
 
 /* node_dq[a] <- exp(step * xi[a]) (x) node_dq[a]; exp = rotation exp(omega), translation v. */
 int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream);

@@ -239,3 +239,136 @@ def associate_depth(points_idx, K, Kinv, lw_cam, dm, scale, center, half):
     cworld = (ccam - t) @ np.linalg.inv(R).T
     cidx = (cworld - center) / scale + half
     return np.where(valid[:, None], cidx, 0.0), valid
+
+
+# ---------------------------------------------------------------- block-sparse assembly + truncated PCG
+# (what the HIP build ships: csrc/dfh_solve.hip gn_build_* + pcg_cg1_kernel).  Same algorithm as assemble_dense
+# + a dense solve, but sized for BASELINE configs 3/4 (512 / 2 048 nodes, 1e5..1e6 samples) and with the SAME
+# truncated linear solve the device runs, so that the benched settings (10 PCG iterations) have a CPU value beside them.
+def _reduce_by_key(keys, vals):
+    """Sum vals (n, ...) over equal keys -> (sorted unique keys, sums)."""
+    order = np.argsort(keys, kind="stable")
+    ks = keys[order]
+    start = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+    return ks[start], np.add.reduceat(vals[order], start, axis=0)
+
+
+def assemble_blocks(N, r_data, J_data, nbr, rho, nb, Ji, Jj, valid=None):
+    """Block-sparse normal equations of the same rows as assemble_dense: returns
+    (keys (B,) sorted unique i*N+j, blocks (B,6,6), Jtr (N,6), cost).  Only valid data rows are touched."""
+    k = nbr.shape[1]
+    if valid is not None:
+        sel = np.flatnonzero(valid)
+        r_data, J_data, nbr = r_data[sel], J_data[sel], nbr[sel]
+    key_parts, blk_parts = [], []
+    Jtr = np.zeros((N, 6))
+    for a in range(k):
+        np.add.at(Jtr, nbr[:, a], J_data[:, a, :] * r_data[:, None])
+        for b_ in range(k):
+            kk, bb = _reduce_by_key(nbr[:, a].astype(np.int64) * N + nbr[:, b_], J_data[:, a, :, None] * J_data[:, b_, None, :])
+            key_parts.append(kk); blk_parts.append(bb)
+    cost = 0.5 * float(np.sum(r_data * r_data))
+    Nn, kn = nb.shape
+    ii = np.repeat(np.arange(Nn)[:, None], kn, axis=1).reshape(-1)
+    jj = nb.reshape(-1)
+    Ji_, Jj_ = Ji.reshape(-1, 3, 6), Jj.reshape(-1, 3, 6)
+    for (ra, rb, A_, B_) in ((ii, ii, Ji_, Ji_), (jj, jj, Jj_, Jj_), (ii, jj, Ji_, Jj_), (jj, ii, Jj_, Ji_)):
+        kk, bb = _reduce_by_key(ra.astype(np.int64) * N + rb, np.einsum('nci,ncj->nij', A_, B_))
+        key_parts.append(kk); blk_parts.append(bb)
+    np.add.at(Jtr, ii, np.einsum('nci,nc->ni', Ji_, rho.reshape(-1, 3)))
+    np.add.at(Jtr, jj, np.einsum('nci,nc->ni', Jj_, rho.reshape(-1, 3)))
+    cost += 0.5 * float(np.sum(rho * rho))
+    keys, blocks = _reduce_by_key(np.concatenate(key_parts), np.concatenate(blk_parts))
+    return keys, blocks, Jtr, cost
+
+
+def blocks_to_bsr(N, keys, blocks):
+    import scipy.sparse as sp
+    rows = keys // N
+    indptr = np.searchsorted(rows, np.arange(N + 1))
+    return sp.bsr_matrix((blocks, (keys % N).astype(np.int64), indptr), shape=(6 * N, 6 * N))
+
+
+def damp_blocks(N, keys, blocks, lm_abs, lm_rel):
+    """The device's damping: d <- d + lm_abs + lm_rel * d on the scalar diagonal (written into the matrix)."""
+    out = blocks.copy()
+    diag = np.flatnonzero(keys // N == keys % N)
+    idx = np.arange(6)
+    out[diag[:, None], idx, idx] = out[diag[:, None], idx, idx] + lm_abs + lm_rel * out[diag[:, None], idx, idx]
+    return out
+
+
+def pcg_cg1(N, keys, blocks, Jtr, iters, lm_abs=0.0, lm_rel=0.0):
+    """x after `iters` iterations of the single-reduction preconditioned CG of Chronopoulos & Gear on
+    (A + lm_abs I + lm_rel diag A) x = -J^T r with the block-Jacobi preconditioner -- the recurrence of
+    pcg_cg1_kernel (csrc/dfh_solve.hip): u = M^-1 r, w = A u, gamma = r.u, delta = w.u, beta = gamma/gamma_old,
+    alpha = gamma / (delta - beta gamma / alpha_old), p = u + beta p, s = w + beta s, t = v + beta t (v = M^-1 w),
+    x += alpha p, r -= alpha s, u -= alpha t."""
+    Bd = damp_blocks(N, keys, blocks, lm_abs, lm_rel)
+    A = blocks_to_bsr(N, keys, Bd)
+    diag = np.full(N, -1, dtype=np.int64)
+    dsel = np.flatnonzero(keys // N == keys % N)
+    diag[keys[dsel] // N] = dsel
+    D = np.where((diag >= 0)[:, None, None], Bd[np.maximum(diag, 0)], np.eye(6)[None])
+    Minv = np.linalg.inv(D)
+    M = lambda v: np.einsum('nij,nj->ni', Minv, v.reshape(N, 6)).reshape(-1)
+    x = np.zeros(6 * N)
+    r = -Jtr.reshape(-1).copy()
+    u = M(r)
+    w = A @ u
+    v = M(w)
+    gamma, delta = float(r @ u), float(w @ u)
+    p = np.zeros_like(x); s = np.zeros_like(x); t = np.zeros_like(x)
+    gamma_prev = alpha_prev = 0.0
+    for it in range(iters):
+        beta = gamma / gamma_prev if gamma_prev != 0.0 else 0.0
+        denom = delta - (beta * gamma) / alpha_prev if alpha_prev != 0.0 else delta
+        alpha = gamma / denom if denom != 0.0 else 0.0
+        p = u + beta * p; s = w + beta * s; t = v + beta * t
+        x = x + alpha * p; r = r - alpha * s; u = u - alpha * t
+        if it == iters - 1:
+            break
+        w = A @ u
+        v = M(w)
+        gamma_prev, alpha_prev = gamma, alpha
+        gamma, delta = float(r @ u), float(w @ u)
+    return x
+
+
+def huber_scale(r, delta):
+    """(sqrt of the IRLS weight per row, Huber objective sum rho(r)) -- dfh_gn_build_planned's huber_delta."""
+    a = np.abs(r)
+    sc = np.sqrt(np.minimum(1.0, delta / np.maximum(a, 1e-300)))
+    obj = float(np.where(a <= delta, 0.5 * r * r, delta * (a - 0.5 * delta)).sum())
+    return sc, obj
+
+
+def gn_loop_truncated(dqs, pos, nrm, nbr, node_nbr, node_pos, node_w, lw, associate, iters, rw, lm_abs, lm_rel, huber, pcg_iters,
+                      exact=False):
+    """The shipped GN loop (pipeline.FrameSolver.gn_iteration x iters) on the CPU: per iteration associate ->
+    Huber-weighted normal equations -> `pcg_iters` iterations of pcg_cg1 (exact=True: sparse direct solve) -> twist
+    update.  associate(warped_points) -> (corr, valid).  Returns (costs at every build, valid counts, final dqs)."""
+    N = len(dqs)
+    dqs = np.asarray(dqs, dtype=np.float64).copy()
+    costs, counts = [], []
+    for _ in range(iters):
+        warped = O.warp(pos, dqs[nbr], node_pos[nbr], node_w[nbr], m_lw=lw)
+        corr, valid = associate(warped)
+        sel = np.flatnonzero(valid)
+        r, J = data_residual_jacobian(dqs, pos[sel], nrm[sel], corr[sel], nbr[sel], node_pos, node_w, lw)
+        obj = 0.5 * float(r @ r)
+        if huber > 0.0:
+            sc, obj = huber_scale(r, huber)
+            r, J = r * sc, J * sc[:, None, None]
+        rho, nb, Ji, Jj = reg_residual_jacobian(dqs, np.arange(N), node_nbr, node_pos, node_w, rw)
+        keys, blocks, Jtr, _ = assemble_blocks(N, r, J, nbr[sel], rho, nb, Ji, Jj)
+        costs.append(obj + 0.5 * float(np.sum(rho * rho)))
+        counts.append(int(len(sel)))
+        if exact:
+            import scipy.sparse.linalg as spla
+            A = blocks_to_bsr(N, keys, damp_blocks(N, keys, blocks, lm_abs, lm_rel)).tocsc()
+            dx = spla.spsolve(A, -Jtr.reshape(-1))
+        else:
+            dx = pcg_cg1(N, keys, blocks, Jtr, pcg_iters, lm_abs, lm_rel)
+        dqs = apply_twists(dqs, dx.reshape(N, 6))
+    return costs, counts, dqs

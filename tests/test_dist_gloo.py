@@ -97,3 +97,28 @@ def test_two_ranks_gloo():
         p.join(120)
     assert all(p.exitcode == 0 for p in procs)
     assert list(out) == [1] * ws
+
+
+def test_spawn_ranks_runs_a_gloo_job(tmp_path):
+    """launch.spawn_ranks (what `python bench.py --gpus N` uses to start its own ranks): N fresh processes with the
+    torch.distributed environment, rank 0's stdout relayed, worst exit code returned, survivors of a failed rank ended."""
+    import subprocess
+    import sys
+    script = tmp_path / "job.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(dist.get_rank() + 1)])\n"
+        "dist.all_reduce(t)\n"
+        "print('SUM', int(t.item()), os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'])\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(int(sys.argv[1]) if dist.is_available() and os.environ['RANK'] == '1' else 0)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from dynamicfusion_body_amd import launch; "
+            "sys.exit(launch.spawn_ranks([%r, sys.argv[1]], 3, timeout=120))" % (root, str(script)))
+    r = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if not l.startswith("[Gloo]")]     # (gloo's own banner)
+    assert lines == ["SUM 6 3 0"]                                       # only rank 0's stdout comes through
+    r = subprocess.run([sys.executable, "-c", code, "7"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 7

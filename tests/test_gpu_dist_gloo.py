@@ -170,3 +170,87 @@ def test_slab_frame_two_ranks():
         assert err is None, err
         assert ddq < 1e-6 and dT < 1e-4 and dW < 1e-4 and dmask < 1e-4
         assert moved > 1.0                                                   # the frames really changed the canonical volume
+
+
+def _config4_worker(rank, ws, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_WORLD_SIZE"] = str(ws)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from dynamicfusion_body_amd import scene, kernels
+        from dynamicfusion_body_amd import dist as D
+        from dynamicfusion_body_amd.pipeline import FrameSolver
+        torch.cuda.set_device(0)
+        R, N, k = 512, 2048, 4
+        H, W, fx, cx, cy = scene.CAMERAS["C5"]
+        K = scene.intrinsics(fx, cx, cy); Kinv = np.linalg.inv(K)
+        scale, center, tdist = scene.grid_params(R)
+        T = torch.full((R, R, R), tdist, dtype=torch.float32, device="cuda"); Wt = torch.zeros_like(T)
+        for ang in (0.0, 40.0, -40.0):
+            lw = scene.view_extrinsic(ang)
+            d = torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda()
+            kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist)
+        node_pos, node_w = scene.fibonacci_nodes(N, R)
+        ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
+        rng = np.random.default_rng(7)
+        from oracle import gn_np as G
+        dq0 = torch.from_numpy(G.apply_twists(ident, rng.normal(scale=[2e-3] * 3 + [0.15] * 3, size=(N, 6)))).cuda()
+        lw_cam = scene.view_extrinsic(0.0)
+        depth = torch.from_numpy(scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=np.array([0.6, -0.4, 0.3]) * scale,
+                                                    sphere_r=scene.SPHERE_R * 1.005)).cuda()
+        a, b = D.slab_range(R, rank, ws)
+        lo, hi = max(a - 1, 0), min(b + 1, R)
+        Wp = Wt[lo:hi].clone()
+        if lo < a:
+            Wp[0] = 0
+        if hi > b:
+            Wp[-1] = 0
+        systems = {}
+        for mode in ("sharded", "whole"):
+            fs = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=10, distributed=(mode == "sharded"))
+            fs.set_graph(node_pos, ident, node_w)
+            if mode == "sharded":
+                S = fs.set_canonical(T[lo:hi].contiguous(), Wp, band=4.0, x0=lo)
+            else:
+                S = fs.set_canonical(T, Wt, band=4.0)
+            sv = fs.solver
+            sv.node_dq.copy_(dq0)
+            sv.associate_depth(depth, fs.K, fs.Kinv, lw_cam, scale, center, R / 2, fs.lw, 2.0)
+            sv.build(fs.lw, 5.0, 0.5)                         # sharded: all-reduce of the flat system inside
+            c, n = sv.cost()
+            systems[mode] = (S, sv._pattern_keys.clone(), sv.vals.clone(), sv.rhs.clone(), c, n)
+        tot = torch.tensor([float(systems["sharded"][0])], dtype=torch.float64)
+        dist.all_reduce(tot)
+        Ss, ks, vs, rs, cs, ns = systems["sharded"]
+        Sw, kw, vw, rw_, cw, nw = systems["whole"]
+        same_pattern = bool(ks.numel() == kw.numel() and torch.equal(ks, kw))
+        dv = float((vs - vw).abs().max() / vw.abs().max()) if same_pattern else -1.0
+        dr = float((rs - rw_).abs().max() / rw_.abs().max())
+        out.put((rank, int(tot.item()), Sw, same_pattern, dv, dr, abs(cs - cw) / cw, ns, nw, None))
+    except Exception:                                                       # pragma: no cover
+        import traceback
+        out.put((rank, 0, 0, False, 0, 0, 0, 0, 0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_two_rank_split():
+    """BASELINE config 4 (512^3, 2 048 nodes) cut into two axis-0 slabs: each rank builds the Huber-weighted normal
+    equations of its own slab's samples, ONE all-reduce of the flat buffer sums them, and the result is the whole-grid
+    system: same sample union, same block pattern, blocks / J^T r / cost to summation order (1e-11 relative)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_config4_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [out.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+    for rank, s_union, s_whole, same_pattern, dv, dr, dc, n_valid, n_valid_whole, err in got:
+        assert err is None, err
+        assert s_union == s_whole and s_whole > 500000
+        assert n_valid == n_valid_whole and n_valid > 100000                # the all-reduced count is the whole grid's
+        assert same_pattern
+        assert 0 <= dv <= 1e-11 and dr <= 1e-11 and dc <= 1e-12

@@ -276,8 +276,12 @@ def test_dqb_config3_scale_properties():
     T2, W2 = T.clone(), W.clone()
     kernels.fuse_volume_dqb(T, W, live, node_pos, node_dq, node_w, k, ident, tdist)
     kernels.fuse_volume_rigid(T2, W2, live, ident, tdist)
-    assert torch.equal(T != tdist, T2 != tdist) or torch.equal((W != 1), (W2 != 1))
     assert torch.equal(W != 1, W2 != 1)
+    # T mask: with the identity warp the sample is live[i] itself.  The two kernels average it with different weights, so a
+    # sample within a few ulp of tdist may round back to tdist in one of them only; everywhere else the masks must agree
+    sel = (live >= tdist) | (live < tdist - 1e-3)
+    assert torch.equal((T != tdist)[sel], (T2 != tdist)[sel])
+    assert int(((T != tdist) & sel).sum()) > 500000
     # same sampled value, different weight rule: T = (T*1 + m*wi)/(wi+1) vs (T*1 + m)/2
     T3, W3 = torch.full_like(T, tdist), torch.ones_like(T)
     kernels.fuse_volume_dqb(T3, W3, live, node_pos, node_dq, node_w, k, ident, tdist)

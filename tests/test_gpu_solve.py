@@ -200,6 +200,44 @@ def test_pcg_paths_agree_and_are_deterministic(golden, monkeypatch):
     assert torch.equal(x1, sv.dx)
 
 
+def test_persistent_pcg_timeout_is_reported(golden, monkeypatch):
+    """A grid barrier of the persistent PCG that does not complete within its spin bound makes every workgroup leave
+    (x = NaN, node_dq untouched) -- and the host must hear about it: the next synchronising call raises DfhTimeout,
+    the process then takes the multi-launch path, and the next solve is sound.  The time-out is forced with a spin
+    bound of 0 polls (DFH_PCG_SPIN_LIMIT), which no 2-workgroup barrier meets."""
+    from dynamicfusion_body_amd import _lib
+    g, verts, norms, corr, nbr, vidx, npos, ndq, nw, lw, rw = load(golden)
+    lib = _lib.load()
+    lib.dfh_pcg_set_mode(0)
+    try:
+        sv = make_solver(npos, ndq, nw, nbr, vidx, verts, norms, corr, nbr.shape[1], pcg_iters=12)
+        assert sv.N > 8                                                  # more than one workgroup: a real grid barrier
+        sv.build(lw, rw)
+        sv.check_status()                                                # nothing pending
+        v0 = sv.vals.clone()
+        dq0 = sv.node_dq.clone()
+        monkeypatch.setenv("DFH_PCG_SPIN_LIMIT", "0")
+        sv.step(lw, rw, 0.5, 1e-3)                                       # build + PCG + twist update in one go
+        monkeypatch.delenv("DFH_PCG_SPIN_LIMIT")
+        with pytest.raises(_lib.DfhTimeout):
+            sv.cost()
+        assert torch.isnan(sv.dx).all() and torch.equal(sv.node_dq, dq0)  # no update was applied
+        sv.check_status()                                                # the counter was cleared by the raise
+        # the process has fallen back to the multi-launch PCG: same system, sound answer
+        sv.vals.copy_(v0)
+        sv.build(lw, rw)
+        sv.solve_linear(0.5, 1e-3)
+        x_fallback = sv.dx.clone()
+        assert torch.isfinite(x_fallback).all()
+        lib.dfh_pcg_set_mode(0)
+        sv.build(lw, rw)
+        sv.solve_linear(0.5, 1e-3)
+        sv.check_status()
+        assert (sv.dx - x_fallback).abs().max() <= 1e-9 * x_fallback.abs().max()
+    finally:
+        lib.dfh_pcg_set_mode(0)
+
+
 def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, monkeypatch):
     """dfh_gn_build_planned (per-run partial rows + gather, regulariser included) has no floating-point
     atomics: two builds give the same bits; dfh_gn_build (atomics) gives the same system to rounding."""

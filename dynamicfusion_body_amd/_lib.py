@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "libdfusion_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dfusion_hip.h")
 
 F32, F64 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -24,8 +24,9 @@ _SIGNATURES = {
     "dfh_version": (_int, []),
     "dfh_last_error": (ctypes.c_char_p, []),
     "dfh_stream_synchronize": (_int, [_vp]),
+    "dfh_integrate_workspace_bytes": (ctypes.c_size_t, [_int, _int, _int, _c_int_p, _int, _int]),
     "dfh_integrate_depth": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _int, _vp, _int, _int, _int,
-                                   _c_double_p, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp]),
+                                   _c_double_p, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, ctypes.c_size_t, _vp]),
     "dfh_integrate_multi_workspace_bytes": (ctypes.c_size_t, [_int]),
     "dfh_integrate_depth_multi": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _int, _int, ctypes.POINTER(ctypes.c_void_p), _int, _int,
                                          _int, _c_double_p, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp,
@@ -42,6 +43,9 @@ _SIGNATURES = {
     "dfh_residual_reg": (_int, [_vp, _int, _int, _vp, _vp, _vp, _dbl, _vp, _vp]),
     "dfh_warp_points": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _int, _c_double_p, _vp, _vp, _vp]),
     "dfh_closest_correspondences": (_int, [_vp, _vp, _int, _vp, _int, _int, _dbl, _vp, _vp, _vp, _vp]),
+    "dfh_nearest_points": (_int, [_vp, _int, _vp, _int, _vp, _vp, _vp]),
+    "dfh_graph_unsupported": (_int, [_vp, _int, _vp, _int, _vp, _vp, _int, _vp, _vp]),
+    "dfh_dq_blend_points": (_int, [_vp, _int, _vp, _int, _vp, _vp, _vp, _int, _vp, _vp]),
     "dfh_sample_knn": (_int, [_vp, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "dfh_dqb_build_candidates": (_int, [_c_int_p, _int, _int, _vp, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "dfh_sample_knn_bricks": (_int, [_vp, _int, _vp, _vp, _int, _int, _c_int_p, _int, _int, _vp, ctypes.c_size_t, _vp, _vp, _vp]),

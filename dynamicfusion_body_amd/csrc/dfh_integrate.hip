@@ -48,6 +48,11 @@ struct IntegrateParams {
     int x0, nx;        // slab: planes [x0, x0+nx)
     int H, W;
     int zpacks;        // ceil(Z / VEC)
+    // brick kernels: max-depth pyramid of this view (levels 1..kPyrLevels, level l = max of z = -depth over 2^l x 2^l
+    // pixel cells, invalid pixels count as 0), NULL = no occlusion culling
+    const float *pyr;
+    int pyr_off[6], pyr_w[6], pyr_h[6];     // per level (index 0 unused)
+    int cull;          // 1: brick culling enabled
 };
 
 constexpr int kFixShift = 20;                   // pixel coordinates in 2^-20 px fixed point
@@ -55,6 +60,8 @@ constexpr int kFixOne = 1 << kFixShift;
 constexpr int kFixHalf = 1 << (kFixShift - 1);
 constexpr int kFixBand = 8;                     // guard band around multiples of 0.5 px
 constexpr int kFastMaxDim = 2048;               // (dim-1) << 20 must fit in int32
+constexpr int kPyrLevels = 5;                   // pyramid levels 1..5 (cells of 2..32 pixels)
+constexpr int kCullMargin = 1 << 10;            // 2^-10 px: corner projections are good to 2^-19 px, the reference's to 1e-12 px
 constexpr long kTargetBlocks = 1L << 40;        // measured (profiles/kbench_r1.txt): one plane per block is
                                                 // fastest at 256^3 and 512^3; the plane loop stays as a knob
 
@@ -140,9 +147,16 @@ __device__ __forceinline__ void pack_coords(const IntegrateParams &p, int &y, in
 //
 // view_pack: one depth view's contribution to the VEC voxels (x, y, z0 + j*ZS): ms[j] = min(tdist, sd) / scale and
 // upd[j] = the reference's update condition; returns whether any voxel of the pack is updated.
-template <typename DepthT, int VEC, bool PINHOLE, bool STRIDED>
+struct NoHook {
+    __device__ __forceinline__ void operator()(bool) const {}
+};
+
+// after_gathers(any_inside): called right after the depth gathers have been issued and before their values are used --
+// the place to issue further independent loads (the brick sweep starts its T / w loads there, one memory round trip
+// instead of two); any_inside = some voxel of the pack projects into the image.
+template <typename DepthT, int VEC, bool PINHOLE, bool STRIDED, typename Hook = NoHook>
 __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const DepthT *__restrict__ depth, int x, int y, int z0,
-                                          float (&ms)[VEC], bool (&upd)[VEC]) {
+                                          float (&ms)[VEC], bool (&upd)[VEC], Hook &&after_gathers = NoHook()) {
     constexpr int ZS = STRIDED ? 64 : 1;                 // z step between a lane's voxels
     constexpr int NC = PINHOLE ? 3 : 4;
     const unsigned ulim = (unsigned)(p.W - 1) << kFixShift;
@@ -188,6 +202,12 @@ __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const DepthT
     DepthT dval[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) dval[j] = depth[pix[j]];
+    {
+        bool any_inside = false;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) any_inside = any_inside | inside[j] | amb[j];
+        after_gathers(any_inside);
+    }
     // phase 3: sd > -tdist on float32 differences; guard-banded voxels re-run exactly
     bool any = false;
 #pragma unroll
@@ -336,6 +356,254 @@ __global__ __launch_bounds__(256) void integrate_depth_multi_kernel(float *__res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Brick mapping with conservative culling.
+// The row mapping above gives every wave a 1 x 1 x 256 run of voxels: such a run crosses the frustum planes and the
+// occlusion boundary almost always, so the ~50 % of the voxels a view cannot update still pay the whole projection and
+// gather.  Here a wave owns a compact 4 x 4 x 16 brick (lane = z-pack + 4 y + 16 x; a quarter-wave touches four 64-byte
+// row segments, the four waves of a workgroup sit behind one another in z, so every 256-byte stretch of a row is
+// consumed by one workgroup).  Voxel centres of a brick span a box; an affine map followed by the perspective divide
+// keeps the image of a box in front of the camera inside the bounding rectangle of its eight projected corners.  So:
+//   * all corners in front of the camera and the rectangle entirely outside [0, W-1) x [0, H-1) (with a 2^-10 px
+//     margin, the corners being good to 2^-19 px): no voxel is visible -> the wave skips the view;
+//   * (pinhole) z_max = the largest valid depth over the pixels the rectangle can round to, from a max-pyramid of the
+//     depth map, and z_max + tdist (+ margin) <= the smallest corner depth: every voxel has sd <= -tdist or no depth at
+//     all -> nothing is updated -> skip.
+// Skipping is only ever done when NO voxel of the brick would be updated, so the result is bit-identical to the row
+// kernels (tests compare every voxel).  Bricks that survive run view_pack exactly as before.
+struct BrickGeom {
+    int nzg;           // workgroups along z (64 voxels each)
+    int nyb;           // bricks along y
+    int nxb;           // bricks along x (slab)
+    int order;         // launch order of the workgroups (tuning): 0 = z fastest, 1 = y fastest, 2 = one contiguous x range per XCD
+};
+
+// true when `p`'s view provably updates no voxel of the brick whose first voxel is (x0, y0, z0) (global indices)
+template <bool PINHOLE>
+__device__ __forceinline__ bool brick_culled(const IntegrateParams &p, int x0, int y0, int z0) {
+    constexpr int NC = PINHOLE ? 3 : 4;
+    double base[NC];
+    {
+        const double xf = (double)x0, yf = (double)y0, zf = (double)z0;
+#pragma unroll
+        for (int r = 0; r < NC; ++r) base[r] = __builtin_fma(p.Az[r], zf, __builtin_fma(p.Ax[r], xf, __builtin_fma(p.Ay[r], yf, p.Ac[r])));
+    }
+    int umin = 0x7fffffff, umax = (int)0x80000000, vmin = 0x7fffffff, vmax = (int)0x80000000;
+    double l2min = __builtin_huge_val();
+    bool front = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                        // the affine map is linear in the corner offsets
+        double q[NC];
+#pragma unroll
+        for (int r = 0; r < NC; ++r)
+            q[r] = base[r] + (((c & 1) ? 3.0 * p.Ax[r] : 0.0) + ((c & 2) ? 3.0 * p.Ay[r] : 0.0) + ((c & 4) ? 15.0 * p.Az[r] : 0.0));
+        front = front && q[2] > 1e-6;
+        const double rr = rcp_nr1(q[2]);
+        const int qu = cvt_i32_sat(q[0] * rr), qv = cvt_i32_sat(q[1] * rr);
+        umin = min(umin, qu); umax = max(umax, qu); vmin = min(vmin, qv); vmax = max(vmax, qv);
+        l2min = fmin(l2min, q[NC - 1]);
+    }
+    if (!front) return false;                            // a corner at or behind the camera plane: no claim
+    const int ulim = (p.W - 1) << kFixShift, vlim = (p.H - 1) << kFixShift;
+    // (the corner sums above differ from view_pack's FMA chain by ~1e-13 relative: far inside the 2^-10 px margin)
+    if (umax < -kCullMargin || umin > ulim + kCullMargin || vmax < -kCullMargin || vmin > vlim + kCullMargin) return true;
+    if (!PINHOLE || p.pyr == nullptr) return false;
+    // pixels the voxels can round to: [floor(umin), ceil(umax)] x [floor(vmin), ceil(vmax)], clipped to the image
+    // (corner coordinates may be saturated at INT32_MIN / MAX: clamp to just outside the image BEFORE any arithmetic)
+    umin = max(umin, -2 * kFixOne); vmin = max(vmin, -2 * kFixOne);
+    umax = min(umax, ulim + 2 * kFixOne); vmax = min(vmax, vlim + 2 * kFixOne);
+    int px0 = (umin - kCullMargin) >> kFixShift, px1 = (umax + kCullMargin + kFixOne - 1) >> kFixShift;
+    int py0 = (vmin - kCullMargin) >> kFixShift, py1 = (vmax + kCullMargin + kFixOne - 1) >> kFixShift;
+    px0 = max(px0, 0); py0 = max(py0, 0); px1 = min(px1, p.W - 1); py1 = min(py1, p.H - 1);
+    if (px1 < px0 || py1 < py0) return false;            // (cannot happen after the rectangle test: no claim)
+    int L = 1;
+    while (L <= kPyrLevels && (((px1 >> L) - (px0 >> L)) > 1 || ((py1 >> L) - (py0 >> L)) > 1)) ++L;
+    if (L > kPyrLevels) return false;                    // footprint wider than two 32-pixel cells: no claim
+    const float *lv = p.pyr + p.pyr_off[L];
+    const int wl = p.pyr_w[L];
+    const int cx0 = px0 >> L, cx1 = px1 >> L, cy0 = py0 >> L, cy1 = py1 >> L;
+    const float zmax = fmaxf(fmaxf(lv[cy0 * wl + cx0], lv[cy0 * wl + cx1]), fmaxf(lv[cy1 * wl + cx0], lv[cy1 * wl + cx1]));
+    // sd = z - l2 <= zmax - l2min for every voxel with a valid pixel; the margin covers the float32 rounding of l2min
+    const float l2f = (float)l2min;
+    return zmax + p.tdist_f + fmaf(fabsf(l2f), 4e-7f, 1e-5f) <= l2f;
+}
+
+// Classification pass: one THREAD per brick, bit v of mask[brick] = view v may update a voxel of the brick.  Bricks are
+// numbered ((bx * nyb + by) * nzg + bzg) * 4 + wave, i.e. the four bricks of one sweep workgroup are consecutive.
+template <bool PINHOLE, bool BYVAL>
+__global__ __launch_bounds__(256) void brick_classify_kernel(const IntegrateParams *__restrict__ views, const IntegrateParams p1,
+                                                              int n_views, const BrickGeom g, int n_bricks,
+                                                              unsigned short *__restrict__ mask) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_bricks) return;
+    const int wv = b & 3;
+    int t = b >> 2;
+    const int bzg = t % g.nzg; t /= g.nzg;
+    const int by = t % g.nyb;
+    const int bx = t / g.nyb;
+    const int z0 = 64 * bzg + 16 * wv;
+    unsigned m = 0;
+    if (z0 < p1.Z) {
+        for (int v = 0; v < n_views; ++v) {
+            const IntegrateParams &p = BYVAL ? p1 : views[v];
+            if (!(p.cull && brick_culled<PINHOLE>(p, p.x0 + 4 * bx, 4 * by, z0))) m |= 1u << v;
+        }
+    }
+    mask[b] = (unsigned short)m;
+}
+
+__device__ __forceinline__ void brick_coords(const IntegrateParams &p, const BrickGeom g, int &xl, int &y, int &z0, int &brick) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int bzg, by, bx;
+    const long lin = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    if (g.order == 0) {                                   // z fastest, then y, then x
+        bzg = (int)(lin % g.nzg); by = (int)((lin / g.nzg) % g.nyb); bx = (int)(lin / ((long)g.nzg * g.nyb));
+    } else if (g.order == 1) {                            // y fastest, then z, then x
+        by = (int)(lin % g.nyb); bzg = (int)((lin / g.nyb) % g.nzg); bx = (int)(lin / ((long)g.nzg * g.nyb));
+    } else if (g.order == 3) {                            // x fastest, then y, then z
+        bx = (int)(lin % g.nxb); by = (int)((lin / g.nxb) % g.nyb); bzg = (int)(lin / ((long)g.nxb * g.nyb));
+    } else if (g.order == 4) {                            // y fastest with a diagonal z
+        by = (int)(lin % g.nyb); bzg = (int)((lin / g.nyb + by) % g.nzg); bx = (int)(lin / ((long)g.nzg * g.nyb));
+    } else if (g.order == 5) {                            // y fastest, then x, then z
+        by = (int)(lin % g.nyb); bx = (int)((lin / g.nyb) % g.nxb); bzg = (int)(lin / ((long)g.nxb * g.nyb));
+    } else {
+        // workgroups are dealt round-robin to the 8 XCDs: give XCD k the k-th eighth of the (x, y, z) ordered bricks
+        const long total = (long)gridDim.x * gridDim.y;
+        const long per = (total + 7) / 8;
+        const long logical = (lin & 7) * per + (lin >> 3);      // (total % 8 == 0, checked on the host)
+        bzg = (int)(logical % g.nzg); by = (int)((logical / g.nzg) % g.nyb); bx = (int)(logical / ((long)g.nzg * g.nyb));
+    }
+    brick = (((bx * g.nyb + by) * g.nzg) + bzg) * 4 + wv;
+    xl = 4 * bx + (lane >> 4);                            // slab-local plane
+    y = 4 * by + ((lane >> 2) & 3);
+    z0 = 64 * bzg + 16 * wv + 4 * (lane & 3);
+}
+
+// One view.  mask == NULL: every brick is swept (no classification pass ran).
+template <typename DepthT, bool PINHOLE, bool EARLY>
+__global__ __launch_bounds__(256) void integrate_depth_brick_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                     const DepthT *__restrict__ depth, const IntegrateParams p,
+                                                                     const BrickGeom g, const unsigned short *__restrict__ mask) {
+    int xl, y, z0, brick;
+    brick_coords(p, g, xl, y, z0, brick);
+    if (mask && __builtin_amdgcn_readfirstlane((int)mask[__builtin_amdgcn_readfirstlane(brick)]) == 0) return;   // (wave-uniform)
+    const bool in_grid = xl < p.nx && y < p.Y && z0 < p.Z;
+    float ms[4];
+    bool upd[4];
+    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
+    using P = Pack<float, 4>;
+    P t, w;
+    bool loaded = false;
+    // T / w of a pack that projects into the image are requested together with its depth gathers: in the bricks that
+    // survive the classification nearly every such pack is updated, so little is fetched in vain and the sweep pays one
+    // memory round trip instead of two
+    const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, depth, p.x0 + xl, y, z0, ms, upd, [&](bool any_inside) {
+        if (EARLY && any_inside && in_grid) {
+            t = *reinterpret_cast<const P *>(tsdf + off);
+            w = *reinterpret_cast<const P *>(tsdf_w + off);
+            loaded = true;
+        }
+    });
+    if (!(any && in_grid)) return;
+    if (!loaded) {                                        // (late variant; early: cannot happen, any implies any_inside)
+        t = *reinterpret_cast<const P *>(tsdf + off);
+        w = *reinterpret_cast<const P *>(tsdf_w + off);
+    }
+    apply_pack<4>(t, w, ms, upd, p.wmax_f);
+    *reinterpret_cast<P *>(tsdf + off) = t;
+    *reinterpret_cast<P *>(tsdf_w + off) = w;
+}
+
+template <typename DepthT, bool PINHOLE>
+__global__ __launch_bounds__(256) void integrate_depth_multi_brick_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                           const IntegrateParams *__restrict__ views, const ViewPtrs vp,
+                                                                           const BrickGeom g, const unsigned short *__restrict__ mask) {
+    int xl, y, z0, brick;
+    brick_coords(views[0], g, xl, y, z0, brick);
+    unsigned m = mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)mask[__builtin_amdgcn_readfirstlane(brick)]) : (1u << vp.n) - 1u;
+    if (m == 0) return;
+    const bool in_grid = xl < views[0].nx && y < views[0].Y && z0 < views[0].Z;
+    using P = Pack<float, 4>;
+    P t, w;
+    bool loaded = false;
+    const size_t off = ((size_t)xl * views[0].Y + y) * views[0].Z + z0;
+    while (m) {                                           // views in ascending order: the order of consecutive sweeps
+        const int v = __builtin_ctz(m);
+        m &= m - 1;
+        const IntegrateParams &p = views[v];             // uniform address: scalar loads
+        float ms[4];
+        bool upd[4];
+        const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd);
+        if (!(any && in_grid)) continue;
+        if (!loaded) {
+            t = *reinterpret_cast<const P *>(tsdf + off);
+            w = *reinterpret_cast<const P *>(tsdf_w + off);
+            loaded = true;
+        }
+        apply_pack<4>(t, w, ms, upd, p.wmax_f);
+    }
+    if (loaded) {
+        *reinterpret_cast<P *>(tsdf + off) = t;
+        *reinterpret_cast<P *>(tsdf_w + off) = w;
+    }
+}
+
+// Max-depth pyramid of up to kMaxViews depth maps: blockIdx.z = view, one workgroup per 32 x 32 pixel tile, levels 1..5.
+struct PyrViews {
+    const void *depth[kMaxViews];
+    float *pyr[kMaxViews];
+};
+
+template <typename DepthT>
+__global__ __launch_bounds__(256) void depth_pyramid_kernel(const PyrViews pv, int H, int W, const IntegrateParams p1) {
+    // level geometry is the same for every view: taken from p1 (kernel argument)
+    const DepthT *__restrict__ depth = static_cast<const DepthT *>(pv.depth[blockIdx.z]);
+    float *__restrict__ pyr = pv.pyr[blockIdx.z];
+    __shared__ float s[256];
+    const int t = threadIdx.x;
+    const int qx = t & 15, qy = t >> 4;
+    const int px = 32 * (int)blockIdx.x + 2 * qx, py = 32 * (int)blockIdx.y + 2 * qy;
+    auto zval = [&](int x, int y) {
+        if (x >= W || y >= H) return 0.0f;
+        const float z = -(float)depth[(size_t)y * W + x];
+        return z > 0.0f ? z : 0.0f;                       // invalid (0, NaN) pixels never update a voxel
+    };
+    float m = fmaxf(fmaxf(zval(px, py), zval(px + 1, py)), fmaxf(zval(px, py + 1), zval(px + 1, py + 1)));
+    {
+        const int cx = 16 * (int)blockIdx.x + qx, cy = 16 * (int)blockIdx.y + qy;
+        if (cx < p1.pyr_w[1] && cy < p1.pyr_h[1]) pyr[p1.pyr_off[1] + cy * p1.pyr_w[1] + cx] = m;
+    }
+    s[t] = m;
+    __syncthreads();
+    int n = 16;                                           // side of the level held in s[]
+#pragma unroll
+    for (int L = 2; L <= kPyrLevels; ++L) {
+        const int h = n >> 1;
+        float v = 0.0f;
+        const int x = t % h, y = t / h;
+        if (t < h * h) v = fmaxf(fmaxf(s[(2 * y) * n + 2 * x], s[(2 * y) * n + 2 * x + 1]), fmaxf(s[(2 * y + 1) * n + 2 * x], s[(2 * y + 1) * n + 2 * x + 1]));
+        __syncthreads();
+        if (t < h * h) {
+            s[y * h + x] = v;
+            const int cx = h * (int)blockIdx.x + x, cy = h * (int)blockIdx.y + y;
+            if (cx < p1.pyr_w[L] && cy < p1.pyr_h[L]) pyr[p1.pyr_off[L] + cy * p1.pyr_w[L] + cx] = v;
+        }
+        __syncthreads();
+        n = h;
+    }
+}
+
+static size_t pyramid_floats(int H, int W, int *off, int *pw, int *ph) {
+    size_t tot = 0;
+    for (int L = 1; L <= kPyrLevels; ++L) {
+        const int wl = (W + (1 << L) - 1) >> L, hl = (H + (1 << L) - 1) >> L;
+        if (off) { off[L] = (int)tot; pw[L] = wl; ph[L] = hl; }
+        tot += (size_t)wl * hl;
+    }
+    return (tot + 3) / 4 * 4;                             // whole 16-byte units
+}
+
 // Any volume dtype: the reference's chain evaluated exactly for every voxel.
 template <typename VolT, typename DepthT, int VEC, bool PINHOLE>
 __global__ __launch_bounds__(256) void integrate_depth_exact_kernel(VolT *__restrict__ tsdf,
@@ -462,6 +730,8 @@ static bool fill_params(IntegrateParams &p, const int res[3], int tsdf_res, int 
     p.zpacks = vec4 ? res[2] / 4 : res[2];
     p.zp_shift = -1;
     for (int b = 0; b < 31; ++b) if (p.zpacks == (1 << b)) p.zp_shift = b;
+    p.pyr = nullptr; p.cull = 0;
+    for (int l = 0; l < 6; ++l) { p.pyr_off[l] = 0; p.pyr_w[l] = 0; p.pyr_h[l] = 0; }
     fold_affine(p);
     {   // ~kTargetBlocks blocks in total, each looping over consecutive x planes
         const long per_plane_blocks = ((long)p.Y * p.zpacks + 255) / 256;
@@ -478,11 +748,58 @@ static bool fill_params(IntegrateParams &p, const int res[3], int tsdf_res, int 
 
 }  // namespace dfh
 
+namespace dfh {
+
+static size_t params_bytes(int n_views) { return ((size_t)n_views * sizeof(IntegrateParams) + 15) / 16 * 16; }
+
+// pyramid geometry into p, pointer = workspace + params + view * pyramid
+static void attach_pyramid(IntegrateParams &p, void *workspace, int n_views, int view, int H, int W) {
+    const size_t pf = pyramid_floats(H, W, p.pyr_off, p.pyr_w, p.pyr_h);
+    p.pyr = reinterpret_cast<const float *>(static_cast<char *>(workspace) + params_bytes(n_views)) + (size_t)view * pf;
+}
+
+template <typename DepthT>
+static int launch_pyramids(const void *const *depth, int n_views, int H, int W, const IntegrateParams *hp, hipStream_t s) {
+    PyrViews pv;
+    for (int v = 0; v < n_views; ++v) { pv.depth[v] = depth[v]; pv.pyr[v] = const_cast<float *>(hp[v].pyr); }
+    dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 31) / 32), (unsigned)n_views);
+    hipLaunchKernelGGL(depth_pyramid_kernel<DepthT>, grid, dim3(256), 0, s, pv, H, W, hp[0]);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+static BrickGeom brick_geom(int Y, int Z, int nx, dim3 &grid, int &n_bricks) {
+    BrickGeom g;
+    g.nzg = (Z + 63) / 64;
+    g.nyb = (Y + 3) / 4;
+    const int nxb = (nx + 3) / 4;
+    g.nxb = nxb;
+    // launch order of the workgroups: measured at 512^3 (profiles/r2_k1_experiments.txt) y-fastest beats z-fastest by 3-10 %
+    // (which HBM channels the workgroups in flight hit together), an XCD-contiguous order loses 20 %
+    g.order = getenv("DFH_K1_ORDER") ? atoi(getenv("DFH_K1_ORDER")) : 1;
+    if (g.order == 2 && ((long)g.nzg * g.nyb * nxb) % 8 != 0) g.order = 0;     // the XCD split needs whole eighths
+    grid = dim3((unsigned)(g.nzg * g.nyb), (unsigned)nxb);
+    n_bricks = g.nzg * g.nyb * nxb * 4;
+    return g;
+}
+
+static size_t pyr_bytes(int n_views, int H, int W) { return (size_t)n_views * pyramid_floats(H, W, nullptr, nullptr, nullptr) * sizeof(float); }
+
+}  // namespace dfh
+
+extern "C" size_t dfh_integrate_workspace_bytes(int n_views, int H, int W, const int res[3], int x0, int x1) {
+    if (n_views <= 0 || H < 2 || W < 2 || !res || res[1] <= 0 || res[2] <= 0 || x1 < x0) return 0;
+    dim3 grid;
+    int n_bricks = 0;
+    dfh::brick_geom(res[1], res[2], x1 - x0, grid, n_bricks);
+    return dfh::params_bytes(n_views) + dfh::pyr_bytes(n_views, H, W) + ((size_t)n_bricks * sizeof(unsigned short) + 15) / 16 * 16;
+}
+
 extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3],
                                    int tsdf_res, int x0, int x1, const void *depth, int depth_dtype,
                                    int H, int W, const double K[9], const double Kinv[9],
                                    const double lw[12], double scale, const double center[3],
-                                   double tdist, double wmax, void *stream) {
+                                   double tdist, double wmax, void *workspace, size_t workspace_bytes, void *stream) {
     using namespace dfh;
     DFH_REQUIRE(tsdf && tsdf_w && depth && res && K && Kinv && lw && center, "dfh_integrate_depth: null pointer");
     DFH_REQUIRE(vol_dtype == DFH_F32 || vol_dtype == DFH_F64, "dfh_integrate_depth: bad vol_dtype %d", vol_dtype);
@@ -503,6 +820,42 @@ extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, cons
     // fixed-point pixel coordinates need (dim-1) << 20 to fit in int32
     const bool fast_ok = H <= kFastMaxDim && W <= kFastMaxDim && scale > 0.0 && tdist > 0.0;
 
+    // brick sweep + culling: float32 volumes on the fast path, with a workspace for the depth pyramid and the brick masks
+    // For ONE view the brick sweep costs two small launches more (pyramid, classification) and pays off on large slabs only:
+    // 512^3 337-350 us against 360-394 us for the row sweep (a view that updates nothing: 73 against 233 us), 256^3 48-51
+    // against 43.5 us (profiles/r2_k1_experiments.txt).  Smaller slabs keep the row sweep; DFH_K1_BRICKS_MIN overrides.
+    const bool have_ws = workspace && workspace_bytes >= dfh_integrate_workspace_bytes(1, H, W, res, x0, x1);
+    const long bricks_min = getenv("DFH_K1_BRICKS_MIN") ? atol(getenv("DFH_K1_BRICKS_MIN")) : 131072;
+    const long slab_bricks = (long)((res[1] + 3) / 4) * ((res[2] + 63) / 64) * ((x1 - x0 + 3) / 4) * 4;
+    const bool bricks = vol_dtype == DFH_F32 && fast_ok && vec4 && !getenv("DFH_K1_NO_BRICKS") && slab_bricks >= bricks_min &&
+                        (have_ws || getenv("DFH_K1_BRICKS_NOCULL"));
+    if (bricks) {
+        const bool cull = have_ws && !getenv("DFH_K1_BRICKS_NOCULL");
+        dim3 grid;
+        int n_bricks = 0;
+        const BrickGeom g = brick_geom(p.Y, p.Z, p.nx, grid, n_bricks);
+        unsigned short *mask = nullptr;
+        if (cull) {
+            p.cull = 1;
+            attach_pyramid(p, workspace, 1, 0, H, W);
+            mask = reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + params_bytes(1) + pyr_bytes(1, H, W));
+            const void *dptr[1] = {depth};
+            const int rc = depth_dtype == DFH_F32 ? launch_pyramids<float>(dptr, 1, H, W, &p, s) : launch_pyramids<double>(dptr, 1, H, W, &p, s);
+            if (rc != DFH_OK) return rc;
+            const dim3 cgrid((unsigned)((n_bricks + 255) / 256));
+            if (pinhole) hipLaunchKernelGGL((brick_classify_kernel<true, true>), cgrid, dim3(256), 0, s, nullptr, p, 1, g, n_bricks, mask);
+            else hipLaunchKernelGGL((brick_classify_kernel<false, true>), cgrid, dim3(256), 0, s, nullptr, p, 1, g, n_bricks, mask);
+        }
+        const bool early = !getenv("DFH_K1_LATE_LOADS");
+#define DFH_BRICK(DT, PH) do { if (early) hipLaunchKernelGGL((integrate_depth_brick_kernel<DT, PH, true>), grid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const DT *)depth, p, g, mask); \
+                               else hipLaunchKernelGGL((integrate_depth_brick_kernel<DT, PH, false>), grid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const DT *)depth, p, g, mask); } while (0)
+        if (depth_dtype == DFH_F32) { if (pinhole) DFH_BRICK(float, true); else DFH_BRICK(float, false); }
+        else { if (pinhole) DFH_BRICK(double, true); else DFH_BRICK(double, false); }
+#undef DFH_BRICK
+        DFH_HIP_CHECK(hipGetLastError());
+        return DFH_OK;
+    }
+
 #define DFH_DISPATCH(VT, DT, FAST)                                                            \
     return vec4 ? launch_integrate<VT, DT, 4, FAST>(tsdf, tsdf_w, depth, p, pinhole, s)       \
                 : launch_integrate<VT, DT, 1, FAST>(tsdf, tsdf_w, depth, p, pinhole, s)
@@ -520,7 +873,7 @@ extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, cons
 }
 
 extern "C" size_t dfh_integrate_multi_workspace_bytes(int n_views) {
-    return n_views > 0 ? (size_t)n_views * sizeof(dfh::IntegrateParams) : 0;
+    return n_views > 0 ? dfh::params_bytes(n_views) : 0;
 }
 
 extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
@@ -544,7 +897,7 @@ extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype
         // one sweep per view: the same results (every argument is checked there)
         for (int v = 0; v < n_views; ++v) {
             const int rc = dfh_integrate_depth(tsdf, tsdf_w, vol_dtype, res, tsdf_res, x0, x1, depth[v], depth_dtype, H, W, K, Kinv,
-                                               lw + 12 * v, scale, center, tdist, wmax, stream);
+                                               lw + 12 * v, scale, center, tdist, wmax, workspace, workspace_bytes, stream);
             if (rc != DFH_OK) return rc;
         }
         return DFH_OK;
@@ -556,16 +909,41 @@ extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype
     IntegrateParams hp[kMaxViews];
     ViewPtrs vp;
     bool pinhole = true;
+    const bool have_pyr = workspace_bytes >= dfh_integrate_workspace_bytes(n_views, H, W, res, x0, x1);
+    const bool bricks = vec4 && !getenv("DFH_K1_NO_BRICKS") && (have_pyr || getenv("DFH_K1_BRICKS_NOCULL"));
+    const bool cull = bricks && have_pyr && !getenv("DFH_K1_BRICKS_NOCULL");
     for (int v = 0; v < n_views; ++v) {
         pinhole = fill_params(hp[v], res, tsdf_res, x0, x1, H, W, K, Kinv, lw + 12 * v, scale, center, tdist, wmax, vec4) && pinhole;
         vp.depth[v] = depth[v];
+        hp[v].cull = cull ? 1 : 0;
+        if (cull) attach_pyramid(hp[v], workspace, n_views, v, H, W);
     }
     vp.n = n_views;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DFH_HIP_CHECK(hipMemcpyAsync(workspace, hp, sizeof(IntegrateParams) * n_views, hipMemcpyHostToDevice, s));   // pageable source: staged before the call returns
     const IntegrateParams &p = hp[0];
-    dim3 grid((unsigned)(((long)p.Y * p.zpacks + 255) / 256), (unsigned)((p.nx + p.planes_per_block - 1) / p.planes_per_block)), block(256);
     const IntegrateParams *dv = static_cast<const IntegrateParams *>(workspace);
+    if (bricks) {
+        dim3 bgrid;
+        int n_bricks = 0;
+        const BrickGeom g = brick_geom(p.Y, p.Z, p.nx, bgrid, n_bricks);
+        unsigned short *mask = nullptr;
+        if (cull) {
+            mask = reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + params_bytes(n_views) + pyr_bytes(n_views, H, W));
+            const int rc = depth_dtype == DFH_F32 ? launch_pyramids<float>(depth, n_views, H, W, hp, s) : launch_pyramids<double>(depth, n_views, H, W, hp, s);
+            if (rc != DFH_OK) return rc;
+            const dim3 cgrid((unsigned)((n_bricks + 255) / 256));
+            if (pinhole) hipLaunchKernelGGL((brick_classify_kernel<true, false>), cgrid, dim3(256), 0, s, dv, p, n_views, g, n_bricks, mask);
+            else hipLaunchKernelGGL((brick_classify_kernel<false, false>), cgrid, dim3(256), 0, s, dv, p, n_views, g, n_bricks, mask);
+        }
+#define DFH_MBRICK(DT, PH) hipLaunchKernelGGL((integrate_depth_multi_brick_kernel<DT, PH>), bgrid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, dv, vp, g, mask)
+        if (depth_dtype == DFH_F32) { if (pinhole) DFH_MBRICK(float, true); else DFH_MBRICK(float, false); }
+        else { if (pinhole) DFH_MBRICK(double, true); else DFH_MBRICK(double, false); }
+#undef DFH_MBRICK
+        DFH_HIP_CHECK(hipGetLastError());
+        return DFH_OK;
+    }
+    dim3 grid((unsigned)(((long)p.Y * p.zpacks + 255) / 256), (unsigned)((p.nx + p.planes_per_block - 1) / p.planes_per_block)), block(256);
 #define DFH_MULTI(DT, VEC, PH) hipLaunchKernelGGL((integrate_depth_multi_kernel<DT, VEC, PH>), grid, block, 0, s, (float *)tsdf, (float *)tsdf_w, dv, vp)
     if (depth_dtype == DFH_F32) {
         if (vec4) { if (pinhole) DFH_MULTI(float, 4, true); else DFH_MULTI(float, 4, false); }

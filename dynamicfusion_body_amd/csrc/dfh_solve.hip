@@ -273,6 +273,73 @@ __global__ __launch_bounds__(256) void closest_corr_kernel(const double *__restr
     keep[i] = best_cost <= tolerance ? 1 : 0;                    // :242
 }
 
+// ------------------------------------------------------------------------------- deformation-graph maintenance
+// Device side of update_graph / construct_graph (reference core/fusion.py:101-123, 201-239).
+
+// Nearest cloud point of every query (KDTree(cloud).query(q), :209-212: a node's anchor vertex): one workgroup per
+// query, threads stride over the cloud, lexicographic (d2, index) minimum -- ties go to the lower index.
+__global__ __launch_bounds__(256) void nearest_point_kernel(const double *__restrict__ query, int nq, const double *__restrict__ cloud,
+                                                             int nc, int *__restrict__ idx_out, double *__restrict__ d2_out) {
+    __shared__ double sd[256];
+    __shared__ int si[256];
+    const int qi = blockIdx.x;
+    const double qx = query[3 * (size_t)qi], qy = query[3 * (size_t)qi + 1], qz = query[3 * (size_t)qi + 2];
+    double best = __builtin_huge_val();
+    int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < nc; j += 256) {
+        const double dx = qx - cloud[3 * (size_t)j], dy = qy - cloud[3 * (size_t)j + 1], dz = qz - cloud[3 * (size_t)j + 2];
+        const double d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < best) { best = d2; bi = j; }            // (ascending j per thread: the first minimum is kept)
+    }
+    sd[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            const double o = sd[threadIdx.x + st];
+            const int oi = si[threadIdx.x + st];
+            if (o < sd[threadIdx.x] || (o == sd[threadIdx.x] && oi < si[threadIdx.x])) { sd[threadIdx.x] = o; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        idx_out[qi] = si[0];
+        if (d2_out) d2_out[qi] = sd[0];
+    }
+}
+
+// "unsupported surface point" test of update_graph (:215-219): min over the vertex's knn nodes of |node - v| / w >= 1
+__global__ __launch_bounds__(256) void graph_unsupported_kernel(const double *__restrict__ verts, int V, const int *__restrict__ nbr, int k,
+                                                                 const double *__restrict__ node_pos, const double *__restrict__ node_w,
+                                                                 unsigned char *__restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const double px = verts[3 * (size_t)i], py = verts[3 * (size_t)i + 1], pz = verts[3 * (size_t)i + 2];
+    double m = __builtin_huge_val();
+    for (int j = 0; j < k; ++j) {
+        const int gi = nbr[(size_t)i * k + j];
+        const double dx = node_pos[3 * gi] - px, dy = node_pos[3 * gi + 1] - py, dz = node_pos[3 * gi + 2] - pz;
+        const double r = sqrt((dx * dx + dy * dy) + dz * dz) / node_w[gi];
+        m = r < m ? r : m;
+    }
+    flag[i] = m >= 1.0 ? 1 : 0;
+}
+
+// Fusion.dq_blend for a batch (:527-551): the normalised blend of the given nodes' DQs at every point (identity when
+// the blend vanishes) -- the DQ a newly inserted node starts from (:222).
+__global__ __launch_bounds__(256) void dq_blend_points_kernel(const double *__restrict__ pts, int P, const int *__restrict__ nbr, int k,
+                                                               const double *__restrict__ node_dq, const double *__restrict__ node_pos,
+                                                               const double *__restrict__ node_w, double *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    int idx[kKMaxS];
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) idx[j] = j < k ? nbr[(size_t)i * k + j] : 0;
+    double bh[8];
+    blend_from_indices(node_dq, node_pos, node_w, idx, k, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], bh, nullptr, nullptr);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[8 * (size_t)i + c] = bh[c];
+}
+
 // ------------------------------------------------------------------------------- sample setup
 
 // k nearest nodes + Gaussian blend weights of arbitrary sample points.  The 256 samples of a workgroup are
@@ -1599,6 +1666,40 @@ int dfh_closest_correspondences(const double *warped_pos, const double *warped_n
     DFH_REQUIRE(warped_pos && warped_nrm && live_verts && corr_out && keep_out, "dfh_closest_correspondences: null pointer");
     hipLaunchKernelGGL(closest_corr_kernel, dim3((n_verts + 255) / 256), dim3(256), 0, (hipStream_t)stream, warped_pos, warped_nrm,
                        n_verts, live_verts, n_live, knn, tolerance, corr_out, cost_out, keep_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_nearest_points(const double *query, int n_query, const double *cloud, int n_cloud, int *idx_out, double *d2_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_query >= 0 && n_cloud >= 1, "dfh_nearest_points: bad sizes");
+    if (n_query == 0) return DFH_OK;
+    DFH_REQUIRE(query && cloud && idx_out, "dfh_nearest_points: null pointer");
+    hipLaunchKernelGGL(nearest_point_kernel, dim3(n_query), dim3(256), 0, (hipStream_t)stream, query, n_query, cloud, n_cloud, idx_out, d2_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_graph_unsupported(const double *verts, int n_verts, const int *nbr, int knn, const double *node_pos, const double *node_w,
+                          int n_nodes, unsigned char *flag_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_verts >= 0 && knn >= 1 && knn <= kKMaxS && n_nodes >= 1, "dfh_graph_unsupported: bad sizes");
+    if (n_verts == 0) return DFH_OK;
+    DFH_REQUIRE(verts && nbr && node_pos && node_w && flag_out, "dfh_graph_unsupported: null pointer");
+    hipLaunchKernelGGL(graph_unsupported_kernel, dim3((n_verts + 255) / 256), dim3(256), 0, (hipStream_t)stream, verts, n_verts, nbr, knn,
+                       node_pos, node_w, flag_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_dq_blend_points(const double *points, int n_points, const int *nbr, int knn, const double *node_dq, const double *node_pos,
+                        const double *node_w, int n_nodes, double *dq_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_points >= 0 && knn >= 1 && knn <= kKMaxS && n_nodes >= 1, "dfh_dq_blend_points: bad sizes");
+    if (n_points == 0) return DFH_OK;
+    DFH_REQUIRE(points && nbr && node_dq && node_pos && node_w && dq_out, "dfh_dq_blend_points: null pointer");
+    hipLaunchKernelGGL(dq_blend_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, points, n_points, nbr, knn,
+                       node_dq, node_pos, node_w, dq_out);
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }

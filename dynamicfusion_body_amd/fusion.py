@@ -410,23 +410,47 @@ class Fusion:
         self._radius = self._subsample_rate * np.average(e)                      # :92
         self.construct_graph()
 
-    def construct_graph(self):
-        """Reference core/fusion.py:101-123 (needs `_vertices` and `_radius`)."""
+    def construct_graph(self, host=False):
+        """Reference core/fusion.py:101-123 (needs `_vertices` and `_radius`).  The vertex -> node table is computed on the
+        device (dfh_sample_knn); host=True runs the numpy / KDTree twin instead (CPU-side tests of the definition)."""
         if self._vertices is None or getattr(self, '_radius', None) is None:
             raise ValueError('construct_graph needs _vertices and _radius')
-        self._nodes, self._kdtree, self._neighbor_look_up = _graph.construct_graph(self._vertices, self._radius, self._knn)
+        if host:
+            self._nodes, self._kdtree, self._neighbor_look_up = _graph.construct_graph(self._vertices, self._radius, self._knn)
+            return
+        from scipy.spatial import KDTree
+        vidx, pos, dq, w, lookup = _graph.construct_graph_device(self._vertices, self._radius, self._knn)
+        self._nodes = [(vidx[i], pos[i], dq[i].copy(), w[i]) for i in range(len(pos))]
+        self._kdtree = KDTree(pos)                                               # (N nodes: host look-ups of single points)
+        self._neighbor_look_up = lookup.cpu().numpy().astype(np.int64)
 
     def _dq_blend_kdtree(self, pos):
         d, loc = self._kdtree.query(pos, k=self._knn)                       # core/fusion.py:529
         return self.dq_blend(pos, [self._nodes[i][2] for i in np.atleast_1d(loc)], np.atleast_1d(loc))
 
-    def update_graph(self, refresh_surface=True):
+    def update_graph(self, refresh_surface=True, host=False):
         """Reference core/fusion.py:201-239: refresh the surface, re-anchor the nodes, insert nodes
-        for unsupported vertices, rebuild the lookup, drop the live-frame data, write the warp field."""
+        for unsupported vertices, rebuild the lookup, drop the live-frame data, write the warp field.
+        The O(vertices x nodes) steps run on the device (graph.update_graph_device); host=True runs the numpy / KDTree
+        twin instead (CPU-side tests of the definition against the reference's outputs)."""
         if refresh_surface:
             self.marching_cubes()
-        self._nodes, self._kdtree, self._neighbor_look_up, n_new = _graph.update_graph(
-            self._nodes, self._kdtree, self._vertices, self._radius, self._knn, self._dq_blend_kdtree)
+        if host:
+            self._nodes, self._kdtree, self._neighbor_look_up, n_new = _graph.update_graph(
+                self._nodes, self._kdtree, self._vertices, self._radius, self._knn, self._dq_blend_kdtree)
+        else:
+            from scipy.spatial import KDTree
+            pos, dq, w, _ = self.node_arrays()
+            vidx, P2, Q2, W2, lookup, n_new = _graph.update_graph_device(pos, dq, w, np.asarray(self._vertices, dtype=np.float64),
+                                                                        self._radius, self._knn)
+            vidx, P2, Q2 = vidx.cpu().numpy(), P2.cpu().numpy(), Q2.cpu().numpy()
+            old = self._nodes
+            N = len(old)
+            # old nodes keep their position / DQ objects (:208-212); new ones carry the blend (:222)
+            self._nodes = [(vidx[i], old[i][1], old[i][2], 2 * self._radius) for i in range(N)] + \
+                          [(vidx[i], P2[i], Q2[i], 2 * self._radius) for i in range(N, len(P2))]
+            self._kdtree = KDTree(P2)
+            self._neighbor_look_up = lookup.cpu().numpy().astype(np.int64)
         self._curr_tsdf = None
         self._correspondences = []
         self._workspace_key = None

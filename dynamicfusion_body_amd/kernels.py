@@ -25,13 +25,37 @@ def _check_volume_pair(T, Wt, res, x_range):
                          % (tuple(T.shape), tuple(Wt.shape), want, tuple(res)))
 
 
+_ws_cache = {}
+
+
+def integrate_workspace(n_views, H, W, res, x_range=None, device=None):
+    """Scratch tensor for integrate_depth / integrate_depth_views on planes `x_range` of a `res` grid (the views'
+    parameters, depth pyramids and per-brick view masks); cached per (device, stream, n_views, H, W, grid, slab size):
+    launches on one stream are ordered, so consecutive calls may share it."""
+    lib = _lib.load()
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if x_range is None:
+        x_range = (0, res[0])
+    nx = int(x_range[1]) - int(x_range[0])
+    key = (dev.index, current_stream_ptr(), int(n_views), int(H), int(W), int(res[1]), int(res[2]), nx)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        nbytes = lib.dfh_integrate_workspace_bytes(int(n_views), int(H), int(W), _lib.iarr(res), 0, nx)
+        ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
+        if len(_ws_cache) > 64:
+            _ws_cache.clear()
+        _ws_cache[key] = ws
+    return ws
+
+
 def integrate_depth(T, Wt, depth, K, Kinv, lw, scale, center, tdist, wmax=100.0, tsdf_res=None,
-                    res=None, x_range=None):
+                    res=None, x_range=None, workspace=None):
     """K1 = FusionDM.fuseDepths (reference core/fusion_dm.py:180-217) on device tensors.
 
     T, Wt : (x1-x0, Y, Z) float32/float64 CUDA tensors holding planes [x0,x1) of a `res`
             grid (default: the whole grid).  depth: (H, W) float32/float64 CUDA tensor of
-            negative depths.  Runs asynchronously on the current stream."""
+            negative depths.  Runs asynchronously on the current stream.  workspace: scratch from
+            integrate_workspace(1, H, W) (default: a cached one); False = sweep without brick culling."""
     require_gpu()
     lib = _lib.load()
     if res is None:
@@ -46,11 +70,14 @@ def integrate_depth(T, Wt, depth, K, Kinv, lw, scale, center, tdist, wmax=100.0,
     if not (isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dim() == 2 and depth.is_contiguous()):
         raise ValueError("depth must be a contiguous 2-D CUDA tensor")
     H, W = depth.shape
+    if workspace is None and T.dtype == torch.float32:
+        workspace = integrate_workspace(1, H, W, res, x_range, T.device)
+    ws_ptr, ws_bytes = (workspace.data_ptr(), workspace.numel() * workspace.element_size()) if isinstance(workspace, torch.Tensor) else (0, 0)
     rc = lib.dfh_integrate_depth(T.data_ptr(), Wt.data_ptr(), dtype_code(T), _lib.iarr(res), int(tsdf_res),
                                  int(x_range[0]), int(x_range[1]), depth.data_ptr(), dtype_code(depth),
                                  int(H), int(W), _lib.darr(K, 9), _lib.darr(Kinv, 9), _lib.darr(lw, 12),
                                  float(scale), _lib.darr(np.asarray(center, dtype=np.float64), 3),
-                                 float(tdist), float(wmax), current_stream_ptr())
+                                 float(tdist), float(wmax), ws_ptr, ws_bytes, current_stream_ptr())
     _lib.check(rc, "dfh_integrate_depth")
     return T, Wt
 
@@ -84,9 +111,9 @@ def integrate_depth_views(T, Wt, depths, K, Kinv, lws, scale, center, tdist, wma
     for i in range(0, len(depths), 16):
         dd, ll = depths[i:i + 16], lws[i:i + 16]
         n = len(dd)
-        nbytes = lib.dfh_integrate_multi_workspace_bytes(n)
+        nbytes = lib.dfh_integrate_workspace_bytes(n, int(H), int(W), _lib.iarr(res), int(x_range[0]), int(x_range[1]))
         ws = workspace if (workspace is not None and workspace.numel() * workspace.element_size() >= nbytes) else \
-            torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=T.device)
+            integrate_workspace(n, H, W, res, x_range, T.device)
         ptrs = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dd])
         lw_flat = np.concatenate([np.asarray(l, dtype=np.float64).reshape(12) for l in ll])
         rc = lib.dfh_integrate_depth_multi(T.data_ptr(), Wt.data_ptr(), dtype_code(T), _lib.iarr(res), int(tsdf_res), int(x_range[0]),

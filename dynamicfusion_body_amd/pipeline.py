@@ -135,7 +135,7 @@ class SlabFrame:
         ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
         self.fs.set_graph(node_pos, ident, node_w)
         self.ws_dqb = kernels.dqb_workspace((R, R, R), (self.a, self.b), knn=knn, n_nodes=N)
-        self.ws_views = torch.empty(16 * 128, dtype=torch.int64, device="cuda")        # dfh_integrate_depth_multi's per-view parameters
+        self.ws_views = None                     # dfh_integrate_depth_multi's scratch (parameters + depth pyramids): sized on first use
         self.knn_bricks = None
         if self.b > self.a:
             kernels.dqb_build_candidates(self.ws_dqb, (R, R, R), node_pos, knn, (self.a, self.b))
@@ -163,7 +163,61 @@ class SlabFrame:
             Tp.append(hi[None]); Wp.append(torch.zeros_like(hi)[None])
         return self.fs.set_canonical(torch.cat(Tp).contiguous(), torch.cat(Wp).contiguous(), band=self.band, x0=x0, knn_bricks=self.knn_bricks)
 
-    def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5, stage_ms=None):
+    def update_graph(self, radius=None):
+        """Deformation-graph maintenance after a TSDF update (reference Fusion.update_graph, core/fusion.py:201-239) on the
+        device path, with this loop's surface points -- the band samples of the canonical slab -- in the role of the mesh
+        vertices: samples no node supports (min over their knn nodes of |node - p| / w >= 1) are radius-subsampled into new
+        nodes whose DQs are the blend of the old graph at their positions; the solver's graph, K3's stored neighbourhoods
+        and candidate lists and the samples' node table are rebuilt when nodes were inserted.  Every rank inserts the same
+        nodes (the unsupported points are gathered in rank order before the greedy subsampling).  Returns the number of
+        inserted nodes.  radius defaults to half the nodes' weight (w = 2 radius, core/fusion.py:116)."""
+        from . import graph as _graph
+        sv = self.fs.solver
+        if radius is None:
+            radius = 0.5 * float(sv.node_w[0])
+        pts = sv.spos if sv.S > 0 else torch.zeros((0, 3), dtype=torch.float64, device="cuda")
+        gather = None
+        if self.ws > 1:
+            import torch.distributed as dist
+
+            def gather(uns):
+                n = torch.tensor([uns.shape[0]], dtype=torch.int64)
+                sizes = [torch.zeros_like(n) for _ in range(self.ws)]
+                dist.all_gather(sizes, n if dist.get_backend() != "nccl" else n.cuda())
+                m = max(1, int(max(int(s_) for s_ in sizes)))
+                buf = torch.zeros((m, 3), dtype=torch.float64)
+                buf[:uns.shape[0]] = torch.from_numpy(uns.reshape(-1, 3))
+                if dist.get_backend() == "nccl":
+                    buf = buf.cuda()
+                parts = [torch.zeros_like(buf) for _ in range(self.ws)]
+                dist.all_gather(parts, buf)
+                return np.concatenate([p_[:int(n_)].cpu().numpy() for p_, n_ in zip(parts, sizes)])
+        # the samples are stored sorted by node tuple; the greedy subsampling depends on the order of its input, so it is
+        # fed in a canonical order (by position) that does not depend on the slab partition
+        def canon(uns):
+            if gather is not None:
+                uns = gather(uns)
+            if len(uns) == 0:
+                return uns
+            return uns[np.lexsort((uns[:, 2], uns[:, 1], uns[:, 0]))]
+        vidx, P2, Q2, W2, lookup, n_new = _graph.update_graph_device(sv.node_pos, sv.node_dq, sv.node_w, pts, radius, self.knn,
+                                                                    gather_unsupported=canon)
+        if n_new == 0:
+            return 0
+        self.fs.set_graph(P2, Q2, W2)                    # resets the block pattern; node-node table of the regulariser rebuilt
+        N = int(P2.shape[0])
+        R = self.R
+        self.ws_dqb = kernels.dqb_workspace((R, R, R), (self.a, self.b), knn=self.knn, n_nodes=N)
+        self.knn_bricks = None
+        if self.b > self.a:
+            kernels.dqb_build_candidates(self.ws_dqb, (R, R, R), P2, self.knn, (self.a, self.b))
+            self.knn_bricks = ((R, R, R), (self.a, self.b), self.ws_dqb)
+        self._first = True                               # K3 stores its per-voxel neighbourhoods again on the next call
+        self.refresh_samples()
+        return n_new
+
+    def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5, stage_ms=None,
+             update_graph=False):
         """Defaults (regulariser weight, LM damping, association gate and Huber threshold in voxels) are the ones under which the loop tracks
         a +-0.5 voxel oscillation of the bench scene for hundreds of frames without drift (tools/soak.py); with a 4-voxel
         gate and weak damping, nodes without data support wander and the TSDF update then corrupts the canonical volume.
@@ -188,6 +242,8 @@ class SlabFrame:
         depth, lw_cam = depth_list[0], lw_list[0]
         self.live.fill_(self.tvox)
         self.live_w.zero_()
+        if self.ws_views is None:
+            self.ws_views = kernels.integrate_workspace(min(len(depth_list), 16), depth.shape[0], depth.shape[1], (R, R, R), (self.a, self.b), self.live.device)
         kernels.integrate_depth_views(self.live, self.live_w, depth_list, self.K, self.Kinv, lw_list, self.scale, self.center,
                                       self.tdist_world, tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_views)
         mark("live_tsdf")
@@ -204,4 +260,8 @@ class SlabFrame:
         n = self.refresh_samples()
         mark("samples")
         self.fs.solver.check_status()          # the sample count's read-back has synchronised: a timed-out PCG raises here
+        if update_graph:
+            if self.update_graph():
+                n = self.fs.solver.S
+            mark("graph")
         return n

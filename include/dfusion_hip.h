@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DFH_ABI_VERSION 1
+#define DFH_ABI_VERSION 2
 
 #define DFH_F32 0
 #define DFH_F64 1
@@ -62,20 +62,28 @@ int dfh_stream_synchronize(void *stream);
  *   T <- (scale*T*w + min(tdist,sd)) / (scale*(1+w));  w <- min(1+w, wmax)   (:209-210)
  * tsdf/tsdf_w: planes [x0,x1) of the volume, dtype vol_dtype.  depth: H x W row-major,
  * negative depths, 0 = no measurement, dtype depth_dtype.  K, Kinv: 3x3 row-major;
- * lw: 3x4 row-major; center: 3.  tsdf_res is the ctor's tsdf_res (:60,:183). */
+ * lw: 3x4 row-major; center: 3.  tsdf_res is the ctor's tsdf_res (:60,:183).
+ * workspace (may be NULL): device scratch of dfh_integrate_workspace_bytes(1, H, W, res, x0, x1) bytes.  With it, float32
+ * volumes are swept in 4 x 4 x 16 voxel bricks after a classification pass (same call, same stream) that marks the bricks
+ * whose eight projected corners prove that the view updates none of their voxels -- outside the image, or behind the
+ * surface by more than tdist according to a max-depth pyramid of the depth map -- and the sweep skips those: same result,
+ * bit for bit, about half the projection work for a typical view.  Without it every voxel is projected. */
+size_t dfh_integrate_workspace_bytes(int n_views, int H, int W, const int res[3], int x0, int x1);
 int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res,
                         int x0, int x1, const void *depth, int depth_dtype, int H, int W,
                         const double K[9], const double Kinv[9], const double lw[12],
                         double scale, const double center[3], double tdist, double wmax,
-                        void *stream);
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same for n_views depth maps in ONE sweep of the volume: what the reference's loops over fuseDepths do
  * (core/fusion_dm.py:152-154 initial fusion, :166-170 compute_live_tsdf), with every voxel's T and w read once, updated
  * view by view in registers -- the float32 operations of consecutive dfh_integrate_depth calls, so the same bits --
  * and written once.  depth: HOST array of n_views device pointers (all H x W, depth_dtype); lw: n_views x 12.
- * n_views <= 16.  workspace: device scratch of dfh_integrate_multi_workspace_bytes(n_views) bytes (the views'
- * folded projection parameters); without it, for float64 volumes and for depth maps beyond 2048 pixels a side the call
- * runs one sweep per view. */
+ * n_views <= 16.  workspace: device scratch; dfh_integrate_workspace_bytes(n_views, H, W, res, x0, x1) bytes enable the brick
+ * sweep with the per-(brick, view) classification described above (a brick runs only the views that may update it, a brick
+ * no view updates is never loaded), dfh_integrate_multi_workspace_bytes(n_views)
+ * bytes (the views' folded projection parameters only) the plain sweep; without a workspace, for float64 volumes and for
+ * depth maps beyond 2048 pixels a side the call runs one sweep per view. */
 size_t dfh_integrate_multi_workspace_bytes(int n_views);
 int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
                               int n_views, const void *const *depth, int depth_dtype, int H, int W,
@@ -179,6 +187,21 @@ int dfh_dqb_build_candidates(const int res[3], int x0, int x1, const double *nod
 int dfh_sample_knn_bricks(const double *sample_pos, int n_samples, const double *node_pos, const double *node_w,
                           int n_nodes, int knn, const int res[3], int x0, int x1, const void *workspace,
                           size_t workspace_bytes, int *nbr_out, double *weights_out, void *stream);
+
+/* ---- deformation-graph maintenance: the device side of Fusion.update_graph / construct_graph ---------------------
+ * (core/fusion.py:101-123, 201-239; the greedy radius subsampling of the unsupported vertices, core/util.py:27-47, is
+ * sequential by definition and stays with the caller).
+ * dfh_nearest_points: idx_out[q] = nearest cloud point of query q (KDTree(cloud).query(q), :209-212 -- a node's anchor
+ *   vertex; ties go to the lower index), d2_out (may be NULL) its squared distance.
+ * dfh_graph_unsupported: flag_out[v] = 1 iff min over the vertex's knn nodes nbr[v][.] of |node - v| / node_w >= 1
+ *   (the "unsupported surface point" test, :215-219).
+ * dfh_dq_blend_points: dq_out[p] = Fusion.dq_blend(points[p]) over the nodes nbr[p][.] (:527-551; the DQ a newly
+ *   inserted node starts from, :222), 8 doubles per point. */
+int dfh_nearest_points(const double *query, int n_query, const double *cloud, int n_cloud, int *idx_out, double *d2_out, void *stream);
+int dfh_graph_unsupported(const double *verts, int n_verts, const int *nbr, int knn, const double *node_pos, const double *node_w,
+                          int n_nodes, unsigned char *flag_out, void *stream);
+int dfh_dq_blend_points(const double *points, int n_points, const int *nbr, int knn, const double *node_dq, const double *node_pos,
+                        const double *node_w, int n_nodes, double *dq_out, void *stream);
 
 /* Projective data association (not in the reference, which matches marching-cubes vertices through a
  * KD-tree, core/fusion.py:255-276): warp each sample with the current field (Fusion.warp), map index ->

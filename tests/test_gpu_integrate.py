@@ -19,6 +19,18 @@ pytestmark = pytest.mark.gpu
 F32_EPS = float(np.finfo(np.float32).eps)
 
 
+@pytest.fixture(autouse=True, params=["bricks", "rows"])
+def k1_path(request, monkeypatch):
+    """Every test of this file runs on both sweeps of float32 volumes: the default 4 x 4 x 16 brick sweep with conservative
+    culling (workspace with the depth pyramid) and the row sweep that projects every voxel (DFH_K1_NO_BRICKS)."""
+    if request.param == "rows":
+        monkeypatch.setenv("DFH_K1_NO_BRICKS", "1")
+    else:
+        monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
+        monkeypatch.setenv("DFH_K1_BRICKS_MIN", "0")          # (single views take the brick sweep on large slabs only)
+    return request.param
+
+
 def f32_tol(n_integrations):
     return 2.0 * n_integrations * F32_EPS
 
@@ -349,3 +361,58 @@ def test_config4_512_size_independent_properties():
     kernels.integrate_depth(T64, W64, d, K, Kinv, lw, scale, center, tdist, 3.0)
     assert torch.equal(W64 > 0, upd)
     assert float((T64.float() - T1).abs().max()) <= 4 * F32_EPS * float(T1.abs().max())
+
+
+def test_brick_culling_never_changes_a_voxel(k1_path, monkeypatch):
+    """The brick sweep skips a brick only when its eight projected corners PROVE that the view updates none of its voxels.
+    Geometries that stress the proof -- camera inside the grid, grid partly and wholly behind the camera, grazing views,
+    a close wall that occludes almost everything, grids whose sides are no multiples of the brick, slabs that cut bricks,
+    a skewed (non-pinhole) K -- must give the row sweep's volumes bit for bit, single- and multi-view."""
+    if k1_path == "rows":
+        pytest.skip("compares the two paths itself")
+    rng = np.random.default_rng(77)
+    cases = []
+    for res, (H, W_), pin in (((37, 21, 68), (60, 80), True), ((16, 16, 64), (48, 64), True), ((9, 30, 132), (90, 70), False),
+                              ((64, 64, 64), (120, 160), True)):
+        fx = 0.9 * W_ + 0.137
+        K = scene.intrinsics(fx, W_ / 2 - 0.2713, H / 2 + 0.1371)
+        if not pin:
+            K[0, 1] = 0.31; K[1, 1] = fx * 1.07
+        cases.append((res, H, W_, K))
+    for res, H, W_, K in cases:
+        Kinv = np.linalg.inv(K)
+        scale = scene.GRID_SIDE / max(res)
+        center = scene.SPHERE_C.copy()
+        tdist = 3.3 * scale
+        views = []
+        for a, dz, wall in ((0.0, 0.0, 3.0), (75.0, 0.0, 3.0), (-20.0, -1.9, 3.0), (10.0, -4.5, 3.0), (200.0, 0.0, 3.0), (35.0, 0.6, 1.6),
+                            (float(rng.uniform(-180, 180)), float(rng.uniform(-2.5, 1.0)), 2.4)):
+            lw = scene.view_extrinsic(a)
+            lw[2, 3] += dz                                        # camera pushed towards / into / through the grid
+            lw[:, 3] += rng.normal(size=3) * 0.02
+            views.append((lw, scene.render_depth(K, lw, H, W_, invalid_frac=0.05, seed=len(views), dtype=np.float32, wall_z=wall)))
+        outs = {}
+        for path in ("bricks", "rows"):
+            if path == "rows":
+                monkeypatch.setenv("DFH_K1_NO_BRICKS", "1")
+            else:
+                monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
+                monkeypatch.setenv("DFH_K1_BRICKS_MIN", "0")
+            T = torch.full(res, tdist / scale, dtype=torch.float32, device="cuda"); Wt = torch.zeros_like(T)
+            Tm, Wm = T.clone(), Wt.clone()
+            Tsl, Wsl = T.clone(), Wt.clone()
+            per_view = []
+            for lw, dm in views:
+                d = torch.from_numpy(dm).cuda()
+                kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist, 7.0)
+                per_view.append(int((Wt > 0).sum()))
+                for a, b in ((0, 5), (5, res[0])):                # slabs that cut through bricks
+                    kernels.integrate_depth(Tsl[a:b], Wsl[a:b], d, K, Kinv, lw, scale, center, tdist, 7.0, tsdf_res=res[0], res=res, x_range=(a, b))
+            kernels.integrate_depth_views(Tm, Wm, [torch.from_numpy(dm).cuda() for _, dm in views], K, Kinv, [lw for lw, _ in views],
+                                          scale, center, tdist, 7.0)
+            assert torch.equal(Tm, T) and torch.equal(Wm, Wt) and torch.equal(Tsl, T) and torch.equal(Wsl, Wt)
+            outs[path] = (T, Wt, per_view)
+        assert torch.equal(outs["bricks"][0], outs["rows"][0]) and torch.equal(outs["bricks"][1], outs["rows"][1])
+        assert outs["bricks"][2] == outs["rows"][2]
+        assert 0 < int((outs["rows"][1] > 0).sum()) < outs["rows"][1].numel()
+    monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)

@@ -29,10 +29,10 @@ def test_update_graph_matches_reference(golden):
     k = int(g["knn"])
     fu = Fusion(np.zeros((4, 4, 4)), 1.0, knn=k, write_warpfield=False)
     fu._vertices, fu._radius = g["verts"], float(g["radius"])
-    fu.construct_graph()
+    fu.construct_graph(host=True)
     fu._nodes = [(n[0], n[1], g["ug_dq_in"][i], n[3]) for i, n in enumerate(fu._nodes)]
     fu._vertices = g["verts2"]
-    n_new = fu.update_graph(refresh_surface=False)
+    n_new = fu.update_graph(refresh_surface=False, host=True)
     assert n_new == len(g["ug_idx"]) - len(g["cg_idx"]) and n_new > 0
     assert np.array_equal(np.array([n[0] for n in fu._nodes]), g["ug_idx"])
     assert np.array_equal(np.array([n[1] for n in fu._nodes]), g["ug_pos"])

@@ -9,15 +9,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--views", type=int, default=3)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--orbit", action="store_true", help="BASELINE config 5's views: 45 degrees apart around the grid (default: a fan of +-50 degrees)")
 a = ap.parse_args()
 R, V = a.res, a.views
 H, W, fx, cx, cy = scene.CAMERAS["C2" if R <= 256 else "C5"]
 K = scene.intrinsics(fx, cx, cy); Kinv = np.linalg.inv(K)
 scale, center, tdist = scene.grid_params(R)
-lws = [scene.view_extrinsic(ang) for ang in np.linspace(-50, 50, V)]
+lws = [scene.view_extrinsic(ang) for ang in (45.0 * np.arange(V) if a.orbit else np.linspace(-50, 50, V))]
 dms = [torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32)).cuda() for lw in lws]
 T = torch.full((R, R, R), tdist / scale, dtype=torch.float32, device="cuda"); Wt = torch.zeros_like(T)
-ws = torch.empty(4096, dtype=torch.int64, device="cuda")
+ws = kernels.integrate_workspace(min(V, 16), H, W, (R, R, R))
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 def timeit(fn):
     fn(); torch.cuda.synchronize()

@@ -58,6 +58,12 @@ _SIGNATURES = {
     "dfh_gn_build_planned": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _c_double_p, _dbl,
                                     _vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _dbl, _vp]),
+    "dfh_gn_sort_workspace_bytes": (ctypes.c_size_t, [_int]),
+    "dfh_gn_sort_samples": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dfh_gn_plan_count": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
+    "dfh_gn_plan_workspace_bytes": (ctypes.c_size_t, [_int, _int]),
+    "dfh_gn_plan_build": (_int, [_vp, _int, _int, _int, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 ctypes.c_size_t, _vp]),
     "dfh_pcg_workspace_bytes": (ctypes.c_size_t, [_int, _int]),
     "dfh_pcg_solve": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp]),
     "dfh_pcg_solve_update": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp, _dbl, _vp]),

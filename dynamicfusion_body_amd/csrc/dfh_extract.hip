@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void surface_emit_kernel(const VolT *__restric
     }
     __syncthreads();
     long at = (long)block_offset[blockIdx.x];
+    const long total = (long)block_offset[gridDim.x];      // sentinel written by the scan: number of samples of the volume
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         long mine = at + before[j];
@@ -157,9 +158,18 @@ __global__ __launch_bounds__(256) void surface_emit_kernel(const VolT *__restric
             if (w_ < wv) mine += wave_cnt[j][w_];
             at += wave_cnt[j][w_];               // after the loop: start of chunk j+1
         }
-        if (ok[j] && mine < capacity) {
+        // capacity < total: an EVEN subsample in voxel order -- sample i goes to slot floor(i * capacity / total) and is kept
+        // iff it is the first one of its slot (every slot gets exactly one), instead of the first `capacity` samples,
+        // which would all lie in the lowest x planes
+        long dst = mine;
+        bool keep = ok[j];
+        if (capacity < total) {
+            dst = (long)(((__int128)mine * capacity) / total);
+            keep = keep && (mine == 0 || (long)(((__int128)(mine - 1) * capacity) / total) != dst);
+        }
+        if (keep) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { pos_out[3 * mine + a] = pos[j][a]; nrm_out[3 * mine + a] = nrm[j][a]; }
+            for (int a = 0; a < 3; ++a) { pos_out[3 * dst + a] = pos[j][a]; nrm_out[3 * dst + a] = nrm[j][a]; }
         }
     }
 }

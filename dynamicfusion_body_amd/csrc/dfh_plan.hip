@@ -1,0 +1,274 @@
+// Per-frame bookkeeping of the warp-field solve on the device: samples sorted by node tuple, and the static plan of
+// dfh_gn_build_planned (rows = runs of equal tuples inside 256-sample tiles; per 6x6 block and per node the list of
+// (row, slot) entries that contribute to it).  The host used to assemble all this from ~35 torch launches per frame
+// (pack, sort, cumsum, searchsorted, ...): host-bound at ~0.6 ms.  Here it is a handful of launches behind three C
+// entry points; the two key sorts are rocPRIM's device radix sort (stable, so every list comes out in ascending entry
+// order -- the fixed summation order the bit-reproducible build relies on), everything else is hand-written.
+#include "dfh_common.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace dfh {
+
+constexpr int kPlanTile = 256;          // == kTile of dfh_solve.hip: a row never spans two tiles
+constexpr int kKMaxP = 8;
+
+__device__ __forceinline__ int plan_find_block(const int *__restrict__ row_ptr, const int *__restrict__ col, int a, int b) {
+    int lo = row_ptr[a], hi = row_ptr[a + 1] - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = col[mid];
+        if (c == b) return mid;
+        if (c < b) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+// ---- samples sorted by node tuple ------------------------------------------------------------------------------
+// key = the tuple read as a k-digit number in base N (lexicographic order of the tuples), value = sample index
+__global__ __launch_bounds__(256) void plan_pack_keys_kernel(const int *__restrict__ nbr, int S, int k, unsigned long long N,
+                                                              unsigned long long *__restrict__ key, int *__restrict__ idx) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    unsigned long long kk = 0;
+    for (int j = 0; j < k; ++j) kk = kk * N + (unsigned long long)nbr[(size_t)s * k + j];
+    key[s] = kk;
+    idx[s] = s;
+}
+
+__global__ __launch_bounds__(256) void plan_permute_kernel(const int *__restrict__ order, int S, int k, const double *__restrict__ pos,
+                                                           const double *__restrict__ nrm, const int *__restrict__ nbr,
+                                                           const double *__restrict__ wts, double *__restrict__ pos_o,
+                                                           double *__restrict__ nrm_o, int *__restrict__ nbr_o, double *__restrict__ wts_o) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    const size_t src = (size_t)order[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pos_o[3 * (size_t)i + c] = pos[3 * src + c];
+        nrm_o[3 * (size_t)i + c] = nrm[3 * src + c];
+    }
+    for (int j = 0; j < k; ++j) {
+        nbr_o[(size_t)i * k + j] = nbr[src * k + j];
+        wts_o[(size_t)i * k + j] = wts[src * k + j];
+    }
+}
+
+// ---- rows ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool plan_is_head(const int *__restrict__ nbr, int s, int k) {
+    if ((s & (kPlanTile - 1)) == 0) return true;          // a row never spans two tiles
+    bool h = false;
+    for (int j = 0; j < k; ++j) h = h || nbr[(size_t)s * k + j] != nbr[(size_t)(s - 1) * k + j];
+    return h;
+}
+
+// rows per tile
+__global__ __launch_bounds__(256) void plan_heads_kernel(const int *__restrict__ nbr, int S, int k, int *__restrict__ tile_rows) {
+    __shared__ int cnt[4];
+    const int s = blockIdx.x * kPlanTile + threadIdx.x;
+    const bool head = s < S && plan_is_head(nbr, s, k);
+    const unsigned long long b = __ballot(head);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_rows[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+}
+
+// exclusive scan of the tile counts in place (one workgroup; tile_rows[n_tiles] = total = *n_rows_out)
+__global__ __launch_bounds__(1024) void plan_scan_kernel(int *__restrict__ tile_rows, int n_tiles, int *__restrict__ n_rows_out) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_tiles ? tile_rows[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        int off = carry_s;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        if (i < n_tiles) tile_rows[i] = off + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { tile_rows[n_tiles] = carry_s; *n_rows_out = carry_s; }
+}
+
+// run_id of every sample and the first sample of every row
+__global__ __launch_bounds__(256) void plan_runid_kernel(const int *__restrict__ nbr, int S, int k, const int *__restrict__ tile_off,
+                                                          int *__restrict__ run_id, int *__restrict__ row_first) {
+    __shared__ int cnt[4];
+    const int s = blockIdx.x * kPlanTile + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool head = s < S && plan_is_head(nbr, s, k);
+    const unsigned long long b = __ballot(head);
+    if (lane == 0) cnt[wv] = __popcll(b);
+    __syncthreads();
+    int r = tile_off[blockIdx.x] + __popcll(b & ((2ull << lane) - 1ull)) - 1;        // heads up to and including this lane
+    for (int w = 0; w < wv; ++w) r += cnt[w];
+    if (s < S) {
+        run_id[s] = r;
+        if (head) row_first[r] = s;
+    }
+}
+
+// ---- list keys -----------------------------------------------------------------------------------------------------
+// entry e = row * k^2 + sa * k + sb -> key = index of block (node[sa], node[sb]) in the pattern (B if it is not there);
+// entries with sa == 0 also emit the node entry row * k + sb -> key = node[sb]
+__global__ __launch_bounds__(256) void plan_keys_kernel(const int *__restrict__ nbr, const int *__restrict__ row_first, int n_rows, int k,
+                                                         const int *__restrict__ row_ptr, const int *__restrict__ col, int B,
+                                                         int *__restrict__ blk_key, int *__restrict__ blk_val, int *__restrict__ node_key,
+                                                         int *__restrict__ node_val, int *__restrict__ uncovered) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const int kk = k * k;
+    if (e >= (long)n_rows * kk) return;
+    const int row = (int)(e / kk), pr = (int)(e - (long)row * kk);
+    const int sa = pr / k, sb = pr - sa * k;
+    const size_t s0 = (size_t)row_first[row] * k;
+    const int na = nbr[s0 + sa], nb = nbr[s0 + sb];
+    int blk = plan_find_block(row_ptr, col, na, nb);
+    if (blk < 0) { blk = B; atomicOr(uncovered, 1); }
+    blk_key[e] = blk;
+    blk_val[e] = (int)e;
+    if (sa == 0) {
+        node_key[(size_t)row * k + sb] = nb;
+        node_val[(size_t)row * k + sb] = row * k + sb;
+    }
+}
+
+// ptr[v] = first position of a key >= v in the sorted keys, v = 0..n_keys (CSR offsets of the lists)
+__global__ __launch_bounds__(256) void plan_ptr_kernel(const int *__restrict__ sorted, int n, int n_keys, int *__restrict__ ptr) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v > n_keys) return;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sorted[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    ptr[v] = lo;
+}
+
+static unsigned bits_for(unsigned long long max_value) {
+    unsigned b = 1;
+    while (b < 64 && (max_value >> b) != 0) ++b;
+    return b;
+}
+
+static size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+
+static size_t sort_temp_bytes_u64(int n) {
+    size_t t = 0;
+    if (rocprim::radix_sort_pairs(nullptr, t, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int *)nullptr, (int *)nullptr,
+                                  (size_t)n) != hipSuccess) t = 0;
+    return t;
+}
+static size_t sort_temp_bytes_i32(long n) {
+    size_t t = 0;
+    if (rocprim::radix_sort_pairs(nullptr, t, (int *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr, (size_t)n) != hipSuccess) t = 0;
+    return t;
+}
+
+}  // namespace dfh
+
+extern "C" {
+
+size_t dfh_gn_sort_workspace_bytes(int n_samples) {
+    using namespace dfh;
+    if (n_samples <= 0) return 0;
+    return align16(sizeof(unsigned long long) * (size_t)n_samples) + align16(sizeof(int) * (size_t)n_samples) +
+           align16(sort_temp_bytes_u64(n_samples));
+}
+
+int dfh_gn_sort_samples(const double *pos, const double *nrm, const int *nbr, const double *weights, int n_samples, int knn,
+                        int n_nodes, double *pos_out, double *nrm_out, int *nbr_out, double *weights_out, long *key_out,
+                        int *order_out, void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_samples >= 0 && knn >= 1 && knn <= kKMaxP && n_nodes >= 1, "dfh_gn_sort_samples: bad sizes");
+    if (n_samples == 0) return DFH_OK;
+    DFH_REQUIRE(pos && nrm && nbr && weights && pos_out && nrm_out && nbr_out && weights_out && key_out && order_out && workspace,
+                "dfh_gn_sort_samples: null pointer");
+    DFH_REQUIRE(workspace_bytes >= dfh_gn_sort_workspace_bytes(n_samples), "dfh_gn_sort_samples: workspace too small");
+    double span = 1.0;
+    for (int j = 0; j < knn; ++j) span *= (double)n_nodes;
+    DFH_REQUIRE(span < 9.0e18, "dfh_gn_sort_samples: %d digits in base %d do not fit 64 bits", knn, n_nodes);
+    hipStream_t s = (hipStream_t)stream;
+    char *w = static_cast<char *>(workspace);
+    unsigned long long *key_in = reinterpret_cast<unsigned long long *>(w); w += align16(sizeof(unsigned long long) * (size_t)n_samples);
+    int *idx_in = reinterpret_cast<int *>(w); w += align16(sizeof(int) * (size_t)n_samples);
+    int *order = order_out;
+    size_t temp = sort_temp_bytes_u64(n_samples);
+    const dim3 grid((unsigned)((n_samples + 255) / 256)), block(256);
+    hipLaunchKernelGGL(plan_pack_keys_kernel, grid, block, 0, s, nbr, n_samples, knn, (unsigned long long)n_nodes, key_in, idx_in);
+    const unsigned end_bit = bits_for((unsigned long long)(span - 1.0) + 1ull);
+    DFH_HIP_CHECK(rocprim::radix_sort_pairs(w, temp, key_in, reinterpret_cast<unsigned long long *>(key_out), idx_in, order,
+                                            (size_t)n_samples, 0u, end_bit > 64u ? 64u : end_bit, s));
+    hipLaunchKernelGGL(plan_permute_kernel, grid, block, 0, s, order, n_samples, knn, pos, nrm, nbr, weights, pos_out, nrm_out, nbr_out,
+                       weights_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_gn_plan_count(const int *nbr, int n_samples, int knn, int *tile_off, int *n_rows_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_samples >= 1 && knn >= 1 && knn <= kKMaxP, "dfh_gn_plan_count: bad sizes");
+    DFH_REQUIRE(nbr && tile_off && n_rows_out, "dfh_gn_plan_count: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int n_tiles = (n_samples + kPlanTile - 1) / kPlanTile;
+    hipLaunchKernelGGL(plan_heads_kernel, dim3(n_tiles), dim3(256), 0, s, nbr, n_samples, knn, tile_off);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, tile_off, n_tiles, n_rows_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+size_t dfh_gn_plan_workspace_bytes(int n_rows, int knn) {
+    using namespace dfh;
+    if (n_rows <= 0 || knn < 1 || knn > kKMaxP) return 0;
+    const size_t E = (size_t)n_rows * knn * knn, E2 = (size_t)n_rows * knn;
+    return 3 * align16(sizeof(int) * E) + 3 * align16(sizeof(int) * E2) + align16(sort_temp_bytes_i32((long)E)) + 16;
+}
+
+int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const int *tile_off, int n_rows, const int *row_ptr,
+                      const int *col, int n_blocks, int *run_id, int *row_first, int *blk_ptr, int *blk_ent, int *node_ptr,
+                      int *node_ent, int *uncovered_out, void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_samples >= 1 && knn >= 1 && knn <= kKMaxP && n_nodes >= 1 && n_blocks >= 1 && n_rows >= 1, "dfh_gn_plan_build: bad sizes");
+    DFH_REQUIRE(nbr && tile_off && row_ptr && col && run_id && row_first && blk_ptr && blk_ent && node_ptr && node_ent && uncovered_out &&
+                workspace, "dfh_gn_plan_build: null pointer");
+    DFH_REQUIRE(workspace_bytes >= dfh_gn_plan_workspace_bytes(n_rows, knn), "dfh_gn_plan_build: workspace too small");
+    DFH_REQUIRE((long)n_rows * knn * knn < (1L << 31), "dfh_gn_plan_build: too many rows for 32-bit entries");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t E = (size_t)n_rows * knn * knn, E2 = (size_t)n_rows * knn;
+    char *w = static_cast<char *>(workspace);
+    int *bk_in = reinterpret_cast<int *>(w); w += align16(sizeof(int) * E);
+    int *bv_in = reinterpret_cast<int *>(w); w += align16(sizeof(int) * E);
+    int *bk_out = reinterpret_cast<int *>(w); w += align16(sizeof(int) * E);
+    int *nk_in = reinterpret_cast<int *>(w); w += align16(sizeof(int) * E2);
+    int *nv_in = reinterpret_cast<int *>(w); w += align16(sizeof(int) * E2);
+    int *nk_out = reinterpret_cast<int *>(w); w += align16(sizeof(int) * E2);
+    size_t temp = sort_temp_bytes_i32((long)E);
+    const int n_tiles = (n_samples + kPlanTile - 1) / kPlanTile;
+    DFH_HIP_CHECK(hipMemsetAsync(uncovered_out, 0, sizeof(int), s));
+    hipLaunchKernelGGL(plan_runid_kernel, dim3(n_tiles), dim3(256), 0, s, nbr, n_samples, knn, tile_off, run_id, row_first);
+    hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, row_first, n_rows, knn, row_ptr, col,
+                       n_blocks, bk_in, bv_in, nk_in, nv_in, uncovered_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    DFH_HIP_CHECK(rocprim::radix_sort_pairs(w, temp, bk_in, bk_out, bv_in, blk_ent, E, 0u, bits_for((unsigned long long)n_blocks + 1ull), s));
+    size_t temp2 = sort_temp_bytes_i32((long)E2);
+    DFH_REQUIRE(temp2 <= temp, "dfh_gn_plan_build: scratch of the node sort exceeds the block sort's");
+    DFH_HIP_CHECK(rocprim::radix_sort_pairs(w, temp2, nk_in, nk_out, nv_in, node_ent, E2, 0u, bits_for((unsigned long long)n_nodes), s));
+    hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((n_blocks + 1 + 255) / 256)), dim3(256), 0, s, bk_out, (int)E, n_blocks, blk_ptr);
+    hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((n_nodes + 1 + 255) / 256)), dim3(256), 0, s, nk_out, (int)E2, n_nodes, node_ptr);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+}  // extern "C"

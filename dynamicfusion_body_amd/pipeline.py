@@ -18,7 +18,8 @@ def extract_surface_samples(T, Wt, band, x0=0, max_samples=None):
     """Band voxels (w > 0, |T| < band; T in voxel units as fuseDepths stores it) of a slab starting
     at global plane x0 -> (surface points (S,3) in global index space, unit normals), fp64 CUDA
     tensors in voxel order.  Three HIP launches (count, scan, emit) and one 8-byte read-back of the
-    sample count."""
+    sample count.  max_samples < the number of band voxels keeps an even subsample in voxel order (sample i iff it is the
+    first one with slot floor(i * max_samples / n)), i.e. the whole surface at a lower density, never a prefix."""
     require_gpu()
     lib = _lib.load()
     if not (isinstance(T, torch.Tensor) and T.is_cuda and T.dim() == 3 and T.is_contiguous() and Wt.shape == T.shape
@@ -48,7 +49,8 @@ def extract_surface_samples_torch(T, Wt, band, x0=0, max_samples=None):
     mask = (Wt > 0) & (Tf.abs() < band)
     idx = mask.nonzero(as_tuple=False)
     if max_samples is not None and idx.shape[0] > max_samples:
-        idx = idx[torch.linspace(0, idx.shape[0] - 1, max_samples, device=idx.device).long()]
+        n, cap = idx.shape[0], int(max_samples)                  # the device rule: first sample of every slot floor(i * cap / n)
+        idx = idx[(torch.arange(cap, device=idx.device, dtype=torch.int64) * n + cap - 1) // cap]
     X, Y, Z = T.shape
     ix, iy, iz = idx[:, 0], idx[:, 1], idx[:, 2]
 

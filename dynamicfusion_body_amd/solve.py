@@ -168,6 +168,18 @@ def solve_rigid_gn(x0, verts, normals, corr, valid=None, iters=10, lm=0.0):
     return x, costs
 
 
+class _LazyLong:
+    """int32 device permutation, widened to int64 (what tensor indexing wants) only if somebody indexes with it."""
+
+    def __init__(self, idx32):
+        self._i32, self._i64 = idx32, None
+
+    def long(self):
+        if self._i64 is None:
+            self._i64 = self._i32.long()
+        return self._i64
+
+
 # ------------------------------------------------------------------------------ non-rigid solver
 class WarpSolver:
     """Gauss-Newton / LM solver for the node dual quaternions.
@@ -235,20 +247,40 @@ class WarpSolver:
         if sort and pos.shape[0] > 0:
             # group samples with the same ordered node tuple: few runs per 256-sample tile.  The tuple is packed
             # into one int64 (base-N digits, lexicographic order preserved) so that a 1-D radix sort does it.
-            key = self._pack_tuples(nbr)
-            if key is not None:
-                key, self.order = torch.sort(key, stable=True)
-                self._tuple_key = key
+            if float(self.N) ** self.knn < 2.0 ** 62 and not os.environ.get("DFH_PLAN_TORCH"):
+                pos, nrm, nbr, weights = self._sort_samples_device(pos, nrm, nbr, weights)      # pack + sort + permute behind one call
             else:
-                _, inv = torch.unique(nbr, dim=0, return_inverse=True)
-                self.order = torch.argsort(inv, stable=True)
-            pos, nrm, nbr, weights = self._permute(pos, nrm, nbr, weights)
+                key = self._pack_tuples(nbr)
+                if key is not None:
+                    key, self.order = torch.sort(key, stable=True)
+                    self._tuple_key = key
+                else:
+                    _, inv = torch.unique(nbr, dim=0, return_inverse=True)
+                    self.order = torch.argsort(inv, stable=True)
+                pos, nrm, nbr, weights = self._permute(pos, nrm, nbr, weights)
         self.spos, self.snrm = pos.contiguous(), nrm.contiguous()
         self.snbr, self.swts = nbr.contiguous(), weights.contiguous()
         self.S = pos.shape[0]
         self.corr = torch.zeros((self.S, 3), dtype=torch.float64, device="cuda")
         self.valid = torch.zeros(self.S, dtype=torch.uint8, device="cuda")
         self._pattern = None
+
+    def _sort_samples_device(self, pos, nrm, nbr, weights):
+        """dfh_gn_sort_samples: the samples in the (stable) order of their node tuples; sets order and _tuple_key."""
+        S = pos.shape[0]
+        pos, nrm, nbr, weights = pos.contiguous(), nrm.contiguous(), nbr.contiguous(), weights.contiguous()
+        out = (torch.empty_like(pos), torch.empty_like(nrm), torch.empty_like(nbr), torch.empty_like(weights))
+        key = torch.empty(S, dtype=torch.int64, device="cuda")
+        order = torch.empty(S, dtype=torch.int32, device="cuda")
+        nbytes = self.lib.dfh_gn_sort_workspace_bytes(S)
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device="cuda")
+        _lib.check(self.lib.dfh_gn_sort_samples(pos.data_ptr(), nrm.data_ptr(), nbr.data_ptr(), weights.data_ptr(), S, self.knn, self.N,
+                                                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), key.data_ptr(),
+                                                order.data_ptr(), ws.data_ptr(), ws.numel() * 8, current_stream_ptr()), "dfh_gn_sort_samples")
+        self._tuple_key = key
+        self._order32 = order
+        self.order = _LazyLong(order)
+        return out
 
     def _permute(self, pos, nrm, nbr, weights):
         """The four per-sample arrays in `self.order`, one fused pass (dfh_permute_samples)."""
@@ -296,7 +328,7 @@ class WarpSolver:
                 self._pattern = True
                 return
             if self.S > 0:
-                new.append(self._pair_keys)
+                new.append(self._pair_keys_of_rows())
             new.append(old)
         elif self.S > 0:
             # distinct node tuples only (the pattern is a function of the tuples, not of the samples)
@@ -343,50 +375,103 @@ class WarpSolver:
     def _build_plan(self, keys, reg=True):
         """Static part of the data term (dfh_gn_build_planned): rows = runs of equal node tuples inside a
         256-sample tile, and for every block / node the rows (and tuple slots) that contribute to it.
-        reg=False keeps the regularisation lists (they depend on the pattern and the graph only)."""
+        reg=False keeps the regularisation lists (they depend on the pattern and the graph only).
+        The data plan is built on the device (dfh_gn_plan_count / dfh_gn_plan_build: run scan, block look-up, two radix
+        sorts); `keys` must be the pattern row_ptr / col describe.  Returns whether every node pair of every row is a
+        block of the pattern (always True when reg=True: that call follows a pattern build)."""
+        if self.S == 0 or self._tuple_key is None or os.environ.get("DFH_PLAN_TORCH"):
+            return self._build_plan_torch(keys, reg)
         N, k, S, dev = self.N, self.knn, self.S, "cuda"
+        n_tiles = (S + 255) // 256
+        tile_off = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+        n_rows_d = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(self.lib.dfh_gn_plan_count(self.snbr.data_ptr(), S, k, tile_off.data_ptr(), n_rows_d.data_ptr(), current_stream_ptr()),
+                   "dfh_gn_plan_count")
+        R = int(n_rows_d.item())                                       # (the one read-back: sizes of the plan arrays)
+        self.n_rows = R
+        if R * k * k >= 2 ** 31:
+            raise ValueError("too many sample runs for 32-bit plan entries")
+        self.run_id = torch.empty(S, dtype=torch.int32, device=dev)
+        self._row_first = torch.empty(R, dtype=torch.int32, device=dev)
+        self.blk_ptr = torch.empty(self.B + 1, dtype=torch.int32, device=dev)
+        self.blk_ent = torch.empty(R * k * k, dtype=torch.int32, device=dev)
+        self.node_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.node_ent = torch.empty(R * k, dtype=torch.int32, device=dev)
+        unc = torch.empty(1, dtype=torch.int32, device=dev)
+        nbytes = self.lib.dfh_gn_plan_workspace_bytes(R, k)
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        _lib.check(self.lib.dfh_gn_plan_build(self.snbr.data_ptr(), S, k, N, tile_off.data_ptr(), R, self.row_ptr.data_ptr(),
+                                              self.col.data_ptr(), self.B, self.run_id.data_ptr(), self._row_first.data_ptr(),
+                                              self.blk_ptr.data_ptr(), self.blk_ent.data_ptr(), self.node_ptr.data_ptr(),
+                                              self.node_ent.data_ptr(), unc.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                              current_stream_ptr()), "dfh_gn_plan_build")
+        ne = int(self.lib.dfh_gn_partial_doubles(k))
+        self.partial = torch.empty(max(1, R * ne) + 2 * n_tiles, dtype=torch.float64, device=dev)   # rows | {cost, count} per tile
+        self._pair_keys = None                                         # (computed on demand: only a growing pattern needs them)
+        if reg:
+            self._build_reg_plan(keys)
+            return True
+        return int(unc.item()) == 0
+
+    def _pair_keys_of_rows(self):
+        """Node-pair keys a * N + b of every row's tuple (what the block pattern has to contain)."""
+        if getattr(self, "_pair_keys", None) is None:
+            tup = self.snbr[self._row_first.long()].long()
+            self._pair_keys = (tup[:, :, None] * self.N + tup[:, None, :]).reshape(-1)
+        return self._pair_keys
+
+    def _csr_lists(self, tup, keys):
+        """CSR lists for the gather: per block the entries row*K^2 + sa*K + sb, per node the entries row*K + slot (torch)."""
+        N, dev = self.N, "cuda"
         i32 = lambda t: t.to(torch.int32).contiguous()
+        key = (tup[:, :, None] * N + tup[:, None, :]).reshape(-1)
+        blk = torch.searchsorted(keys, key)
+        covered = (keys[blk.clamp(max=keys.numel() - 1)] == key).all()                 # every pair is a block of the pattern?
+        sblk, order = torch.sort(blk.to(torch.int32), stable=True)                     # 32-bit keys: half the sort traffic
+        bp = torch.searchsorted(sblk, torch.arange(self.B + 1, device=dev, dtype=torch.int32), out_int32=True)
+        snode, order2 = torch.sort(tup.reshape(-1).to(torch.int32), stable=True)
+        npt = torch.searchsorted(snode, torch.arange(N + 1, device=dev, dtype=torch.int32), out_int32=True)
+        return (bp, i32(order), npt, i32(order2)), key, covered
+
+    def _build_reg_plan(self, keys):
+        """Lists of the regulariser's pair rows (pattern + graph only: rebuilt with the pattern, not per frame)."""
+        N, k, dev = self.N, self.knn, "cuda"
+        self.partial_reg = None
+        if self.node_nbr is not None:
+            ii = torch.arange(N, device=dev, dtype=torch.int64)[:, None].expand(N, k).reshape(-1)
+            pair = torch.stack([ii, self.node_nbr.long().reshape(-1)], dim=1)          # row t = i*k + slot
+            (self.rblk_ptr, self.rblk_ent, self.rnode_ptr, self.rnode_ent), _, _ = self._csr_lists(pair, keys)
+            self.partial_reg = torch.zeros(N * k * int(self.lib.dfh_gn_partial_doubles(2)), dtype=torch.float64, device=dev)
+
+    def _build_plan_torch(self, keys, reg=True):
+        """The same plan from torch ops (samples without packed tuple keys, S = 0, DFH_PLAN_TORCH=1 for A/B)."""
+        N, k, S, dev = self.N, self.knn, self.S, "cuda"
         if S == 0:
             self.run_id = torch.zeros(1, dtype=torch.int32, device=dev)
             self.n_rows = 0
             tup = torch.zeros((0, k), dtype=torch.int64, device=dev)
+            self._row_first = torch.zeros(0, dtype=torch.int32, device=dev)
         else:
             head = torch.empty(S, dtype=torch.bool, device=dev)
             head[1:] = (self._tuple_key[1:] != self._tuple_key[:-1]) if self._tuple_key is not None else \
                 (self.snbr[1:] != self.snbr[:-1]).any(dim=1)
             head[::256] = True                                        # a row never spans two 256-sample tiles
             self.run_id = torch.cumsum(head, 0, dtype=torch.int32).sub_(1)
+            self._row_first = torch.nonzero(head).reshape(-1).to(torch.int32)
             tup = self.snbr[head].long()
             self.n_rows = int(tup.shape[0])
         R = self.n_rows
-
-        found = []
-
-        def lists(tup):
-            """CSR lists for the gather: per block the entries row*K^2 + sa*K + sb, per node the entries row*K + slot."""
-            key = (tup[:, :, None] * N + tup[:, None, :]).reshape(-1)
-            blk = torch.searchsorted(keys, key)
-            found.append((key, (keys[blk.clamp(max=keys.numel() - 1)] == key).all()))     # every pair is a block of the pattern?
-            sblk, order = torch.sort(blk.to(torch.int32), stable=True)                     # 32-bit keys: half the sort traffic
-            bp = torch.searchsorted(sblk, torch.arange(self.B + 1, device=dev, dtype=torch.int32), out_int32=True)
-            snode, order2 = torch.sort(tup.reshape(-1).to(torch.int32), stable=True)
-            npt = torch.searchsorted(snode, torch.arange(N + 1, device=dev, dtype=torch.int32), out_int32=True)
-            return bp, i32(order), npt, i32(order2)
-
-        self.blk_ptr, self.blk_ent, self.node_ptr, self.node_ent = lists(tup)
-        self._pair_keys, covered = found[0]
+        (self.blk_ptr, self.blk_ent, self.node_ptr, self.node_ent), self._pair_keys, covered = self._csr_lists(tup, keys)
         if reg:
-            self.partial_reg = None
-        if reg and self.node_nbr is not None:
-            ii = torch.arange(N, device=dev, dtype=torch.int64)[:, None].expand(N, k).reshape(-1)
-            pair = torch.stack([ii, self.node_nbr.long().reshape(-1)], dim=1)          # row t = i*k + slot
-            self.rblk_ptr, self.rblk_ent, self.rnode_ptr, self.rnode_ent = lists(pair)
-            self.partial_reg = torch.zeros(N * k * int(self.lib.dfh_gn_partial_doubles(2)), dtype=torch.float64, device=dev)
+            self._build_reg_plan(keys)
         ne = int(self.lib.dfh_gn_partial_doubles(k))
         self.partial = torch.empty(max(1, R * ne) + 2 * ((S + 255) // 256), dtype=torch.float64, device=dev)   # rows | {cost, count} per tile
         if R * k * k >= 2 ** 31:
             raise ValueError("too many sample runs for 32-bit plan entries")
         return bool(covered) if not reg else True          # (reg=True is the call that follows a pattern build: covered by construction)
+
+    def _order_index(self):
+        return self.order.long() if isinstance(self.order, _LazyLong) else self.order
 
     # -- correspondences ---------------------------------------------------------------------
     def set_correspondences(self, corr, valid=None):
@@ -394,13 +479,13 @@ class WarpSolver:
         if c.shape[0] != self.S:
             raise ValueError("Please first call setupCorrespondences to compute point to point correspondences "
                              "between canonical and live frame vertices!")         # core/fusion.py:337-338
-        self.corr = c[self.order].contiguous() if self.order is not None else c
+        self.corr = c[self._order_index()].contiguous() if self.order is not None else c
         if valid is None:
             self.valid = torch.ones(self.S, dtype=torch.uint8, device="cuda")
         else:
             v = valid if isinstance(valid, torch.Tensor) else torch.from_numpy(np.asarray(valid))
             v = v.to(device="cuda", dtype=torch.uint8)
-            self.valid = v[self.order].contiguous() if self.order is not None else v.contiguous()
+            self.valid = v[self._order_index()].contiguous() if self.order is not None else v.contiguous()
 
     def associate_depth(self, depth, K, Kinv, lw_cam, scale, center, half, lw_dq, max_dist=0.0):
         """Projective association of the warped samples against a live depth map (CUDA tensor)."""

@@ -259,6 +259,26 @@ int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, con
                          const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
                          void *stream);
 
+/* ---- per-frame bookkeeping of the planned build, on the device ---------------------------------------------------------
+ * dfh_gn_sort_samples: the four per-sample arrays in the order of their node tuples (lexicographic, stable: equal tuples
+ *   keep their input order), key_out[i] = the i-th sorted tuple as a knn-digit number in base n_nodes, order_out[i] =
+ *   input index of the i-th sorted sample.
+ * dfh_gn_plan_count:   rows = maximal runs of equal tuples inside 256-sample tiles of the SORTED nbr; tile_off
+ *   (ceil(n_samples/256) + 1 ints) <- first row of every tile, *n_rows_out (device) <- number of rows.
+ * dfh_gn_plan_build:   run_id (n_samples), row_first (n_rows: first sample of every row) and the CSR lists of
+ *   dfh_gn_build_planned -- blk_ptr (n_blocks + 1) / blk_ent (n_rows * knn^2), node_ptr (n_nodes + 1) / node_ent (n_rows * knn),
+ *   every list in ascending entry order; *uncovered_out (device int) <- 1 if some node pair of some row is not a block
+ *   of the pattern (row_ptr / col), its entries are left out.  n_rows is the value dfh_gn_plan_count produced. */
+size_t dfh_gn_sort_workspace_bytes(int n_samples);
+int dfh_gn_sort_samples(const double *pos, const double *nrm, const int *nbr, const double *weights, int n_samples, int knn,
+                        int n_nodes, double *pos_out, double *nrm_out, int *nbr_out, double *weights_out, long *key_out,
+                        int *order_out, void *workspace, size_t workspace_bytes, void *stream);
+int dfh_gn_plan_count(const int *nbr, int n_samples, int knn, int *tile_off, int *n_rows_out, void *stream);
+size_t dfh_gn_plan_workspace_bytes(int n_rows, int knn);
+int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const int *tile_off, int n_rows, const int *row_ptr,
+                      const int *col, int n_blocks, int *run_id, int *row_first, int *blk_ptr, int *blk_ent, int *node_ptr,
+                      int *node_ent, int *uncovered_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Block-Jacobi preconditioned CG on (A + lm_abs I + lm_rel diag(A)) x = -rhs, `iters` iterations, no
  * host synchronisation.  The damping is written into vals' diagonal (vals is consumed). */
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters);
@@ -291,7 +311,9 @@ int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step,
  * = voxel centre - T * gradient / (|gradient| * max(|gradient|, 1)) (one Newton step, never longer than |T|; global index space, plane 0 of the buffer is global plane x0), normal n =
  * gradient / |gradient|.  Samples come out in voxel order, deterministically.
  *   dfh_surface_count : per-block counts + exclusive scan into `workspace`, *total_out (device) = count
- *   dfh_surface_emit  : writes min(total, capacity) samples (n x 3 fp64 each); uses the same workspace. */
+ *   dfh_surface_emit  : writes min(total, capacity) samples (n x 3 fp64 each); uses the same workspace.  capacity < total:
+ *                       an even subsample in voxel order (sample i is kept iff it is the first with slot floor(i * capacity /
+ *                       total), and stored in that slot), not a prefix. */
 size_t dfh_surface_workspace_bytes(const int res[3]);
 int dfh_surface_count(const void *tsdf, const void *tsdf_w, int vol_dtype, const int res[3], double band, void *workspace,
                       size_t workspace_bytes, long *total_out, void *stream);

@@ -120,9 +120,14 @@ def test_device_extraction_matches_torch_definition(dtype):
         pt, nt = extract_surface_samples_torch(Td, Wd, 1.5, x0=x0)
         assert pos.shape == pt.shape and pos.shape[0] > 50
         assert float((pos - pt).abs().max()) <= 1e-12 and float((nrm - nt).abs().max()) <= 1e-12
-        cap = pos.shape[0] // 3
-        p2, n2 = extract_surface_samples(Td, Wd, 1.5, x0=x0, max_samples=cap)
-        assert p2.shape[0] == cap and torch.equal(p2, pos[:cap]) and torch.equal(n2, nrm[:cap])
+        for cap in (pos.shape[0] // 3, pos.shape[0] - 1, 1, 7):           # an even subsample over the whole surface, not a prefix
+            n_all = pos.shape[0]
+            sel = (torch.arange(cap, device="cuda", dtype=torch.int64) * n_all + cap - 1) // cap
+            p2, n2 = extract_surface_samples(Td, Wd, 1.5, x0=x0, max_samples=cap)
+            assert p2.shape[0] == cap and torch.equal(p2, pos[sel]) and torch.equal(n2, nrm[sel])
+        assert int(sel[-1]) > n_all // 2
+        p3, _ = extract_surface_samples(Td, Wd, 1.5, x0=x0, max_samples=n_all + 5)
+        assert torch.equal(p3, pos)
         pe, ne = extract_surface_samples(Td, torch.zeros_like(Wd), 1.5)
         assert pe.shape == (0, 3) and ne.shape == (0, 3)
     with pytest.raises(ValueError):

@@ -270,6 +270,49 @@ def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, mon
     assert float((s1 - s0).abs().max()) > 0                               # the regulariser really contributes
 
 
+def test_device_plan_builder_equals_the_torch_plan(monkeypatch):
+    """dfh_gn_sort_samples / dfh_gn_plan_count / dfh_gn_plan_build (run scan, block look-up, two stable radix sorts) against the
+    same bookkeeping assembled from torch ops: sample order, tuple keys, run ids, and all four CSR arrays, element for
+    element -- ragged sample counts, several tiles, a pattern that covers the pairs and one that does not."""
+    rng = np.random.default_rng(11)
+    for N, k, S in ((40, 4, 1000), (300, 4, 70000), (9, 2, 257), (64, 3, 256)):
+        npos = rng.uniform(0, 60, size=(N, 3)); nw = rng.uniform(3, 6, size=N)
+        ndq = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
+        pts = rng.uniform(0, 60, size=(S, 3)); nrm = rng.normal(size=(S, 3))
+        node_nbr, _ = solve.sample_knn(npos, npos, nw, k)
+        plans = {}
+        for mode in ("device", "torch"):
+            if mode == "torch":
+                monkeypatch.setenv("DFH_PLAN_TORCH", "1")
+            else:
+                monkeypatch.delenv("DFH_PLAN_TORCH", raising=False)
+            sv = solve.WarpSolver(knn=k, pcg_iters=5, distributed=False)
+            sv.set_graph(npos, ndq, nw, node_nbr=node_nbr)
+            sv.set_samples(pts, nrm)
+            sv.set_correspondences(pts + 0.1)
+            sv.build(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), 0.5)
+            plans[mode] = sv
+        a, b = plans["device"], plans["torch"]
+        assert torch.equal(a._tuple_key, b._tuple_key) and torch.equal(a._order_index(), b._order_index())
+        assert torch.equal(a.spos, b.spos) and torch.equal(a.snbr, b.snbr) and torch.equal(a.swts, b.swts) and torch.equal(a.snrm, b.snrm)
+        assert a.n_rows == b.n_rows and torch.equal(a.run_id, b.run_id) and torch.equal(a._row_first, b._row_first)
+        for name in ("blk_ptr", "blk_ent", "node_ptr", "node_ent", "rblk_ptr", "rblk_ent", "rnode_ptr", "rnode_ent"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        assert torch.equal(a.vals, b.vals) and torch.equal(a.rhs, b.rhs)            # same plan, same kernels: same bits
+        # a second sample set against the kept pattern: covered or not, both builders must agree on the verdict and the result
+        pts2 = rng.uniform(0, 60, size=(S // 2 + 3, 3))
+        for sv in (a, b):
+            if sv is b:
+                monkeypatch.setenv("DFH_PLAN_TORCH", "1")
+            else:
+                monkeypatch.delenv("DFH_PLAN_TORCH", raising=False)
+            sv.set_samples(pts2, rng.normal(size=pts2.shape) * 0 + 1.0)
+            sv.set_correspondences(pts2 + 0.1)
+            sv.build(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), 0.5)
+        assert a.B == b.B and torch.equal(a.col, b.col) and torch.equal(a.blk_ent, b.blk_ent) and torch.equal(a.vals, b.vals)
+    monkeypatch.delenv("DFH_PLAN_TORCH", raising=False)
+
+
 def test_block_pattern_kept_across_sample_sets(golden):
     """New samples on an unchanged graph: the block pattern is kept when it covers the new node pairs (only the data
     plan is rebuilt) and grows otherwise; either way the system and the step equal a fresh solver's."""

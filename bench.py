@@ -128,7 +128,7 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
             with torch.cuda.stream(side):
                 one_solve()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g, stream=side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     one_solve()
             torch.cuda.current_stream().wait_stream(side)
             g.replay()
@@ -418,7 +418,9 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
-                with torch.cuda.graph(g, stream=side):
+                # thread_local: RCCL's watchdog thread may query events while this thread captures; in the default global
+                # mode that would invalidate the capture
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     for i in range(args.steps):
                         step(args.warmup + i)
             torch.cuda.current_stream().wait_stream(side)

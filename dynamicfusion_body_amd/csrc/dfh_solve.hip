@@ -496,33 +496,28 @@ struct AssocParams {
     int H, W, k;
 };
 
-// Warp every sample with the current field, project it into the live depth frame with the
-// reference's primitives and back-project the nearest depth pixel: corr (index space), valid.
-template <typename DepthT>
-__global__ __launch_bounds__(256) void associate_kernel(const double *__restrict__ spos, const int *__restrict__ nbr,
-                                                         const double *__restrict__ wts, int S,
-                                                         const double *__restrict__ node_dq, const DepthT *__restrict__ depth,
-                                                         const AssocParams p, double *__restrict__ corr,
-                                                         unsigned char *__restrict__ valid) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= S) return;
+// normalised blend of a sample's k node DQs with its static weights (identity when the blend vanishes); returns |b|_8
+// (1 in the degenerate case)
+__device__ __forceinline__ double blend_static(const double *__restrict__ node_dq, const int *idx, const double *w, int k, double *bh) {
     double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < kKMaxS; ++j) {
-        if (j < p.k) {
-            const int gi = nbr[(size_t)i * p.k + j];
-            const double w = wts[(size_t)i * p.k + j];
+        if (j < k) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) b[c] = b[c] + w * node_dq[8 * gi + c];
+            for (int c = 0; c < 8; ++c) b[c] = b[c] + w[j] * node_dq[8 * idx[j] + c];
         }
     }
-    const double n = sqrt(((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3])) +
-                          ((b[4] * b[4] + b[5] * b[5]) + (b[6] * b[6] + b[7] * b[7])));
-    if (n == 0.0) { b[0] = 1.0; for (int c = 1; c < 8; ++c) b[c] = 0.0; }
-    else { for (int c = 0; c < 8; ++c) b[c] = b[c] / n; }
-    const double px = spos[3 * (size_t)i], py = spos[3 * (size_t)i + 1], pz = spos[3 * (size_t)i + 2];
-    const D3 x1 = dqb_warp_exact(b, round_f32(px), round_f32(py), round_f32(pz));
-    const D3 xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
+    double nb = sqrt(((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3])) +
+                     ((b[4] * b[4] + b[5] * b[5]) + (b[6] * b[6] + b[7] * b[7])));
+    if (nb == 0.0) { bh[0] = 1.0; for (int c = 1; c < 8; ++c) bh[c] = 0.0; nb = 1.0; }
+    else { for (int c = 0; c < 8; ++c) bh[c] = b[c] / nb; }
+    return nb;
+}
+
+// Projective association of one warped sample xp (index space): project with the reference's primitives, take the
+// nearest depth pixel, back-project, gate.  Returns validity; c = correspondence in index space (0 when invalid).
+template <typename DepthT>
+__device__ __forceinline__ bool associate_point(const AssocParams &p, const DepthT *__restrict__ depth, const D3 &xp, double (&c)[3]) {
     // index -> world -> camera -> pixel (fusion_dm.py:191-195)
     const double wx = p.scale * (xp.x - p.half) + p.cx, wy = p.scale * (xp.y - p.half) + p.cy, wz = p.scale * (xp.z - p.half) + p.cz;
     const double *lw = p.lw_cam.m;
@@ -556,9 +551,37 @@ __global__ __launch_bounds__(256) void associate_kernel(const double *__restrict
             ok = (dx * dx + dy * dy + dz * dz) <= p.max_dist * p.max_dist;
         }
     }
-    corr[3 * (size_t)i] = ok ? c0 : 0.0;
-    corr[3 * (size_t)i + 1] = ok ? c1 : 0.0;
-    corr[3 * (size_t)i + 2] = ok ? c2 : 0.0;
+    c[0] = ok ? c0 : 0.0; c[1] = ok ? c1 : 0.0; c[2] = ok ? c2 : 0.0;
+    return ok;
+}
+
+// Warp every sample with the current field, project it into the live depth frame with the
+// reference's primitives and back-project the nearest depth pixel: corr (index space), valid.
+template <typename DepthT>
+__global__ __launch_bounds__(256) void associate_kernel(const double *__restrict__ spos, const int *__restrict__ nbr,
+                                                         const double *__restrict__ wts, int S,
+                                                         const double *__restrict__ node_dq, const DepthT *__restrict__ depth,
+                                                         const AssocParams p, double *__restrict__ corr,
+                                                         unsigned char *__restrict__ valid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    int idx[kKMaxS];
+    double w[kKMaxS];
+#pragma unroll
+    for (int j = 0; j < kKMaxS; ++j) {
+        idx[j] = j < p.k ? nbr[(size_t)i * p.k + j] : 0;
+        w[j] = j < p.k ? wts[(size_t)i * p.k + j] : 0.0;
+    }
+    double b[8];
+    blend_static(node_dq, idx, w, p.k, b);
+    const double px = spos[3 * (size_t)i], py = spos[3 * (size_t)i + 1], pz = spos[3 * (size_t)i + 2];
+    const D3 x1 = dqb_warp_exact(b, round_f32(px), round_f32(py), round_f32(pz));
+    const D3 xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
+    double c[3];
+    const bool ok = associate_point<DepthT>(p, depth, xp, c);
+    corr[3 * (size_t)i] = c[0];
+    corr[3 * (size_t)i + 1] = c[1];
+    corr[3 * (size_t)i + 2] = c[2];
     valid[i] = ok ? 1 : 0;
 }
 
@@ -590,27 +613,29 @@ __host__ __device__ constexpr int gn_row_stride(int K) { return (gn_row_entries(
 
 // Residual and 6-DoF Jacobian rows of one data sample (formulas: oracle/gn_np.py
 // data_residual_jacobian).  J is written as k x 6 into Jrow (row-major), returns r.
+// second half of data_row: from the normalised blend bh (|b|_8 = nb), the float32-rounded point pf and the warped point xp
+__device__ __forceinline__ double data_row_from(const double *__restrict__ node_dq, const int *idx, const double *w, int k,
+                                                const double *lwq, const double *bh, double nb, double pfx, double pfy, double pfz,
+                                                const D3 &xp, double nx, double ny, double nz, double c0, double c1, double c2,
+                                                double *Jrow);
+
 __device__ __forceinline__ double data_row(const double *__restrict__ node_dq, const int *idx, const double *w, int k,
                                            const double *lwq, double px, double py, double pz, double nx, double ny,
                                            double nz, double c0, double c1, double c2, double *Jrow) {
-    double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < kKMaxS; ++j) {
-        if (j < k) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) b[c] = b[c] + w[j] * node_dq[8 * idx[j] + c];
-        }
-    }
-    double nb = sqrt(((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3])) +
-                     ((b[4] * b[4] + b[5] * b[5]) + (b[6] * b[6] + b[7] * b[7])));
     double bh[8];
-    if (nb == 0.0) { bh[0] = 1.0; for (int c = 1; c < 8; ++c) bh[c] = 0.0; nb = 1.0; }
-    else { for (int c = 0; c < 8; ++c) bh[c] = b[c] / nb; }
+    const double nb = blend_static(node_dq, idx, w, k, bh);
     const double pfx = round_f32(px), pfy = round_f32(py), pfz = round_f32(pz);
-    const double nfx = round_f32(nx), nfy = round_f32(ny), nfz = round_f32(nz);
     const D3 x1 = dqb_warp_exact(bh, pfx, pfy, pfz);
-    const D3 n1 = dqb_warp_normal_exact(bh, nfx, nfy, nfz);
     const D3 xp = dqb_warp_exact(lwq, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
+    return data_row_from(node_dq, idx, w, k, lwq, bh, nb, pfx, pfy, pfz, xp, nx, ny, nz, c0, c1, c2, Jrow);
+}
+
+__device__ __forceinline__ double data_row_from(const double *__restrict__ node_dq, const int *idx, const double *w, int k,
+                                                const double *lwq, const double *bh, double nb, double pfx, double pfy, double pfz,
+                                                const D3 &xp, double nx, double ny, double nz, double c0, double c1, double c2,
+                                                double *Jrow) {
+    const double nfx = round_f32(nx), nfy = round_f32(ny), nfz = round_f32(nz);
+    const D3 n1 = dqb_warp_normal_exact(bh, nfx, nfy, nfz);
     const D3 np_ = dqb_warp_normal_exact(lwq, round_f32(n1.x), round_f32(n1.y), round_f32(n1.z));
     const double d0 = xp.x - c0, d1 = xp.y - c1, d2 = xp.z - c2;
     const double r = (np_.x * d0 + np_.y * d1) + np_.z * d2;
@@ -665,17 +690,26 @@ __device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N,
                              const int *__restrict__ row_ptr, const int *__restrict__ col, double *__restrict__ vals,
                              double *__restrict__ rhs, double *__restrict__ cost_count, double *__restrict__ partial_reg);
 
-template <int K, bool PLANNED>
+// ASSOC: the projective association (associate_kernel's arithmetic, same bits) runs inside this kernel -- every sample of the
+// tile is warped once, associated against `depth`, its correspondence and validity are written to corr / valid (for the
+// callers that read them) and the valid ones go straight on to their Jacobian rows: one launch and one blend + warp per
+// sample less per GN iteration.
+struct AssocArgs {
+    AssocParams ap;
+    const float *depth;
+};
+
+template <int K, bool PLANNED, bool ASSOC>
 __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
                                                              const int *__restrict__ nbr, const double *__restrict__ wts,
-                                                             const double *__restrict__ corr,
-                                                             const unsigned char *__restrict__ valid,
+                                                             double *__restrict__ corr,
+                                                             unsigned char *__restrict__ valid,
                                                              const double *__restrict__ node_dq, const BuildParams p,
                                                              const int *__restrict__ row_ptr, const int *__restrict__ col,
                                                              double *__restrict__ vals, double *__restrict__ rhs,
                                                              double *__restrict__ cost_count, const int *__restrict__ run_id,
                                                              double *__restrict__ partial, double *__restrict__ tile_cost,
-                                                             const RegTail rt) {
+                                                             const RegTail rt, const AssocArgs aa) {
     if (PLANNED && (int)blockIdx.x >= rt.n_tiles) {      // (workgroup-uniform) the regulariser's share of this launch
         gn_reg_pairs((int)blockIdx.x - rt.n_tiles, rt.node_nbr, rt.N, rt.k, node_dq, rt.node_pos, rt.node_w, rt.rw, row_ptr, col, vals,
                      rhs, cost_count, rt.partial_reg);
@@ -690,7 +724,26 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     const int tile_n = min(kTile, p.S - blockIdx.x * kTile);
     // ---- each valid sample computes its residual and Jacobian row and appends it to the tile's
     // compacted list in LDS (order preserved): the reduction below only walks valid rows
-    const bool act = tid < tile_n && valid[s] != 0;
+    int idx[kKMaxS];
+    double w[kKMaxS];
+    double a_bh[8], a_nb = 1.0, a_pf[3] = {0, 0, 0}, a_c[3] = {0, 0, 0};
+    D3 a_xp{0, 0, 0};
+    bool a_ok = false;
+    if (ASSOC && tid < tile_n) {
+#pragma unroll
+        for (int j = 0; j < kKMaxS; ++j) {
+            idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
+            w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
+        }
+        a_nb = blend_static(node_dq, idx, w, K, a_bh);
+        a_pf[0] = round_f32(spos[3 * (size_t)s]); a_pf[1] = round_f32(spos[3 * (size_t)s + 1]); a_pf[2] = round_f32(spos[3 * (size_t)s + 2]);
+        const D3 x1 = dqb_warp_exact(a_bh, a_pf[0], a_pf[1], a_pf[2]);
+        a_xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
+        a_ok = associate_point<float>(aa.ap, aa.depth, a_xp, a_c);
+        corr[3 * (size_t)s] = a_c[0]; corr[3 * (size_t)s + 1] = a_c[1]; corr[3 * (size_t)s + 2] = a_c[2];
+        valid[s] = a_ok ? 1 : 0;
+    }
+    const bool act = ASSOC ? a_ok : (tid < tile_n && valid[s] != 0);
     __shared__ int sWaveCnt[4];
     const unsigned long long bal = __ballot(act);
     const int lane = tid & 63, wv = tid >> 6;
@@ -714,16 +767,20 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     if (act) {
         if (PLANNED) sRow[pos] = run_id[s];
         double Jrow[NJ];
-        int idx[kKMaxS];
-        double w[kKMaxS];
+        double r;
+        if (ASSOC) {
+            r = data_row_from(node_dq, idx, w, K, p.lw.q, a_bh, a_nb, a_pf[0], a_pf[1], a_pf[2], a_xp, snrm[3 * (size_t)s],
+                              snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], a_c[0], a_c[1], a_c[2], Jrow);
+        } else {
 #pragma unroll
-        for (int j = 0; j < kKMaxS; ++j) {
-            idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
-            w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
+            for (int j = 0; j < kKMaxS; ++j) {
+                idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
+                w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
+            }
+            r = data_row(node_dq, idx, w, K, p.lw.q, spos[3 * (size_t)s], spos[3 * (size_t)s + 1], spos[3 * (size_t)s + 2],
+                         snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], corr[3 * (size_t)s],
+                         corr[3 * (size_t)s + 1], corr[3 * (size_t)s + 2], Jrow);
         }
-        double r = data_row(node_dq, idx, w, K, p.lw.q, spos[3 * (size_t)s], spos[3 * (size_t)s + 1], spos[3 * (size_t)s + 2],
-                            snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], corr[3 * (size_t)s],
-                            corr[3 * (size_t)s + 1], corr[3 * (size_t)s + 2], Jrow);
         obj = 0.5 * r * r;                                     // this sample's term of the objective
         if (p.huber > 0.0 && fabs(r) > p.huber) {              // Huber: rho = delta (|r| - delta / 2) beyond delta, and the
             obj = p.huber * (fabs(r) - 0.5 * p.huber);         // row and its residual get sqrt of the IRLS weight
@@ -1576,6 +1633,9 @@ __global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ n
 }  // namespace dfh
 
 // =================================================================================== C ABI
+static int fill_assoc_params(dfh::AssocParams &p, const double lw_dq[8], int H, int W, const double K[9], const double Kinv[9],
+                             const double lw_cam[12], double scale, const double center[3], double half, double max_dist, int knn);
+
 extern "C" {
 
 int dfh_residual_rigid(const double *verts, const double *normals, const double *corr, int n, const double x[8],
@@ -1741,21 +1801,10 @@ int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *wei
     DFH_REQUIRE(sample_pos && nbr && weights && node_dq && lw_dq && depth && K && Kinv && lw_cam && center && corr_out && valid_out,
                 "dfh_gn_associate: null pointer");
     AssocParams p;
-    for (int i = 0; i < 9; ++i) { p.K.m[i] = K[i]; p.Kinv.m[i] = Kinv[i]; }
-    for (int i = 0; i < 12; ++i) p.lw_cam.m[i] = lw_cam[i];
-    for (int i = 0; i < 8; ++i) p.lw.q[i] = lw_dq[i];
-    {   // inverse of the 3x3 part (adjugate)
-        const double *m = lw_cam;
-        const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
-        const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-        DFH_REQUIRE(det != 0.0, "dfh_gn_associate: singular extrinsic");
-        const double id = 1.0 / det;
-        p.Rinv.m[0] = (e * i - f * h) * id; p.Rinv.m[1] = (c * h - b * i) * id; p.Rinv.m[2] = (b * f - c * e) * id;
-        p.Rinv.m[3] = (f * g - d * i) * id; p.Rinv.m[4] = (a * i - c * g) * id; p.Rinv.m[5] = (c * d - a * f) * id;
-        p.Rinv.m[6] = (d * h - e * g) * id; p.Rinv.m[7] = (b * g - a * h) * id; p.Rinv.m[8] = (a * e - b * d) * id;
+    {
+        const int rc = fill_assoc_params(p, lw_dq, H, W, K, Kinv, lw_cam, scale, center, half, max_dist, knn);
+        if (rc != DFH_OK) return rc;
     }
-    p.scale = scale; p.cx = center[0]; p.cy = center[1]; p.cz = center[2]; p.half = half; p.max_dist = max_dist;
-    p.H = H; p.W = W; p.k = knn;
     dim3 grid((n_samples + 255) / 256), block(256);
     if (depth_dtype == DFH_F32) {
         hipLaunchKernelGGL(associate_kernel<float>, grid, block, 0, (hipStream_t)stream, sample_pos, nbr, weights, n_samples,
@@ -1769,15 +1818,16 @@ int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *wei
 }
 
 static int gn_build_impl(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
-                         const double *corr, const unsigned char *valid, int n_samples, int knn, const double *node_dq,
+                         double *corr, unsigned char *valid, int n_samples, int knn, const double *node_dq,
                          const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
                          const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
                          double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
                          const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
                          const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
-                         void *stream) {
+                         void *stream, const dfh::AssocArgs *assoc = nullptr) {
     using namespace dfh;
     const bool planned = blk_ptr != nullptr;
+    DFH_REQUIRE(!assoc || planned, "dfh_gn_build: association inside the build needs a plan");
     DFH_REQUIRE(huber_delta >= 0.0, "dfh_gn_build: negative huber_delta");
     const bool planned_reg = planned && partial_reg != nullptr;
     if (planned_reg) DFH_REQUIRE(rblk_ptr && rblk_ent && rnode_ptr && rnode_ent, "dfh_gn_build_planned: null regulariser plan array");
@@ -1785,7 +1835,8 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
     DFH_REQUIRE(knn >= 1 && knn <= kKMaxS, "dfh_gn_build: knn=%d outside [1,%d]", knn, kKMaxS);
     DFH_REQUIRE(node_dq && node_pos && node_w && lw_dq && row_ptr && col && vals && rhs && cost_count, "dfh_gn_build: null pointer");
     if (planned) {
-        DFH_REQUIRE(n_rows >= 0 && blk_ent && node_ptr && node_ent, "dfh_gn_build_planned: null plan array");
+        // (a rank whose slab holds no surface has no samples, no rows and EMPTY entry lists: null pointers are fine then)
+        DFH_REQUIRE(n_rows >= 0 && node_ptr && (n_rows == 0 || (blk_ent && node_ent)), "dfh_gn_build_planned: null plan array");
         DFH_REQUIRE(n_samples == 0 || (run_id && partial && n_rows > 0), "dfh_gn_build_planned: samples without rows");
     }
     hipStream_t s = (hipStream_t)stream;
@@ -1816,14 +1867,18 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
             rt.rw = rw; rt.N = n_nodes; rt.k = knn;
         }
         dim3 grid((unsigned)(n_tiles + (reg_in_data_launch ? (n_nodes * knn + 3) / 4 : 0))), block(256);
+        const AssocArgs aa = assoc ? *assoc : AssocArgs{};
 #define DFH_BUILD(KK)                                                                                               \
     case KK:                                                                                                        \
-        if (planned)                                                                                                \
-            hipLaunchKernelGGL((gn_build_data_kernel<KK, true>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
-                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost, rt); \
+        if (assoc)                                                                                                  \
+            hipLaunchKernelGGL((gn_build_data_kernel<KK, true, true>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
+                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost, rt, aa); \
+        else if (planned)                                                                                           \
+            hipLaunchKernelGGL((gn_build_data_kernel<KK, true, false>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
+                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost, rt, aa); \
         else                                                                                                        \
-            hipLaunchKernelGGL((gn_build_data_kernel<KK, false>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
-                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost, rt); \
+            hipLaunchKernelGGL((gn_build_data_kernel<KK, false, false>), grid, block, 0, s, sample_pos, sample_nrm, nbr, weights, corr, \
+                               valid, node_dq, p, row_ptr, col, vals, rhs, cost_count, run_id, partial, tile_cost, rt, aa); \
         break
         switch (knn) {
             DFH_BUILD(1); DFH_BUILD(2); DFH_BUILD(3); DFH_BUILD(4); DFH_BUILD(5); DFH_BUILD(6); DFH_BUILD(7); DFH_BUILD(8);
@@ -1873,7 +1928,8 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
                  const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
                  const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
                  double *rhs, double *cost_count, void *stream) {
-    return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr, valid, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
+    return gn_build_impl(sample_pos, sample_nrm, nbr, weights, const_cast<double *>(corr), const_cast<unsigned char *>(valid), n_samples,
+                         knn, node_dq, node_pos, node_w, node_nbr,
                          n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, nullptr, 0, nullptr, nullptr, nullptr,
                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, stream);
 }
@@ -1893,9 +1949,53 @@ int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, con
                          void *stream) {
     using namespace dfh;
     DFH_REQUIRE(blk_ptr, "dfh_gn_build_planned: null blk_ptr");
-    return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr, valid, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
+    return gn_build_impl(sample_pos, sample_nrm, nbr, weights, const_cast<double *>(corr), const_cast<unsigned char *>(valid), n_samples,
+                         knn, node_dq, node_pos, node_w, node_nbr,
                          n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
                          blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream);
+}
+
+static int fill_assoc_params(dfh::AssocParams &p, const double lw_dq[8], int H, int W, const double K[9], const double Kinv[9],
+                             const double lw_cam[12], double scale, const double center[3], double half, double max_dist, int knn) {
+    using namespace dfh;
+    for (int i = 0; i < 9; ++i) { p.K.m[i] = K[i]; p.Kinv.m[i] = Kinv[i]; }
+    for (int i = 0; i < 12; ++i) p.lw_cam.m[i] = lw_cam[i];
+    for (int i = 0; i < 8; ++i) p.lw.q[i] = lw_dq[i];
+    {   // inverse of the 3x3 part (adjugate)
+        const double *m = lw_cam;
+        const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+        const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+        DFH_REQUIRE(det != 0.0, "dfh_gn_associate: singular extrinsic");
+        const double id = 1.0 / det;
+        p.Rinv.m[0] = (e * i - f * h) * id; p.Rinv.m[1] = (c * h - b * i) * id; p.Rinv.m[2] = (b * f - c * e) * id;
+        p.Rinv.m[3] = (f * g - d * i) * id; p.Rinv.m[4] = (a * i - c * g) * id; p.Rinv.m[5] = (c * d - a * f) * id;
+        p.Rinv.m[6] = (d * h - e * g) * id; p.Rinv.m[7] = (b * g - a * h) * id; p.Rinv.m[8] = (a * e - b * d) * id;
+    }
+    p.scale = scale; p.cx = center[0]; p.cy = center[1]; p.cz = center[2]; p.half = half; p.max_dist = max_dist;
+    p.H = H; p.W = W; p.k = knn;
+    return DFH_OK;
+}
+
+int dfh_gn_build_planned_assoc(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                               double *corr_out, unsigned char *valid_out, int n_samples, int knn, const double *node_dq,
+                               const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                               const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                               double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                               const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                               const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                               const float *depth, int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12],
+                               double scale, const double center[3], double half, double max_dist, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(blk_ptr, "dfh_gn_build_planned_assoc: null blk_ptr");
+    DFH_REQUIRE(depth && K && Kinv && lw_cam && center && lw_dq && corr_out && valid_out, "dfh_gn_build_planned_assoc: null pointer");
+    DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "dfh_gn_build_planned_assoc: bad depth map / scale");
+    AssocArgs aa;
+    const int rc = fill_assoc_params(aa.ap, lw_dq, H, W, K, Kinv, lw_cam, scale, center, half, max_dist, knn);
+    if (rc != DFH_OK) return rc;
+    aa.depth = depth;
+    return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
+                         n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
+                         blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream, &aa);
 }
 
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {

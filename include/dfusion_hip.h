@@ -259,6 +259,20 @@ int dfh_gn_build_planned(const double *sample_pos, const double *sample_nrm, con
                          const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
                          void *stream);
 
+/* dfh_gn_associate and dfh_gn_build_planned in ONE launch sequence: the data-row kernel warps every sample once, associates it
+ * against `depth` (float32, H x W) exactly as dfh_gn_associate does -- corr_out / valid_out receive the same values, bit for
+ * bit -- and sends the valid ones straight on to their Jacobian rows; the normal equations are those of dfh_gn_build_planned on
+ * that corr / valid.  One launch and one blend + warp per sample less per GN iteration. */
+int dfh_gn_build_planned_assoc(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                               double *corr_out, unsigned char *valid_out, int n_samples, int knn, const double *node_dq,
+                               const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                               const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                               double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                               const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                               const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                               const float *depth, int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12],
+                               double scale, const double center[3], double half, double max_dist, void *stream);
+
 /* ---- per-frame bookkeeping of the planned build, on the device ---------------------------------------------------------
  * dfh_gn_sort_samples: the four per-sample arrays in the order of their node tuples (lexicographic, stable: equal tuples
  *   keep their input order), key_out[i] = the i-th sorted tuple as a knn-digit number in base n_nodes, order_out[i] =

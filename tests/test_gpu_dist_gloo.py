@@ -107,9 +107,10 @@ def test_two_ranks_one_gpu_match_single_process():
     assert list(out) == [1] * ws
 
 
-def _frame_worker(rank, ws, port, out):
+def _frame_worker(rank, ws, port, out, sphere_r=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_WORLD_SIZE"] = str(ws)
     dist.init_process_group("gloo", rank=rank, world_size=ws)
     try:
         from dynamicfusion_body_amd import scene
@@ -123,19 +124,23 @@ def _frame_worker(rank, ws, port, out):
         node_pos, node_w = scene.fibonacci_nodes(N, R)
         lw_cam = scene.view_extrinsic(0.0)
         frames = []
+        sr = scene.SPHERE_R if sphere_r is None else sphere_r
         for f in range(2):
             off = np.array([0.3, -0.2, 0.15]) * (f + 1) * scale
             frames.append(torch.from_numpy(scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=off,
-                                                              sphere_r=scene.SPHERE_R * 1.01)).cuda())
+                                                              sphere_r=sr * 1.01, wall_z=None if sphere_r is not None else scene.WALL_Z)).cuda())
         res = {}
         for mode in ("sharded", "whole"):
             sf = SlabFrame(K, scale, center, R, tdist / scale, node_pos, node_w, knn=4, pcg_iters=300, band=2.0,
                            distributed=(mode == "sharded"))
             for ang in (0.0, 40.0, -40.0):
                 lw = scene.view_extrinsic(ang)
-                d = torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda()
+                d = torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0, sphere_r=sr,
+                                                        wall_z=None if sphere_r is not None else scene.WALL_Z)).cuda()
                 sf.integrate(d, lw)
-            sf.refresh_samples()
+            n_s = sf.refresh_samples()
+            if mode == "sharded":
+                n_mine = n_s
             for d in frames:
                 sf.step(d, lw_cam, gn_iters=3, lm_abs=1.0)
             res[mode] = sf
@@ -145,10 +150,10 @@ def _frame_worker(rank, ws, port, out):
         Ws, Ww = res["sharded"].Wt, res["whole"].Wt[a:b]
         dq_s, dq_w = res["sharded"].fs.solver.node_dq, res["whole"].fs.solver.node_dq
         out.put((rank, float((Ts - Tw).abs().max()), float((Ws - Ww).abs().max()), float(((Ws > 0) != (Ww > 0)).float().mean()),
-                 float((dq_s - dq_w).abs().max()), float((Tw - tdist / scale).abs().max()), None))
+                 float((dq_s - dq_w).abs().max()), float((Tw - tdist / scale).abs().max()), None, n_mine))
     except Exception as e:                                                  # pragma: no cover
         import traceback
-        out.put((rank, 0, 0, 0, 0, 0, traceback.format_exc()))
+        out.put((rank, 0, 0, 0, 0, 0, traceback.format_exc(), -1))
     finally:
         dist.destroy_process_group()
 
@@ -166,10 +171,31 @@ def test_slab_frame_two_ranks():
     got = [out.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(60)
-    for rank, dT, dW, dmask, ddq, moved, err in got:
+    for rank, dT, dW, dmask, ddq, moved, err, n_mine in got:
         assert err is None, err
         assert ddq < 1e-6 and dT < 1e-4 and dW < 1e-4 and dmask < 1e-4
         assert moved > 1.0                                                   # the frames really changed the canonical volume
+
+
+def test_slab_frame_with_ranks_that_own_no_surface():
+    """Three slabs, a small sphere that lies entirely inside the middle one: ranks 0 and 2 have no samples at all (no rows, no
+    plan, an all-zero contribution to the all-reduce) and must still take every collective the middle rank takes -- the 8-GPU job
+    at 256^3 has such ranks (the sphere spans planes 48..208 of 256).  Same result as the whole-grid run."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frame_worker, args=(r, 3, port, out, 0.15)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    counts = {}
+    for rank, dT, dW, dmask, ddq, moved, err, n_mine in got:
+        assert err is None, err
+        counts[rank] = n_mine
+        assert ddq < 1e-6 and dT < 1e-4 and dW < 1e-4 and dmask < 1e-4
+    assert counts[0] == 0 and counts[2] == 0 and counts[1] > 500
 
 
 def _config4_worker(rank, ws, port, out):

@@ -176,3 +176,43 @@ def test_composed_frame_loop_tracks_without_drift():
     assert max(tmax) < 1.5 and max(tmax[20:]) > 0.3                       # follows the 0.62-voxel amplitude, no run-away
     assert np.linalg.norm(dq[:, 1:4], axis=1).max() < 0.02
     assert max(counts[20:]) < 1.15 * min(counts[20:])                     # steady band
+
+
+def test_association_inside_the_build_is_bit_identical(monkeypatch):
+    """dfh_gn_build_planned_assoc (association folded into the data-row kernel) against dfh_gn_associate followed by
+    dfh_gn_build_planned: same correspondences, same validity, same normal equations and cost, bit for bit -- at identity and
+    after moving the field, with and without Huber weights and a gate, and the whole 5-iteration loop."""
+    R, N, k = 64, 48, 4
+    K, (H, W), scale, center, tdist, T, Wt = build_canonical(R, "C1")
+    node_pos, node_w = scene.fibonacci_nodes(N, R)
+    ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
+    lw_cam = scene.view_extrinsic(0.0)
+    live = scene.render_depth(K, lw_cam, H, W, dtype=np.float32, invalid_frac=0.01, seed=5,
+                              sphere_offset=np.array([0.6, -0.4, 0.3]) * scale, sphere_r=scene.SPHERE_R * 1.02)
+    depth = torch.from_numpy(live).cuda()
+    rng = np.random.default_rng(2)
+    dq1 = G.apply_twists(ident, rng.normal(scale=[3e-3] * 3 + [0.2] * 3, size=(N, 6)))
+    out = {}
+    for mode in ("fused", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("DFH_GN_NO_FUSED_ASSOC", "1")
+        else:
+            monkeypatch.delenv("DFH_GN_NO_FUSED_ASSOC", raising=False)
+        fs = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=10, distributed=False)
+        fs.set_graph(node_pos, ident, node_w)
+        fs.set_canonical(T, Wt, band=2.0)
+        sv = fs.solver
+        snaps = []
+        for dq, max_dist, huber in ((ident, 0.0, 0.0), (dq1, 2.0, 0.5), (dq1, 4.0, 0.0)):
+            sv.node_dq.copy_(torch.from_numpy(dq).cuda())
+            sv.build_associated(depth, fs.K, fs.Kinv, lw_cam, scale, center, R / 2, fs.lw, 0.7, max_dist, huber)
+            snaps.append((sv.corr.clone(), sv.valid.clone(), sv.vals.clone(), sv.rhs.clone(), sv.cost_count.clone()))
+        sv.node_dq.copy_(torch.from_numpy(ident).cuda())
+        costs = fs.solve(depth, lw_cam, rw=5.0, iters=5, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5)
+        out[mode] = (snaps, costs, sv.node_dq.clone())
+    for a, b in zip(out["fused"][0], out["separate"][0]):
+        assert int(a[1].sum()) > 500
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert out["fused"][1] == out["separate"][1] and torch.equal(out["fused"][2], out["separate"][2])
+    monkeypatch.delenv("DFH_GN_NO_FUSED_ASSOC", raising=False)

@@ -8,7 +8,8 @@ import os
 import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libdfusion_hip.so")
+# DFH_LIB_PATH: an alternative build of the SAME library (kernel experiments, tools/build_variant.sh) -- not a fallback
+LIB_PATH = os.environ.get("DFH_LIB_PATH") or os.path.join(_PKG, "libdfusion_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dfusion_hip.h")
 
 F32, F64 = 0, 1

@@ -60,6 +60,13 @@ constexpr int kFixOne = 1 << kFixShift;
 constexpr int kFixHalf = 1 << (kFixShift - 1);
 constexpr int kFixBand = 8;                     // guard band around multiples of 0.5 px
 constexpr int kFastMaxDim = 2048;               // (dim-1) << 20 must fit in int32
+// brick = kBrX x kBrY x kBrZ voxels = one wave (64 lanes x 4 voxels); kBrZ / 4 z-packs per row, kBrX * kBrY rows
+#ifndef DFH_BRICK_Y
+#define DFH_BRICK_Y 4
+#endif
+constexpr int kBrX = 4, kBrY = DFH_BRICK_Y, kBrZ = 256 / (kBrX * kBrY);      // 4 x 4 x 16 (shipped) or 4 x 2 x 32
+constexpr int kBrZP = kBrZ / 4;                  // z-packs per row of a brick
+static_assert(kBrX * kBrY * kBrZP == 64, "a brick is one wave");
 constexpr int kPyrLevels = 5;                   // pyramid levels 1..5 (cells of 2..32 pixels)
 constexpr int kCullMargin = 1 << 10;            // 2^-10 px: corner projections are good to 2^-19 px, the reference's to 1e-12 px
 constexpr long kTargetBlocks = 1L << 40;        // measured (profiles/kbench_r1.txt): one plane per block is
@@ -397,7 +404,8 @@ __device__ __forceinline__ bool brick_culled(const IntegrateParams &p, int x0, i
         double q[NC];
 #pragma unroll
         for (int r = 0; r < NC; ++r)
-            q[r] = base[r] + (((c & 1) ? 3.0 * p.Ax[r] : 0.0) + ((c & 2) ? 3.0 * p.Ay[r] : 0.0) + ((c & 4) ? 15.0 * p.Az[r] : 0.0));
+            q[r] = base[r] + (((c & 1) ? (double)(kBrX - 1) * p.Ax[r] : 0.0) + ((c & 2) ? (double)(kBrY - 1) * p.Ay[r] : 0.0) +
+                              ((c & 4) ? (double)(kBrZ - 1) * p.Az[r] : 0.0));
         front = front && q[2] > 1e-6;
         const double rr = rcp_nr1(q[2]);
         const int qu = cvt_i32_sat(q[0] * rr), qv = cvt_i32_sat(q[1] * rr);
@@ -442,12 +450,12 @@ __global__ __launch_bounds__(256) void brick_classify_kernel(const IntegratePara
     const int bzg = t % g.nzg; t /= g.nzg;
     const int by = t % g.nyb;
     const int bx = t / g.nyb;
-    const int z0 = 64 * bzg + 16 * wv;
+    const int z0 = 4 * kBrZ * bzg + kBrZ * wv;
     unsigned m = 0;
     if (z0 < p1.Z) {
         for (int v = 0; v < n_views; ++v) {
             const IntegrateParams &p = BYVAL ? p1 : views[v];
-            if (!(p.cull && brick_culled<PINHOLE>(p, p.x0 + 4 * bx, 4 * by, z0))) m |= 1u << v;
+            if (!(p.cull && brick_culled<PINHOLE>(p, p.x0 + kBrX * bx, kBrY * by, z0))) m |= 1u << v;
         }
     }
     mask[b] = (unsigned short)m;
@@ -475,9 +483,9 @@ __device__ __forceinline__ void brick_coords(const IntegrateParams &p, const Bri
         bzg = (int)(logical % g.nzg); by = (int)((logical / g.nzg) % g.nyb); bx = (int)(logical / ((long)g.nzg * g.nyb));
     }
     brick = (((bx * g.nyb + by) * g.nzg) + bzg) * 4 + wv;
-    xl = 4 * bx + (lane >> 4);                            // slab-local plane
-    y = 4 * by + ((lane >> 2) & 3);
-    z0 = 64 * bzg + 16 * wv + 4 * (lane & 3);
+    xl = kBrX * bx + lane / (kBrY * kBrZP);               // slab-local plane
+    y = kBrY * by + (lane / kBrZP) % kBrY;
+    z0 = 4 * kBrZ * bzg + kBrZ * wv + 4 * (lane % kBrZP);
 }
 
 // One view.  mask == NULL: every brick is swept (no classification pass ran).
@@ -770,9 +778,9 @@ static int launch_pyramids(const void *const *depth, int n_views, int H, int W, 
 
 static BrickGeom brick_geom(int Y, int Z, int nx, dim3 &grid, int &n_bricks) {
     BrickGeom g;
-    g.nzg = (Z + 63) / 64;
-    g.nyb = (Y + 3) / 4;
-    const int nxb = (nx + 3) / 4;
+    g.nzg = (Z + 4 * kBrZ - 1) / (4 * kBrZ);
+    g.nyb = (Y + kBrY - 1) / kBrY;
+    const int nxb = (nx + kBrX - 1) / kBrX;
     g.nxb = nxb;
     // launch order of the workgroups: measured at 512^3 (profiles/r2_k1_experiments.txt) y-fastest beats z-fastest by 3-10 %
     // (which HBM channels the workgroups in flight hit together), an XCD-contiguous order loses 20 %
@@ -826,7 +834,7 @@ extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, cons
     // against 43.5 us (profiles/r2_k1_experiments.txt).  Smaller slabs keep the row sweep; DFH_K1_BRICKS_MIN overrides.
     const bool have_ws = workspace && workspace_bytes >= dfh_integrate_workspace_bytes(1, H, W, res, x0, x1);
     const long bricks_min = getenv("DFH_K1_BRICKS_MIN") ? atol(getenv("DFH_K1_BRICKS_MIN")) : 131072;
-    const long slab_bricks = (long)((res[1] + 3) / 4) * ((res[2] + 63) / 64) * ((x1 - x0 + 3) / 4) * 4;
+    const long slab_bricks = (long)((res[1] + kBrY - 1) / kBrY) * ((res[2] + 4 * kBrZ - 1) / (4 * kBrZ)) * ((x1 - x0 + kBrX - 1) / kBrX) * 4;
     const bool bricks = vol_dtype == DFH_F32 && fast_ok && vec4 && !getenv("DFH_K1_NO_BRICKS") && slab_bricks >= bricks_min &&
                         (have_ws || getenv("DFH_K1_BRICKS_NOCULL"));
     if (bricks) {

@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--launch", default="auto", choices=("auto", "eager", "graph"),
                     help="how the timed K1 steps are issued: eager ctypes calls, one hipGraph replay, auto = the faster")
     ap.add_argument("--no-k1-512", action="store_true", help="skip the 512^3 K1 roofline leg (1 GPU only)")
+    ap.add_argument("--leg-timeout", type=int, default=300, help="N > 1: seconds the secondary legs (gn, frame) may take before "
+                                                                   "rank 0 prints the line without them and every rank leaves (0 = off)")
     ap.add_argument("--no-frame", action="store_true", help="skip the end-to-end per-frame leg")
     ap.add_argument("--gn-nodes", type=int, default=512)
     ap.add_argument("--gn-solves", type=int, default=5, help="timed solves of 10 GN iterations each")
@@ -69,6 +71,8 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
     from dynamicfusion_body_amd import kernels
     from dynamicfusion_body_amd import dist as D
     from dynamicfusion_body_amd.pipeline import FrameSolver
+    if os.environ.get("DFH_TEST_FAIL_GN_RANK") == str(rank):        # (test hook: the watchdog path of main())
+        raise RuntimeError("injected failure on rank %d" % rank)
     R = args.res
     H, W, fx, cx, cy = scene.CAMERAS["C2" if R <= 256 else "C5"]
     K = scene.intrinsics(fx, cx, cy)
@@ -577,23 +581,55 @@ def main():
         except Exception as e:
             out["k1_512"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
+    # The headline (K1) is measured; the secondary legs below run collectives.  If a rank fails inside one of them its peers would
+    # wait in a collective for ever, so every rank arms a watchdog: when it fires, rank 0 prints the line with what it has and all
+    # ranks leave.  (One rank: exceptions are simply caught.)
+    import threading
+    emit_lock = threading.Lock()
+
+    def emit_and_leave(timed_out=False):
+        with emit_lock:                                   # (the watchdog thread and the main thread must not both print)
+            if timed_out:
+                for leg in ("gn", "frame"):
+                    if leg not in out and not (args.no_gn or (leg == "frame" and args.no_frame)):
+                        out[leg] = {"error": "did not finish within %d s (a rank failed or a collective stalled)" % args.leg_timeout}
+            if rank == 0:
+                print(json.dumps(out))
+                sys.stdout.flush()
+            if timed_out:
+                os._exit(0)
+
+    # (a watchdog THREAD, not SIGALRM: a rank stuck inside a collective is inside a C call, where Python runs no signal handler --
+    # but torch releases the GIL there, so a timer thread does run)
+    watchdog = None
+    if distributed and args.leg_timeout > 0:
+        watchdog = threading.Timer(args.leg_timeout, emit_and_leave, kwargs={"timed_out": True})
+        watchdog.daemon = True
+        watchdog.start()
+    failed = False
     if not args.no_gn:
         try:
             out["gn"] = gn_leg(args, torch, dist, scene, rank, world, barrier)
         except Exception as e:                        # a failure here must not cost the headline line
             out["gn"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-        if not args.no_frame:
+            failed = True
+        if not args.no_frame and not (failed and distributed):
             try:
                 out["frame"] = frame_leg(args, torch, dist, scene, rank, world, barrier)
             except Exception as e:                    # the composed leg must never cost the headline line
                 out["frame"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-
+                failed = True
+    if distributed and failed:
+        # this rank's collectives no longer match its peers': do not enter another one; the watchdogs (theirs and ours) end the job
+        if watchdog is not None:
+            time.sleep(args.leg_timeout + 5)
+        emit_and_leave(timed_out=True)
     if distributed:
         dist.barrier()
+        if watchdog is not None:
+            watchdog.cancel()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+    emit_and_leave()
 
 
 if __name__ == "__main__":

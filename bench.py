@@ -201,11 +201,13 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
     # units (fill value and the truncation of the TSDF->TSDF update = tdist / scale = 4 voxels), unlike the
     # reference's classes, which fill and truncate with the world-unit tdist
     sf = SlabFrame(K, scale, center, R, tdist / scale, node_pos, node_w, knn=4, pcg_iters=10, band=4.0)
-    for a in (0.0, 40.0, -40.0):
+    # config 3 (256^3): three views in front of the object; config 5 (--res 512): its 8-view orbit, 45 degrees apart
+    angles = (0.0, 40.0, -40.0) if R <= 256 else tuple(45.0 * v for v in range(8))
+    for a in angles:
         lw = scene.view_extrinsic(a)
         sf.integrate(torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda(), lw)
     sf.refresh_samples()
-    lws = [scene.view_extrinsic(a) for a in (0.0, 40.0, -40.0)]
+    lws = [scene.view_extrinsic(a) for a in angles]
     lw_cam = lws
     nframes = 8
     depths = []
@@ -248,8 +250,8 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
             "mesh_faces": info["faces"], "final_cost": cost,
             "exchange": "none" if world == 1 else "per frame: all-gather of the live volume (%.0f MB) + face-plane halo; per GN "
                                                   "iteration: one all-reduce of the normal equations" % (R ** 3 * 4 / 1e6),
-            "workload": "%d^3 grid in %d axis-0 slab(s), %d nodes: live TSDF (3 views) + %d GN iterations + DQB TSDF update + "
-                        "sample refresh%s, per frame" % (R, world, N, iters, " + marching cubes" if world == 1 else "")}
+            "workload": "%d^3 grid in %d axis-0 slab(s), %d nodes: live TSDF (%d views of %dx%d, one sweep) + %d GN iterations + DQB "
+                        "TSDF update + sample refresh%s, per frame" % (R, world, N, len(lws), W, H, iters, " + marching cubes" if world == 1 else "")}
 
 
 def pmc_traffic(kernel_substr, res):

@@ -69,6 +69,7 @@ constexpr int kBrZP = kBrZ / 4;                  // z-packs per row of a brick
 static_assert(kBrX * kBrY * kBrZP == 64, "a brick is one wave");
 constexpr int kPyrLevels = 5;                   // pyramid levels 1..5 (cells of 2..32 pixels)
 constexpr int kCullMargin = 1 << 10;            // 2^-10 px: corner projections are good to 2^-19 px, the reference's to 1e-12 px
+constexpr long kEarlyRowsMaxVoxels = 1L << 24;  // slabs up to 256^3 take the early-load row sweep (see integrate_depth_rows_early_kernel)
 constexpr long kTargetBlocks = 1L << 40;        // measured (profiles/kbench_r1.txt): one plane per block is
                                                 // fastest at 256^3 and 512^3; the plane loop stays as a knob
 
@@ -318,6 +319,42 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
             *reinterpret_cast<P *>(tsdf_w + off) = w;
         }
     }
+}
+
+// Row sweep for SMALL slabs (one rank's share of a strongly scaled 256^3 grid: a 5-20 us kernel).  Such a launch is bound by its
+// waves' chain of dependent memory round trips (gathers -> T/w -> store), not by bytes or VALU, so T/w of every pack that projects
+// into the image are requested together with the depth gathers: two round trips instead of three.  (On large grids the extra
+// fetches of packs that turn out not to be updated cost bandwidth: measured equal at 256^3, slower at 512^3 -- the plain kernel
+// stays there.)  Same arithmetic, same bits.
+template <typename DepthT, bool PINHOLE>
+__global__ __launch_bounds__(256) void integrate_depth_rows_early_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                          const DepthT *__restrict__ depth, const IntegrateParams p) {
+    int y, zp;
+    pack_coords(p, y, zp);
+    if (y >= p.Y) return;
+    const int z0 = zp * 4;
+    const int xl = blockIdx.y;
+    float ms[4];
+    bool upd[4];
+    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
+    using P = Pack<float, 4>;
+    P t, w;
+    bool loaded = false;
+    const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, depth, p.x0 + xl, y, z0, ms, upd, [&](bool any_inside) {
+        if (any_inside) {
+            t = *reinterpret_cast<const P *>(tsdf + off);
+            w = *reinterpret_cast<const P *>(tsdf_w + off);
+            loaded = true;
+        }
+    });
+    if (!any) return;
+    if (!loaded) {                                        // (cannot happen: any implies any_inside)
+        t = *reinterpret_cast<const P *>(tsdf + off);
+        w = *reinterpret_cast<const P *>(tsdf_w + off);
+    }
+    apply_pack<4>(t, w, ms, upd, p.wmax_f);
+    *reinterpret_cast<P *>(tsdf + off) = t;
+    *reinterpret_cast<P *>(tsdf_w + off) = w;
 }
 
 // Several depth views in ONE sweep of the volume (FusionDM.compute_live_tsdf / the initial fusion loop call fuseDepths
@@ -679,6 +716,13 @@ static int launch_integrate(void *tsdf, void *tsdf_w, const void *depth, Integra
                                        (float *)tsdf, (float *)tsdf_w, (const DepthT *)depth, p);
                 }
             }
+        } else if (VEC == 4 && p.planes_per_block == 1 && (long)p.nx * p.Y * p.Z <= kEarlyRowsMaxVoxels && !getenv("DFH_K1_LATE_LOADS")) {
+            if (pinhole)
+                hipLaunchKernelGGL((integrate_depth_rows_early_kernel<DepthT, true>), grid, block, 0, stream, (float *)tsdf, (float *)tsdf_w,
+                                   (const DepthT *)depth, p);
+            else
+                hipLaunchKernelGGL((integrate_depth_rows_early_kernel<DepthT, false>), grid, block, 0, stream, (float *)tsdf, (float *)tsdf_w,
+                                   (const DepthT *)depth, p);
         } else if (pinhole) {
             hipLaunchKernelGGL((integrate_depth_kernel<DepthT, VEC, true, false>), grid, block, 0, stream,
                                (float *)tsdf, (float *)tsdf_w, (const DepthT *)depth, p);

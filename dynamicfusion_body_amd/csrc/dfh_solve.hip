@@ -607,9 +607,19 @@ struct BuildParams {
 
 constexpr int kTile = 256;
 
-// scratch row of the planned build: {upper Gram triangle | J^T r | cost | count | live flag}, padded to whole 64-byte lines
-__host__ __device__ constexpr int gn_row_entries(int K) { return (6 * K) * (6 * K + 1) / 2 + 6 * K + 2; }
+// scratch row of the planned build: {Gram matrix of the row's 6K Jacobian columns as 6x6 sub-blocks (slot sa <= slot sb), each
+// stored WHOLE and row-major (36 contiguous doubles; the diagonal ones with both triangles) | J^T r | cost | count | live flag},
+// padded to whole 64-byte lines.  The gather reads one sub-block per list entry: 288 contiguous bytes instead of 36 values strewn
+// over a packed 24 x 24 triangle (6-12 cache lines) -- its traffic was 9x the live rows' size.
+__host__ __device__ constexpr int gn_nsub(int K) { return K * (K + 1) / 2; }
+__host__ __device__ constexpr int gn_sub(int K, int sa, int sb) { return sa * K - (sa * (sa - 1)) / 2 + (sb - sa); }   // sa <= sb
+__host__ __device__ constexpr int gn_row_gram(int K) { return 36 * gn_nsub(K); }
+__host__ __device__ constexpr int gn_row_entries(int K) { return gn_row_gram(K) + 6 * K + 2; }
 __host__ __device__ constexpr int gn_row_stride(int K) { return (gn_row_entries(K) + 1 + 7) / 8 * 8; }
+// element (ia, ib) of the Gram sub-block for tuple slots (sa, sb), any order, inside a scratch row
+__host__ __device__ constexpr int gn_gram_index(int K, int sa, int sb, int ia, int ib) {
+    return sa <= sb ? 36 * gn_sub(K, sa, sb) + 6 * ia + ib : 36 * gn_sub(K, sb, sa) + 6 * ib + ia;
+}
 
 // Residual and 6-DoF Jacobian rows of one data sample (formulas: oracle/gn_np.py
 // data_residual_jacobian).  J is written as k x 6 into Jrow (row-major), returns r.
@@ -843,8 +853,9 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         }
         __syncthreads();
     }
-    // entries: upper triangle of the NJ x NJ Gram matrix, then NJ entries of J^T r, then cost
-    constexpr int NUP = NJ * (NJ + 1) / 2;
+    // entries: PLANNED: the 6x6 sub-blocks (sa <= sb) of the Gram matrix in scratch-row order; else its upper triangle; then NJ
+    // entries of J^T r, then the cost
+    constexpr int NUP = PLANNED ? gn_row_gram(K) : NJ * (NJ + 1) / 2;
     if (PLANNED) {
         if (tid < n_runs) partial[(size_t)sRow[sRun[tid]] * ST_ + NUP + NJ + 1] = (double)(sRun[tid + 1] - sRun[tid]);
         // live flags of this tile's rows: 1 where a run has valid samples this iteration, 0 elsewhere (dead rows are
@@ -858,7 +869,12 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     }
     for (int e = tid; e < NUP + NJ + 1; e += 256) {
         int pa, pb;                              // Jacobian columns of this entry (pb == NJ: residual)
-        if (e < NUP) {
+        if (e < NUP && PLANNED) {
+            int sub = e / 36, sa = 0;
+            const int r36 = e - 36 * sub;
+            while (sub >= K - sa) { sub -= K - sa; ++sa; }          // sub-block (sa, sa + sub)
+            pa = 6 * sa + r36 / 6; pb = 6 * (sa + sub) + r36 % 6;   // (a diagonal sub-block's lower entries: same products, same order)
+        } else if (e < NUP) {
             int row = 0, rem = e;
             while (rem >= NJ - row) { rem -= NJ - row; ++row; }
             pa = row; pb = row + rem;
@@ -921,9 +937,7 @@ __device__ __forceinline__ double gather_block_list(const double *__restrict__ p
     const int ia = (lane % 36) / 6, ib = lane % 6;
     auto value = [&](int ent) {
         const int row = ent / (K * K), pr = ent - row * (K * K);
-        int pa = (pr / K) * 6 + ia, pb = (pr % K) * 6 + ib;
-        if (pa > pb) { const int t = pa; pa = pb; pb = t; }
-        return partial[(size_t)row * NE + (pa * NJ - (pa * (pa - 1)) / 2 + (pb - pa))];
+        return partial[(size_t)row * NE + gn_gram_index(K, pr / K, pr % K, ia, ib)];
     };
     // The walk is a chain of dependent loads (entry -> live flag -> values), so it is organised by hops, not by
     // entries: up to 256 entries and then their flags are fetched together (two hops), the live ones are compacted
@@ -968,11 +982,91 @@ __device__ __forceinline__ double gather_block_list(const double *__restrict__ p
     return acc;
 }
 
+// The data rows' list and the regulariser's list of one block walked TOGETHER: the walk is a chain of dependent hops (list
+// bounds -> entries -> live flags -> values) and doing the two lists one after the other doubles the chain (8 hops; the gather
+// is latency-bound: ~12 entries per block).  Here every hop is issued for both lists at once (4 hops).  Same sums, same order:
+// data entries in list order, then the regulariser's in list order, value = data sum + regulariser sum.  Regulariser lists
+// longer than 64 entries or data lists longer than 256 take the sequential walk (same result).
+template <int K>
+__device__ __forceinline__ double gather_block_both(const double *__restrict__ partial, const int *__restrict__ blk_ptr,
+                                                    const int *__restrict__ blk_ent, const double *__restrict__ rpartial,
+                                                    const int *__restrict__ rblk_ptr, const int *__restrict__ rblk_ent, int b, int lane,
+                                                    int wv) {
+    constexpr int NE = gn_row_stride(K), kLive = gn_row_entries(K);
+    constexpr int NE2 = gn_row_stride(2), kLive2 = gn_row_entries(2);
+    // hop 1
+    const int beg = blk_ptr[b], end = blk_ptr[b + 1];
+    const int rbeg = rblk_ptr[b], rend = rblk_ptr[b + 1];
+    if (end - beg > 256 || rend - rbeg > 64)
+        return gather_block_list<K>(partial, blk_ptr, blk_ent, b, lane, wv) + gather_block_list<2>(rpartial, rblk_ptr, rblk_ent, b, lane, wv);
+    const int ia = (lane % 36) / 6, ib = lane % 6;
+    __shared__ int sLiveD[4][256];
+    __shared__ int sLiveR[4][64];
+    // hop 2: entries
+    int ent[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ent[u] = beg + 64 * u + lane < end ? blk_ent[beg + 64 * u + lane] : -1;
+    const int rent = rbeg + lane < rend ? rblk_ent[rbeg + lane] : -1;
+    // hop 3: live flags
+    bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) on[u] = ent[u] >= 0 && partial[(size_t)(ent[u] / (K * K)) * NE + kLive] != 0.0;
+    const bool ron = rent >= 0 && rpartial[(size_t)(rent / 4) * NE2 + kLive2] != 0.0;
+    int nl = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned long long m = __ballot(on[u]);
+        if (on[u]) sLiveD[wv][nl + __popcll(m & ((1ull << lane) - 1ull))] = ent[u];
+        nl += __popcll(m);
+    }
+    const unsigned long long rm = __ballot(ron);
+    if (ron) sLiveR[wv][__popcll(rm & ((1ull << lane) - 1ull))] = rent;
+    const int rnl = __popcll(rm);
+    __builtin_amdgcn_wave_barrier();
+    double acc = 0.0, racc = 0.0;
+    if (lane < 36) {
+        auto value = [&](int e) {
+            const int row = e / (K * K), pr = e - row * (K * K);
+            return partial[(size_t)row * NE + gn_gram_index(K, pr / K, pr % K, ia, ib)];
+        };
+        auto rvalue = [&](int e) {
+            const int row = e / 4, pr = e - row * 4;
+            return rpartial[(size_t)row * NE2 + gn_gram_index(2, pr / 2, pr % 2, ia, ib)];
+        };
+        // hop 4: values of both lists in flight together (regulariser: at most 4 per batch; usually 1-2 entries)
+        double rv[4];
+        const int r0 = rnl < 4 ? rnl : 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rv[u] = u < r0 ? rvalue(sLiveR[wv][u]) : 0.0;
+        int q = 0;
+        for (; q + 15 < nl; q += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = value(sLiveD[wv][q + u]);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; q + 3 < nl; q += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = value(sLiveD[wv][q + u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
+        for (; q < nl; ++q) acc += value(sLiveD[wv][q]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (u < r0) racc += rv[u];
+        for (int u = 4; u < rnl; ++u) racc += rvalue(sLiveR[wv][u]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return acc + racc;
+}
+
 // one wave: J^T r of node a from its list; the total for unknown i ends up in lanes 0..5
 template <int K>
 __device__ __forceinline__ double gather_node_list(const double *__restrict__ partial, const int *__restrict__ node_ptr,
                                                    const int *__restrict__ node_ent, int a, int lane, int wv) {
-    constexpr int NJ = 6 * K, NUP = NJ * (NJ + 1) / 2, NE = gn_row_stride(K), kLive = gn_row_entries(K);
+    constexpr int NUP = gn_row_gram(K), NE = gn_row_stride(K), kLive = gn_row_entries(K);
     double acc = 0.0;
     const int j = lane / 6, i = lane - 6 * j;                  // lanes 60..63 idle
     __shared__ int sLive[4][64];
@@ -1051,8 +1145,9 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
     if ((int)blockIdx.x < nbw) {
         const int b = (int)blockIdx.x * 4 + wv;
         if (b >= n_blocks) return;
-        double acc = gather_block_list<K>(partial, blk_ptr, blk_ent, b, lane, wv);
-        if (rl.partial) acc = acc + gather_block_list<2>(rl.partial, rl.blk_ptr, rl.blk_ent, b, lane, wv);
+        double acc;
+        if (rl.partial) acc = gather_block_both<K>(partial, blk_ptr, blk_ent, rl.partial, rl.blk_ptr, rl.blk_ent, b, lane, wv);
+        else acc = gather_block_list<K>(partial, blk_ptr, blk_ent, b, lane, wv);
         if (lane < 36) {
             double *dst = vals + 36 * (size_t)b + lane;
             *dst = accumulate ? *dst + acc : acc;
@@ -1068,7 +1163,7 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
         gather_cost(cc, n_cc, cc_stride, red, c0, c1);
         if (rl.partial) {
             double r0, r1;
-            gather_cost(rl.partial + 90, rl.n_rows, gn_row_stride(2), red, r0, r1);
+            gather_cost(rl.partial + gn_row_gram(2) + 12, rl.n_rows, gn_row_stride(2), red, r0, r1);
             c0 = c0 + r0; c1 = c1 + r1;
         }
         if (threadIdx.x == 0) {
@@ -1087,8 +1182,8 @@ __device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N,
                              double *__restrict__ rhs, double *__restrict__ cost_count, double *__restrict__ partial_reg) {
     // partial_reg != NULL (planned build): the pair's {upper triangle of the 12x12 Gram matrix of [J_i | J_j] |
     // J^T rho | 0.5 rho^2 | 0} is STORED in row t (92 doubles) and gathered like a 2-node data row: no atomics.
-    constexpr int NE2 = gn_row_stride(2), kLive2 = gn_row_entries(2);      // 96-double rows, live flag at [92]
-    auto up = [](int pa, int pb) { return pa * 12 - (pa * (pa - 1)) / 2 + (pb - pa); };
+    // rows of the K = 2 layout: sub-blocks (i,i) (i,j) (j,j) | J^T rho (12) | cost | count | live flag
+    constexpr int NE2 = gn_row_stride(2), kLive2 = gn_row_entries(2), kJtr2 = gn_row_gram(2), kCost2 = gn_row_gram(2) + 12;
     const int t = block * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= N * k) return;
@@ -1097,8 +1192,8 @@ __device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N,
     if (i == j) {                                                  // zero rows, zero Jacobian
         if (partial_reg && lane == 0) {                           // dead row (its cost / count are read unconditionally)
             partial_reg[(size_t)t * NE2 + kLive2] = 0.0;
-            partial_reg[(size_t)t * NE2 + 90] = 0.0;
-            partial_reg[(size_t)t * NE2 + 91] = 0.0;
+            partial_reg[(size_t)t * NE2 + kCost2] = 0.0;
+            partial_reg[(size_t)t * NE2 + kCost2 + 1] = 0.0;
         }
         return;
     }
@@ -1129,15 +1224,16 @@ __device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N,
         const double vji = (ja[0] * ib[0] + ja[1] * ib[1]) + ja[2] * ib[2];
         if (partial_reg) {
             double *P = partial_reg + (size_t)t * NE2;
-            if (a <= b) { P[up(a, b)] = vii; P[up(6 + a, 6 + b)] = vjj; }
-            P[up(a, 6 + b)] = vij;                                 // (G[6+a][b] is lane (b,a)'s vij)
+            P[gn_gram_index(2, 0, 0, a, b)] = vii;                 // (whole 6x6 sub-blocks: lane (b,a) computes the same products)
+            P[gn_gram_index(2, 1, 1, a, b)] = vjj;
+            P[gn_gram_index(2, 0, 1, a, b)] = vij;
             if (lane < 6) {
                 double gi[3], gj[3];
                 Jcol(yi, 1.0, si, lane, gi); Jcol(yj, -1.0, sj, lane, gj);
-                P[78 + lane] = (gi[0] * rho[0] + gi[1] * rho[1]) + gi[2] * rho[2];
-                P[84 + lane] = (gj[0] * rho[0] + gj[1] * rho[1]) + gj[2] * rho[2];
+                P[kJtr2 + lane] = (gi[0] * rho[0] + gi[1] * rho[1]) + gi[2] * rho[2];
+                P[kJtr2 + 6 + lane] = (gj[0] * rho[0] + gj[1] * rho[1]) + gj[2] * rho[2];
             }
-            if (lane == 0) { P[90] = 0.5 * ((rho[0] * rho[0] + rho[1] * rho[1]) + rho[2] * rho[2]); P[91] = 0.0; P[kLive2] = 1.0; }
+            if (lane == 0) { P[kCost2] = 0.5 * ((rho[0] * rho[0] + rho[1] * rho[1]) + rho[2] * rho[2]); P[kCost2 + 1] = 0.0; P[kLive2] = 1.0; }
             return;
         }
         const int bii = find_block(row_ptr, col, i, i), bjj = find_block(row_ptr, col, j, j);
@@ -1915,7 +2011,7 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
         if (planned_reg && !reg_in_gather) {
             dim3 grid((unsigned)((n_blocks + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
             hipLaunchKernelGGL(gn_gather_kernel<2>, grid, block, 0, s, partial_reg, n, rblk_ptr, rblk_ent, n_blocks, rnode_ptr,
-                               rnode_ent, n_nodes, vals, rhs, cost_count, partial_reg + 90, n, gn_row_stride(2), true, dbg_part,
+                               rnode_ent, n_nodes, vals, rhs, cost_count, partial_reg + gn_row_gram(2) + 12, n, gn_row_stride(2), true, dbg_part,
                                RegLists{});
         }
         DFH_HIP_CHECK(hipGetLastError());

@@ -216,6 +216,11 @@ class FusionDM:
         verts, faces, normals, values = _mesh.marching_cubes(self._T, 0.0, 1, as_numpy=True)
         _mesh.write_obj(os.path.join(path, filename), verts, faces, normals, ind=self._IND)
 
+    def write_warp_field(self, path, filename):
+        """Reference core/fusion_dm.py:334-336: pickle of `_nodes` into <path>/<filename>__<itercounter>.p."""
+        from . import io as _io
+        return _io.write_warp_field(self._nodes, path, filename, self._itercounter)
+
     def write_live_frame_mesh(self, path, filename, warpfield_path):
         """Reference core/fusion_dm.py:357-358: an empty stub there too."""
         pass
@@ -322,7 +327,8 @@ class FusionDM:
                     self._depthidx = idx
                     self.fuseDepths(dev[idx], lws[idx], T, Wt, scale=12 * std / res, center=avg)
             self._T, self._Wt = T, Wt
-        if outputMesh:                                              # :174-176 (the reference also dumps tsdf_temp.npy; not done)
+        if outputMesh:                                              # :174-176
+            np.save(os.path.join(mesh_path, 'tsdf_temp'), self._T.cpu().numpy())     # the reference's `np.save('tsdf_temp', self._tsdf)` (:175), in mesh_path
             self.write_canonical_mesh(mesh_path, 'test.obj')
         if as_numpy:
             return (self._tsdf, self._tsdfw)

@@ -151,6 +151,31 @@ def test_fusion_dm_methods(tmp_path):
     assert np.abs(N - w[2].astype(np.float64) * 0.5).max() < 1e-6
     lines = open(os.path.join(str(tmp_path), "canon.obj")).read().splitlines()
     assert lines[0].startswith("v ") and lines[len(V)].startswith("vn ") and "//" in lines[-1]
+    # write_warp_field (core/fusion_dm.py:334-336): pickle of `_nodes`, <name>__<itercounter>.p
+    import pickle
+    fu._nodes = [(3, np.array([1.0, 2, 3]), np.arange(8.0), 6.2)]
+    fu._itercounter = 4
+    fn = fu.write_warp_field(str(tmp_path), "wf")
+    assert os.path.basename(fn) == "wf__4.p"
+    back = pickle.load(open(fn, "rb"))
+    assert back[0][0] == 3 and np.array_equal(back[0][2], np.arange(8.0))
+
+
+def test_compute_live_tsdf_output_mesh_writes_the_reference_files(tmp_path):
+    """compute_live_tsdf(outputMesh=True) (core/fusion_dm.py:174-176): `tsdf_temp.npy` and `test.obj`."""
+    R = 32
+    H, W_, fx, cx, cy = scene.CAMERAS["C1"]
+    K = scene.intrinsics(fx, cx, cy)
+    f = FusionDM(0.6, K, tsdf_res=R)
+    avg = np.array([-0.03, -0.43, -5.6], dtype='float32')
+    c = avg.astype(np.float64)
+    lws = [scene.view_extrinsic(a, centre=c) for a in (0.0, 30.0)]
+    dms = [scene.render_depth(K, lw, H, W_, invalid_frac=0.0, sphere_c=c, sphere_r=2.0, wall_z=None) for lw in lws]
+    T, Wt = f.compute_live_tsdf(dms, lws, outputMesh=True, mesh_path=str(tmp_path))
+    saved = np.load(os.path.join(str(tmp_path), "tsdf_temp.npy"))
+    assert saved.shape == (R, R, R) and np.array_equal(saved.astype(np.float64), np.asarray(T, dtype=np.float64))
+    V, F, N = mesh.read_obj(os.path.join(str(tmp_path), "test.obj"))
+    assert len(V) > 100 and len(F) > 100
 
 
 def test_fusion_initial_graph():

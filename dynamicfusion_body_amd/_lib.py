@@ -28,6 +28,8 @@ _SIGNATURES = {
     "dfh_integrate_workspace_bytes": (ctypes.c_size_t, [_int, _int, _int, _c_int_p, _int, _int]),
     "dfh_integrate_depth": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _int, _vp, _int, _int, _int,
                                    _c_double_p, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, ctypes.c_size_t, _vp]),
+    "dfh_integrate_depth_ocl": (_int, [_vp, _vp, _c_int_p, _int, _int, _vp, _int, _int, ctypes.POINTER(ctypes.c_float),
+                                       ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.c_float, _vp]),
     "dfh_integrate_multi_workspace_bytes": (ctypes.c_size_t, [_int]),
     "dfh_integrate_depth_multi": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _int, _int, ctypes.POINTER(ctypes.c_void_p), _int, _int,
                                          _int, _c_double_p, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp,

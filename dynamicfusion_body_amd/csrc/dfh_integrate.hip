@@ -649,6 +649,52 @@ static size_t pyramid_floats(int H, int W, int *off, int *pw, int *ph) {
     return (tot + 3) / 4 * 4;                             // whole 16-byte units
 }
 
+// A2 (optional): the arithmetic of the reference's OpenCL kernel `fuse_depth` (core/fusion_dm.py:630-674), which is NOT the CPU
+// path's: one float32 3x4 map index -> pixel (proj = K lw IND, :695), bilinear depth (:605-622), pixels with no or near depth carve
+// free space (dz = -TDIST, :652-653), dz = voxel depth - measured depth (sign opposite to fuseDepths, :655-658), update iff
+// dz < TDIST with w <- min(1 + w, WMAX), T <- ((w' - 1) T + max(-TDIST, dz)) / w' (:667-672).  Every operation in float32 in the
+// kernel text's order (no contraction).  One voxel per lane, lanes along z.
+struct OclParams {
+    float proj[12], kinv2[3], tdist, wmax;
+    int X, Y, Z, x0, nx, H, W;
+};
+
+__global__ __launch_bounds__(256) void integrate_depth_ocl_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                   const float *__restrict__ depth, const OclParams p) {
+    const long lin = (long)blockIdx.x * 256 + threadIdx.x;
+    if (lin >= (long)p.nx * p.Y * p.Z) return;
+    const int z = (int)(lin % p.Z), y = (int)((lin / p.Z) % p.Y), xl = (int)(lin / ((long)p.Z * p.Y));
+    const float xf = (float)(p.x0 + xl), yf = (float)y, zf = (float)z;
+    const float u = ((p.proj[0] * xf + p.proj[1] * yf) + p.proj[2] * zf) + p.proj[3];       // :640-642
+    const float v = ((p.proj[4] * xf + p.proj[5] * yf) + p.proj[6] * zf) + p.proj[7];
+    const float w = ((p.proj[8] * xf + p.proj[9] * yf) + p.proj[10] * zf) + p.proj[11];
+    float px = u / w, py = v / w;                                                           // :645-646
+    // :647 `if (px < 0 || py < 0 || px >= DM_X - 1 || py >= DM_Y - 1) return;` -- a NaN (w == 0) passes that test in the reference
+    // and then indexes with an undefined int; here it is skipped
+    if (!(px >= 0.0f && py >= 0.0f && px < (float)(p.W - 1) && py < (float)(p.H - 1))) return;
+    const int ix = (int)floorf(px), iy = (int)floorf(py);                                   // :607-608
+    const float wx = px - (float)ix, wy = py - (float)iy;
+    const int lu = iy * p.W + ix, lb = (iy + 1) * p.W + ix;
+    const float up = depth[lu] * (1.0f - wx) + depth[lu + 1] * wx;                          // :617-619
+    const float bot = depth[lb] * (1.0f - wx) + depth[lb + 1] * wx;
+    const float pz = -(up * (1.0f - wy) + bot * wy);                                        // :649
+    float dz;
+    if (pz <= p.tdist) {
+        dz = -p.tdist;                                                                      // :652-653
+    } else {
+        px *= pz; py *= pz;
+        dz = (p.kinv2[0] * (px - u) + p.kinv2[1] * (py - v)) + p.kinv2[2] * (pz - w);       // :657
+        dz = -dz;
+    }
+    if (dz < p.tdist) {                                                                     // :667
+        const long off = lin;
+        const float old = tsdf[off];
+        const float nw = fminf(1.0f + tsdf_w[off], p.wmax);
+        tsdf[off] = ((nw - 1.0f) * old + 1.0f * fmaxf(-p.tdist, dz)) / nw;                  // :671
+        tsdf_w[off] = nw;
+    }
+}
+
 // Any volume dtype: the reference's chain evaluated exactly for every voxel.
 template <typename VolT, typename DepthT, int VEC, bool PINHOLE>
 __global__ __launch_bounds__(256) void integrate_depth_exact_kernel(VolT *__restrict__ tsdf,
@@ -1005,6 +1051,26 @@ extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype
         else { if (pinhole) DFH_MULTI(double, 1, true); else DFH_MULTI(double, 1, false); }
     }
 #undef DFH_MULTI
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+extern "C" int dfh_integrate_depth_ocl(float *tsdf, float *tsdf_w, const int res[3], int x0, int x1, const float *depth, int H, int W,
+                                       const float proj[12], const float kinv_row2[3], float tdist, float wmax, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(tsdf && tsdf_w && res && depth && proj && kinv_row2, "dfh_integrate_depth_ocl: null pointer");
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0, "dfh_integrate_depth_ocl: bad grid %dx%dx%d", res[0], res[1], res[2]);
+    DFH_REQUIRE(0 <= x0 && x0 <= x1 && x1 <= res[0], "dfh_integrate_depth_ocl: slab [%d,%d) outside [0,%d)", x0, x1, res[0]);
+    DFH_REQUIRE(H >= 2 && W >= 2 && (long)H * W < (1L << 31), "dfh_integrate_depth_ocl: bad depth map size %dx%d", H, W);
+    if (x1 == x0) return DFH_OK;
+    OclParams p;
+    for (int i = 0; i < 12; ++i) p.proj[i] = proj[i];
+    for (int i = 0; i < 3; ++i) p.kinv2[i] = kinv_row2[i];
+    p.tdist = tdist; p.wmax = wmax;
+    p.X = res[0]; p.Y = res[1]; p.Z = res[2]; p.x0 = x0; p.nx = x1 - x0; p.H = H; p.W = W;
+    const long n = (long)p.nx * p.Y * p.Z;
+    DFH_REQUIRE((n + 255) / 256 < (1L << 31), "dfh_integrate_depth_ocl: slab too large");
+    hipLaunchKernelGGL(integrate_depth_ocl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tsdf, tsdf_w, depth, p);
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }

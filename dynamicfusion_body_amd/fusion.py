@@ -461,3 +461,19 @@ class Fusion:
     def write_warp_field(self, path, filename):
         """Reference core/fusion.py:571-573."""
         return _io.write_warp_field(self._nodes, path, filename, self._itercounter)
+
+
+# The reference's FusionDM carries a second copy of the non-rigid methods ("functions below not useful for now",
+# core/fusion_dm.py:366-560): computeSparsity, computef, warp, dq_blend, construct_graph, update_graph -- the same statements as
+# Fusion's up to white space.  FusionDM here gets the same methods (and the helpers they call) from Fusion, so the call surface
+# is complete; like in the reference they need `_nodes`, `_vertices`, `_normals`, `_neighbor_look_up`, `_radius` and one
+# correspondence per vertex to be set by the caller.
+def _lend_nonrigid_methods():
+    from .fusion_dm import FusionDM
+    for name in ("node_arrays", "_gather_nodes", "_locations", "dq_blend", "_dqb_warp", "warp", "_vertex_state", "computef",
+                 "computeSparsity", "construct_graph", "_dq_blend_kdtree", "update_graph"):
+        if name not in FusionDM.__dict__:
+            setattr(FusionDM, name, Fusion.__dict__[name])
+
+
+_lend_nonrigid_methods()

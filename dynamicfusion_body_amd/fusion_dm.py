@@ -118,12 +118,45 @@ class FusionDM:
         # float32 on device unless that would change a value (then masks could flip)
         return to_device(dm, dtype=torch.float32 if f32_exact(dm) else torch.float64)
 
-    def fuseDepths(self, dm, lw, tsdf, tsdf_w, scale=1.0, center=np.zeros(3), wmax=100.0):
+    def fuseDepths_ocl(self, dm, lw, tsdf, tsdf_w, wmax=100.0):
+        """The reference's OTHER fuseDepths: FusionDM_GPU's OpenCL kernel (core/fusion_dm.py:600-737), whose arithmetic differs
+        from the CPU path (float32 throughout, bilinear depth, index -> pixel through `_IND`, pixels
+        without depth carve free space, opposite sign, no `scale`).  Like the reference's host code it leaves its inputs alone
+        and returns NEW float32 arrays (:690-691,:737); CUDA tensors in, CUDA tensors out."""
+        lw = np.asarray(lw, dtype=np.float64)
+        if lw.shape != (3, 4):
+            raise ValueError('lw must be a 3x4 camera extrinsic')
+        if _is_tensor(tsdf) != _is_tensor(tsdf_w):
+            raise ValueError('tsdf and tsdf_w must both be numpy arrays or both CUDA tensors')
+        proj = np.matmul(self._K, np.matmul(lw, self._IND)).astype(np.float32)             # :695
+        kinv = self._Kinv.astype(np.float32)                                                # :697
+        tdist_lit = np.float32(float("%f" % self._tdist))                                   # "#define TDIST %ff" (:682-687)
+        wmax_lit = np.float32(float("%f" % wmax))
+        depth = to_device(dm if _is_tensor(dm) else np.asarray(dm), dtype=torch.float32)    # dm.astype(np.float32), :698
+        if depth.dim() != 2:
+            raise ValueError('depth map must be 2-D')
+        if _is_tensor(tsdf):
+            T, Wt = tsdf.to(dtype=torch.float32).clone().contiguous(), tsdf_w.to(dtype=torch.float32).clone().contiguous()
+        else:
+            if tsdf.ndim != 3 or tsdf.shape != tsdf_w.shape:
+                raise ValueError('tsdf and tsdf_w must be 3-D arrays of the same shape')
+            T, Wt = to_device(tsdf.astype(np.float32)), to_device(tsdf_w.astype(np.float32))   # :690-691
+        kernels.integrate_depth_ocl(T, Wt, depth, proj, kinv[2], tdist_lit, wmax_lit)
+        if _is_tensor(tsdf):
+            return (T, Wt)
+        return (T.cpu().numpy(), Wt.cpu().numpy())
+
+    def fuseDepths(self, dm, lw, tsdf, tsdf_w, scale=1.0, center=np.zeros(3), wmax=100.0, mode="cpu"):
         """Integrate one depth map into (tsdf, tsdf_w); reference core/fusion_dm.py:180-217.
 
         numpy volumes are updated in place AND returned (the reference mutates through
         np.nditer and returns the same arrays, :186,:217); CUDA tensors are updated in place
-        with no host traffic."""
+        with no host traffic.  mode="ocl": the arithmetic of the reference's OpenCL override instead
+        (fuseDepths_ocl: new float32 arrays, `scale` / `center` unused as there)."""
+        if mode == "ocl":
+            return self.fuseDepths_ocl(dm, lw, tsdf, tsdf_w, wmax)
+        if mode != "cpu":
+            raise ValueError('mode must be "cpu" (FusionDM.fuseDepths semantics) or "ocl" (FusionDM_GPU.fuseDepths semantics)')
         lw = np.asarray(lw, dtype=np.float64)
         if lw.shape != (3, 4):
             raise ValueError('lw must be a 3x4 camera extrinsic')

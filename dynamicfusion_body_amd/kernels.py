@@ -82,6 +82,31 @@ def integrate_depth(T, Wt, depth, K, Kinv, lw, scale, center, tdist, wmax=100.0,
     return T, Wt
 
 
+def integrate_depth_ocl(T, Wt, depth, proj, kinv_row2, tdist, wmax=100.0, res=None, x_range=None):
+    """A2: the arithmetic of the reference's OpenCL kernel (core/fusion_dm.py:630-674; dfh_integrate_depth_ocl) on float32
+    device volumes, in place.  proj: float32 3x4 index -> pixel map (K lw IND, :695); kinv_row2: third row of K^-1 (float32)."""
+    require_gpu()
+    lib = _lib.load()
+    if res is None:
+        res = tuple(T.shape)
+    if x_range is None:
+        x_range = (0, res[0])
+    _check_volume_pair(T, Wt, res, x_range)
+    if T.dtype != torch.float32:
+        raise ValueError("the OpenCL arithmetic is float32: volumes must be float32")
+    if not (isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dim() == 2 and depth.is_contiguous() and depth.dtype == torch.float32):
+        raise ValueError("depth must be a contiguous 2-D float32 CUDA tensor")
+    if x_range[1] == x_range[0]:
+        return T, Wt
+    pr = (ctypes.c_float * 12)(*np.asarray(proj, dtype=np.float32).reshape(12).tolist())
+    kr = (ctypes.c_float * 3)(*np.asarray(kinv_row2, dtype=np.float32).reshape(3).tolist())
+    H, W = depth.shape
+    _lib.check(lib.dfh_integrate_depth_ocl(T.data_ptr(), Wt.data_ptr(), _lib.iarr(res), int(x_range[0]), int(x_range[1]), depth.data_ptr(),
+                                           int(H), int(W), pr, kr, ctypes.c_float(float(tdist)), ctypes.c_float(float(wmax)),
+                                           current_stream_ptr()), "dfh_integrate_depth_ocl")
+    return T, Wt
+
+
 def integrate_depth_views(T, Wt, depths, K, Kinv, lws, scale, center, tdist, wmax=100.0, tsdf_res=None, res=None,
                           x_range=None, workspace=None):
     """Several views in one sweep of the volume (dfh_integrate_depth_multi): same result, bit for bit, as

@@ -91,6 +91,16 @@ int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype, const int
                               const double center[3], double tdist, double wmax, void *workspace,
                               size_t workspace_bytes, void *stream);
 
+/* A2 (optional)  the arithmetic of the reference's OpenCL kernel `fuse_depth`  core/fusion_dm.py:630-674 -- NOT that of the CPU
+ * path above: index -> pixel through one float32 3x4 map proj = K lw IND (:640-646,:695), bilinear depth (:605-622), pixels without
+ * or with near depth (pz <= tdist) carve free space (dz = -tdist, :652-653), dz = voxel depth - measured depth (:655-658), update
+ * iff dz < tdist: w' = min(1 + w, wmax), T <- ((w' - 1) T + max(-tdist, dz)) / w', w <- w' (:667-672).  All float32, in the kernel
+ * text's operation order, no contraction.  tsdf / tsdf_w: float32 planes [x0,x1), updated in place (the reference's host code
+ * copies its inputs first, :690-691); depth float32 H x W; tdist / wmax as the float literals the reference bakes in ("%ff" of
+ * the Python values, :682-687).  A pixel coordinate that is NaN (w == 0) is skipped (undefined in the reference). */
+int dfh_integrate_depth_ocl(float *tsdf, float *tsdf_w, const int res[3], int x0, int x1, const float *depth, int H, int W,
+                            const float proj[12], const float kinv_row2[3], float tdist, float wmax, void *stream);
+
 /* A3  FusionDM.updateTSDF(curr_tsdf, wmax)                     core/fusion_dm.py:300-316
  * For every canonical voxel i, x in [x0,x1):
  *   q = dqb_warp(lw_dq, float32(i))          (core/util.py:68-72; lw_dq = `_lw`, 8 doubles, voxel-index

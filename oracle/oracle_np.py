@@ -470,3 +470,43 @@ def closest_correspondences(warped_pos, warped_nrm, live_verts, k, tolerance):
         best_cost = np.where(better, cost[:, j], best_cost)
         best = np.where(better[:, None], P[:, j, :], best)
     return best, best_cost, best_cost <= tolerance
+
+
+# ------------------------------------------------------------------------------------------------ A2 (optional)
+def fuse_depths_ocl(dm, lw, K, Kinv, IND, tsdf, tsdf_w, tdist, wmax=100.0):
+    """The reference's OpenCL kernel `fuse_depth` and its host code (core/fusion_dm.py:600-703) in numpy float32, operation by
+    operation in the kernel text's order.  PARITY UNPINNED: no OpenCL device or pyopencl here to run the reference's kernel, and
+    OpenCL C may contract a*b+c; this is the uncontracted IEEE-float32 reading of the text.  Returns new float32 arrays."""
+    f32 = np.float32
+    H, W = dm.shape
+    T = np.asarray(tsdf).astype(f32).copy(); Wt = np.asarray(tsdf_w).astype(f32).copy()              # :690-691
+    proj = np.matmul(K, np.matmul(lw, IND)).astype(f32)                                               # :695
+    k2 = np.asarray(Kinv).astype(f32)[2]
+    depth = np.asarray(dm).astype(f32).reshape(-1)
+    TD, WM = f32(float("%f" % tdist)), f32(float("%f" % wmax))                                        # :682-687
+    X, Y, Z = T.shape
+    x, y, z = [a.astype(f32) for a in np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij")]
+    with np.errstate(all="ignore"):
+        u = ((proj[0, 0] * x + proj[0, 1] * y) + proj[0, 2] * z) + proj[0, 3]                         # :640-642
+        v = ((proj[1, 0] * x + proj[1, 1] * y) + proj[1, 2] * z) + proj[1, 3]
+        w = ((proj[2, 0] * x + proj[2, 1] * y) + proj[2, 2] * z) + proj[2, 3]
+        px = u / w; py = v / w                                                                        # :645-646
+        vis = (px >= 0) & (py >= 0) & (px < f32(W - 1)) & (py < f32(H - 1))                           # :647 (NaN: skipped, see the kernel)
+        pxs, pys = np.where(vis, px, f32(0)), np.where(vis, py, f32(0))
+        ix = np.floor(pxs).astype(np.int64); iy = np.floor(pys).astype(np.int64)                      # :607-608
+        wx = pxs - ix.astype(f32); wy = pys - iy.astype(f32)
+        lu = iy * W + ix; lb = (iy + 1) * W + ix
+        one = f32(1)
+        up = depth[lu] * (one - wx) + depth[lu + 1] * wx                                              # :617-619
+        bot = depth[lb] * (one - wx) + depth[lb + 1] * wx
+        pz = -(up * (one - wy) + bot * wy)                                                            # :649
+        near = pz <= TD
+        pxz, pyz = pxs * pz, pys * pz                                                                 # :655-656
+        dz = -((k2[0] * (pxz - u) + k2[1] * (pyz - v)) + k2[2] * (pz - w))                            # :657-658
+        dz = np.where(near, -TD, dz).astype(f32)                                                      # :652-653
+        upd = vis & (dz < TD)                                                                         # :667
+        nw = np.minimum(one + Wt, WM)                                                                 # :670
+        newT = ((nw - one) * T + one * np.maximum(-TD, dz)) / nw                                      # :671
+    T = np.where(upd, newT, T).astype(f32)
+    Wt = np.where(upd, nw, Wt).astype(f32)
+    return T, Wt

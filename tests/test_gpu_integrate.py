@@ -416,3 +416,44 @@ def test_brick_culling_never_changes_a_voxel(k1_path, monkeypatch):
         assert outs["bricks"][2] == outs["rows"][2]
         assert 0 < int((outs["rows"][1] > 0).sum()) < outs["rows"][1].numel()
     monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
+
+
+def test_ocl_mode_matches_the_float32_restatement(k1_path):
+    """A2 (optional): FusionDM.fuseDepths(mode="ocl") = the arithmetic of the reference's OpenCL kernel (core/fusion_dm.py:600-737),
+    against oracle_np.fuse_depths_ocl, the operation-by-operation float32 reading of that kernel text: bit-exact (same IEEE
+    operations in the same order).  PARITY UNPINNED against the reference itself -- no OpenCL device or pyopencl here to run it.
+    Also: inputs are left alone and new float32 arrays come back (the reference's host code, :690-691,:737), and the result
+    differs from the CPU-path semantics (free-space carving, bilinear depth)."""
+    if k1_path == "rows":
+        pytest.skip("one kernel, no sweep variants")
+    R = 40
+    H, W_, fx, cx, cy = scene.CAMERAS["C1"]
+    K = scene.intrinsics(fx, cx, cy)
+    scale, center, tdist = scene.grid_params(R)
+    f = FusionDM(tdist, K, tsdf_res=R)
+    f._IND = np.eye(4)
+    f._IND[:3, :3] *= scale
+    f._IND[:3, 3] = center - scale * R / 2                              # index -> world, what compute_live_tsdf installs
+    T = np.zeros((R, R, R)) + tdist
+    Wt = np.zeros((R, R, R))
+    To, Wo = T.copy(), Wt.copy()
+    for i, a in enumerate((0.0, 35.0, -50.0)):
+        lw = scene.view_extrinsic(a)
+        dm = scene.render_depth(K, lw, H, W_, invalid_frac=0.05, seed=i)
+        T_in, W_in = T.copy(), Wt.copy()
+        T2, W2 = f.fuseDepths(dm, lw, T, Wt, wmax=2.0, mode="ocl")
+        assert np.array_equal(T, T_in) and np.array_equal(Wt, W_in)     # inputs untouched
+        assert T2.dtype == np.float32 and W2.dtype == np.float32
+        To, Wo = O.fuse_depths_ocl(dm, lw, K, np.linalg.inv(K), f._IND, To, Wo, tdist, wmax=2.0)
+        assert np.array_equal(W2, Wo) and np.array_equal(T2, To), "view %d" % i
+        T, Wt = T2, W2
+    assert 0.3 < (Wo > 0).mean() < 1.0 and Wo.max() == 2.0 and (To < 0).any() and (To == np.float32(-tdist)).any()
+    # CUDA tensors in, CUDA tensors out
+    lw = scene.view_extrinsic(10.0)
+    dm = scene.render_depth(K, lw, H, W_, dtype=np.float32)
+    Td, Wd = torch.from_numpy(To).cuda(), torch.from_numpy(Wo).cuda()
+    T3, W3 = f.fuseDepths(torch.from_numpy(dm).cuda(), lw, Td, Wd, mode="ocl")
+    T3o, W3o = O.fuse_depths_ocl(dm, lw, K, np.linalg.inv(K), f._IND, To, Wo, tdist)
+    assert torch.equal(Td.cpu(), torch.from_numpy(To)) and np.array_equal(T3.cpu().numpy(), T3o) and np.array_equal(W3.cpu().numpy(), W3o)
+    with pytest.raises(ValueError):
+        f.fuseDepths(dm, lw, To, Wo, mode="opencl")

@@ -512,6 +512,30 @@ def test_class_surface_matches_reference(golden):
     fd.solve(None)
     assert np.abs(O.DQTSE3(fd._lw) - O.DQTSE3(x_true)).max() < 1e-3
     assert fd.last_costs[-1][-1] < 1e-8
+    # FusionDM's second copy of the non-rigid methods (core/fusion_dm.py:369-560: the same statements as Fusion's)
+    fd2 = FusionDM(1.0, np.eye(3), tsdf_res=4, knn=nbr.shape[1], write_warpfield=False)
+    fd2._nodes = [(int(vidx[i]), npos[i], ndq[i], float(nw[i])) for i in range(len(npos))]
+    fd2._vertices, fd2._normals, fd2._correspondences = verts, norms, corr
+    fd2._neighbor_look_up = [row for row in nbr]
+    fd2._lw = lw
+    f2 = fd2.computef(ndq.flatten(), 0.2, 0.001, rw)
+    assert np.abs(f2 - g["computef_out"]).max() <= 1e-12
+    S = fd2.computeSparsity(len(f2), 8 * len(npos))
+    assert S.shape == (len(f2), 8 * len(npos)) and S[0, 8 * int(nbr[0][0])] == 1
+    for i in range(3):
+        p_, n_ = g4["warp_P"][i], g4["warp_N"][i]
+        fd3 = FusionDM(1.0, np.eye(3), tsdf_res=4, knn=int(g4["knn"]))
+        fd3._nodes = fu2._nodes
+        loc = g4["warp_loc"][i]
+        dqs = [fu2._nodes[j][2] for j in loc]
+        assert np.abs(fd3.dq_blend(p_, dqs, loc) - g4["blend_out"][i]).max() <= 1e-14
+        a, b = fd3.warp(p_, dqs, loc, normal=n_, m_lw=g4["lw"])
+        assert np.abs(a - g4["warp_pos_out"][i]).max() <= 1e-12 and np.abs(b - g4["warp_nrm_out"][i]).max() <= 1e-12
+    g8 = golden("g8_graph_io")
+    fd4 = FusionDM(1.0, np.eye(3), tsdf_res=4, knn=int(g8["knn"]), write_warpfield=False)
+    fd4._vertices, fd4._radius = g8["verts"], float(g8["radius"])
+    fd4.construct_graph()
+    assert np.array_equal(np.array([n[1] for n in fd4._nodes]), g8["cg_pos"]) and np.array_equal(np.asarray(fd4._neighbor_look_up), g8["cg_lookup"])
 
 
 def test_setup_correspondences_matches_reference(golden):

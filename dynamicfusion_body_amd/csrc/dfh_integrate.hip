@@ -69,7 +69,8 @@ constexpr int kBrZP = kBrZ / 4;                  // z-packs per row of a brick
 static_assert(kBrX * kBrY * kBrZP == 64, "a brick is one wave");
 constexpr int kPyrLevels = 5;                   // pyramid levels 1..5 (cells of 2..32 pixels)
 constexpr int kCullMargin = 1 << 10;            // 2^-10 px: corner projections are good to 2^-19 px, the reference's to 1e-12 px
-constexpr long kEarlyRowsMaxVoxels = 1L << 24;  // slabs up to 256^3 take the early-load row sweep (see integrate_depth_rows_early_kernel)
+constexpr long kEarlyRowsMaxVoxels = 1L << 23;  // slabs up to half of 256^3 take the early-load row sweep (integrate_depth_rows_early_kernel);
+                                                // at 256^3 it is no faster and moves 213 MB instead of 176 MB (PMC, profiles/r2c_summary.json)
 constexpr long kTargetBlocks = 1L << 40;        // measured (profiles/kbench_r1.txt): one plane per block is
                                                 // fastest at 256^3 and 512^3; the plane loop stays as a knob
 

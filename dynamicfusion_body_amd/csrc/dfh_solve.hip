@@ -1437,15 +1437,24 @@ __global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double 
 // ---- persistent PCG: the whole iteration loop in one launch --------------------------------------
 // Every wave owns ONE node row for the whole solve: its 6x6 blocks (up to kRowCache per lane slot), its rows of the
 // block-Jacobi inverse and its six entries of the CG vectors stay in registers; per iteration only the neighbours'
-// published vectors are read (agent-scope loads) and ONE grid-wide reduction, which doubles as the grid barrier,
-// replaces the kernel boundaries.  The grid is sized so that all workgroups are co-resident (<= one per CU on at
-// most half the CUs); the spin is bounded and an abort flag makes every wave leave if one ever times out (x is
-// then NaN, never a hang).  Reductions: every workgroup adds its waves' values in LDS (fixed order) and publishes the
-// partial with an agent-coherent store into a slot that is all-zero bits before the launch (a zero partial is stored
-// as -0.0, so "bits != 0" is the arrival flag); wave 0 polls all slots and adds them in a fixed order: same bits
-// every run and on every rank, no floating-point atomics, no counters, no cache-wide fences.
+// published vectors are read (agent-scope loads) and ONE grid-wide reduction replaces the kernel boundaries.  The
+// grid is sized so that all workgroups are co-resident (<= one per CU on at most half the CUs); every wait is bounded
+// and an abort flag makes every wave leave if one ever times out (x is then NaN, never a hang).  Reductions: every
+// workgroup adds its waves' values in LDS (fixed order) and publishes the partial; wave 0 reads all workgroups'
+// partials and adds them in a fixed order: same bits every run and on every rank, no floating-point atomics, no
+// counters, no cache-wide fences.  Measured (512 rows, tools/kbench_pcg.py): 3.5 us per iteration, of which ~1.9 us
+// is the hand-off (stores becoming visible across the XCDs + one agent-scope load round trip of ~0.9 us).
 constexpr int kRowCache = 3;               // blocks per lane slot held in registers (rows <= 30 blocks)
 constexpr unsigned kSpinLimit = 1u << 22;  // default bound of a barrier's spin (~seconds); DFH_PCG_SPIN_LIMIT overrides (tests)
+#ifndef DFH_PCG_POLL_GAP
+#define DFH_PCG_POLL_GAP 1
+#endif
+#ifndef DFH_PCG_POLL_DELAY
+#define DFH_PCG_POLL_DELAY 16
+#endif
+constexpr int kPollDelay = DFH_PCG_POLL_DELAY;   // s_sleep units (64 clocks) between a publish and the first look: a look costs a
+                                                 // full round trip, one issued at once finds nothing (0 / 8 / 16 / 24 / 32: 4.25 / 3.73 / 3.45 / 3.63 / 3.83 us per iteration)
+constexpr int kPollGap = DFH_PCG_POLL_GAP;       // s_sleep units (64 clocks) between two polls
 constexpr int kMaxPcgBlocks = 512;         // persistent path only for grids up to this many workgroups
 
 __device__ __forceinline__ double ld_agent(const double *p) {
@@ -1458,8 +1467,8 @@ __device__ __forceinline__ void st_agent(double *p, double v) {
 __device__ __forceinline__ void apply_twist_one(double *__restrict__ d, double ox, double oy, double oz, double vx, double vy, double vz);
 
 // ---- single-reduction PCG (Chronopoulos & Gear) -----------------------------------------------------------
-// A grid-wide reduction costs ~3 us across the eight XCDs (MI355X_MICROARCH.md, hand-off price list) and the
-// textbook recurrence needs two per iteration (p.Ap, then r.z).  This variant has ONE: with u = M^-1 r, w = A u,
+// A grid-wide hand-off costs ~1.5-3 us across the eight XCDs (MI355X_MICROARCH.md, hand-off price list) and the
+// textbook recurrence needs two reductions per iteration (p.Ap, then r.z).  This variant has ONE: with u = M^-1 r, w = A u,
 //   gamma = r.u, delta = w.u  (both in the same reduction),  beta = gamma / gamma_old,
 //   alpha = gamma / (delta - beta gamma / alpha_old),  p = u + beta p,  s = w + beta s  (= A p),
 //   x += alpha p,  r -= alpha s,  u = M^-1 r,  w = A u.
@@ -1467,74 +1476,186 @@ __device__ __forceinline__ void apply_twist_one(double *__restrict__ d, double o
 // u_new = u - alpha t with t = M^-1 s = v + beta t_old, v = M^-1 w, so every row publishes (u, v, t_old) BEFORE
 // the reduction and its neighbours form its u_new themselves once alpha and beta are known -- with the same
 // expression the owner uses, hence the same bits.  Same iterates as the textbook PCG in exact arithmetic.
-// Published vectors live in two parity sets (written during iteration i for iteration i+1; the set being
-// overwritten was last read before the reduction that every row has since passed).
+//
+// Hand-offs carry their own arrival flag.  Every published double (a workgroup's partial sums, a row's u, v, t) goes
+// into a slot whose bits are all zero until the one 8-byte agent-scope store that fills it (a zero value is stored as
+// -0.0), so a reader needs no barrier and the writer no store drain: it loads the slot and retries while the bits are
+// zero.  The neighbours' (u, v, t) are requested right after a wave's own stores, i.e. while the reduction is still in
+// flight, so an iteration's critical path is one store becoming visible plus one load (it was: drain the stores,
+// publish the partial, poll the partials, then load the neighbours -- four trips).
+//   * partial sums: a fresh pair of slots per workgroup and reduction (zeroed by the launch's memset);
+//   * vectors: a ring of four phase regions {u, v, t} x 6N (zeroed by the memset); iteration `it` reads region it % 4
+//     and publishes into (it + 1) % 4.  A row's wave clears its own entries of region (it - 1) % 4 after reduction `it`:
+//     every reader was finished with them before it contributed to that reduction.  The wave's wait for its neighbours'
+//     values in iteration it + 1 (loads issued after the clearing stores; vmcnt counts in issue order) proves the
+//     clears complete; only then does the wave contribute to reduction it + 2 and later store the region's next
+//     values (phase it + 3).  A reader asks for those only after it has seen reduction it + 2 complete, so it finds
+//     zero bits or the new value, never the value of four phases ago.
+// A wave whose wait runs out (spin_limit) or that sees the abort flag poisons its row with NaN: the NaN reaches every
+// row through the next reduction, so x is NaN everywhere and nothing hangs.
 struct BarrierLds2 {
     double wave_part[2][16];
     double total[2];
-    int ok;
+};
+struct alignas(16) WaveLds {             // one wave's scratch for trading values between its lanes
+    double q[kRowCache][64];
+    double part[6][10];
+    double w[6];
+};
+// orders a wave's LDS writes before its following LDS reads (the hardware executes one wave's LDS operations in
+// order; this only keeps the compiler from moving them)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+__device__ __forceinline__ double nz_bits(double v) { return __double_as_longlong(v) == 0 ? -0.0 : v; }
+__device__ __forceinline__ bool arrived(double v) { return __double_as_longlong(v) != 0; }
+
+// workgroup barrier for LDS traffic only: vector-memory operations stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Wave-wide sums without the LDS crossbar: DPP row shifts (lanes without a source add 0), then the two cross-row
+// broadcasts; the total is read from lane 63 into scalar registers, i.e. the result is wave-uniform.  Fixed order.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp0_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp0_f64<0x111>(v);                 // row_shr:1
+    v += dpp0_f64<0x112>(v);                 // row_shr:2
+    v += dpp0_f64<0x114>(v);                 // row_shr:4
+    v += dpp0_f64<0x118>(v);                 // row_shr:8   -> lane 15 of every row: the row's sum
+    v += dpp0_f64<0x142, 0xa>(v);            // row_bcast:15 into rows 1 and 3
+    v += dpp0_f64<0x143, 0xc>(v);            // row_bcast:31 into rows 2 and 3
+    return readlane_f64(v, 63);
+}
+__device__ __forceinline__ double sum6_f64(double v) {         // lanes 0..5 -> wave-uniform
+    v += dpp0_f64<0x111>(v);
+    v += dpp0_f64<0x112>(v);
+    v += dpp0_f64<0x114>(v);
+    return readlane_f64(v, 5);
+}
+
+struct PcgAbort {
+    unsigned *flag;                      // this solve's abort flag (zero before the launch); flag[1]: "already counted"
+    unsigned long long *count;           // the library's sticky per-device counter of timed-out solves
+    unsigned spin_limit;
+    __device__ __forceinline__ bool raised() const { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
+    __device__ __forceinline__ void raise() const {                                        // one count per timed-out solve
+        __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (atomicExch(flag + 1, 1u) == 0u) atomicAdd(count, 1ull);
+    }
 };
 
-// two grid-wide sums in one pass; slots = 2 * gridDim.x doubles (workgroup b: 2b, 2b+1), zero before the launch
-__device__ __forceinline__ bool grid_sum2(double *slots, unsigned *abort_flag, unsigned spin_limit, BarrierLds2 *lds, double v0,
-                                          double v1 /* lane 0 */, double *s0, double *s1) {
+#ifdef DFH_PCG_TRACE     // experiment builds only (tools/build_variant.sh): wall-clock stamps of one wave's iteration phases
+__device__ unsigned long long g_pcg_trace[64][16][12];
+#define PCG_STAMP(k) do { if (lane == 0 && tw >= 0 && it < 16) { g_pcg_trace[tw][it][k] = wall_clock64(); if (k == 0) { g_pcg_trace[tw][it][9] = clock64(); g_pcg_trace[tw][it][10] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); } } } while (0)
+#define GS_STAMP(k) do { if ((threadIdx.x & 63) == 0 && tr) tr[k] = wall_clock64(); } while (0)
+#else
+#define PCG_STAMP(k) do {} while (0)
+#define GS_STAMP(k) do {} while (0)
+#endif
+
+// Two grid-wide sums in one pass; slots = 2 * gridDim.x doubles (workgroup b: 2b, 2b+1), zero bits before the launch.
+// in_flight() runs in every wave between the publish and the wait: loads issued there travel beside the reduction.
+// Returns NaN totals when the wait was given up.
+template <class R, class H>
+__device__ __forceinline__ void grid_sum2(double *slots, const PcgAbort &ab, BarrierLds2 *lds, double v0, double v1 /* wave-uniform */,
+                                          double *s0, double *s1, bool fetch, R &&request, H &&here, unsigned long long *tr = nullptr) {
+    // fetch: the wave also wants its neighbours' published values: request() issues the loads, here() says whether the
+    // last request found them all (wave-uniform).  Every wave keeps asking while the reduction is in flight, so the
+    // values and the totals are usually both there one load latency after the slowest workgroup's stores land.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    __builtin_amdgcn_s_waitcnt(0);                      // this wave's published vectors have reached the coherence point
     if (lane == 0) { lds->wave_part[0][wave] = v0; lds->wave_part[1][wave] = v1; }
-    __syncthreads();
-    if (wave == 0) {
-        if (lane < 2) {
-            double v = 0.0;
-            for (int w = 0; w < waves; ++w) v += lds->wave_part[lane][w];
-            if (__double_as_longlong(v) == 0) v = -0.0;
-            st_agent(slots + 2 * blockIdx.x + lane, v);
-        }
-        const int ns = 2 * (int)gridDim.x;              // slot index parity = which sum; b += 64 keeps a lane's parity
-        unsigned spins = 0;
-        int ok = 1;
-        double tot = 0.0;
-        for (;;) {
-            double v = 0.0;
-            bool all = true;
-            for (int b = lane; b < ns; b += 64) {
-                const double t = ld_agent(slots + b);
-                all = all && (__double_as_longlong(t) != 0);
-                v += t;
-            }
-            if (__all(all)) {
-#pragma unroll
-                for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);     // lanes 0 and 1 end with the two totals
-                tot = v;
-                break;
-            }
-            if (++spins > spin_limit || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (lane < 2) lds->total[lane] = tot;
-        if (lane == 0) lds->ok = ok;
+    lds_barrier();
+    GS_STAMP(5);
+#ifdef DFH_PCG_TRACE
+    if (tr && lane == 0) tr[8] = 0ull;
+#endif
+    if (wave == 0 && lane < 2) {
+        double v = 0.0;
+        for (int w = 0; w < waves; ++w) v += lds->wave_part[lane][w];
+        st_agent(slots + 2 * blockIdx.x + lane, nz_bits(v));
     }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    bool have = !fetch;
+    GS_STAMP(6);
+    unsigned spins = 0;
+    if (kPollDelay > 0) __builtin_amdgcn_s_sleep(kPollDelay);   // nothing can have arrived yet
+    if (wave == 0) {
+        const int nb = (int)gridDim.x;                  // lane l adds workgroups l, l + 64, ...
+        double t0 = 0.0, t1 = 0.0;
+        for (;;) {
+            bool all = true;
+            t0 = 0.0;
+            t1 = 0.0;
+            for (int b = lane; b < nb; b += 64) {
+                const double p0 = ld_agent(slots + 2 * b), p1 = ld_agent(slots + 2 * b + 1);
+                all = all && arrived(p0) && arrived(p1);
+                t0 += p0;
+                t1 += p1;
+            }
+            if (!have) {
+                request();
+                have = here();
+            }
+            if (__all(all)) break;
+#ifdef DFH_PCG_TRACE
+            if (tr && lane == 0) tr[8] += 1ull;                 // failed polls
+#endif
+            if (++spins > ab.spin_limit || ab.raised()) {
+                if (lane == 0) ab.raise();
+                t0 = t1 = __builtin_nan("");
+                break;
+            }
+            __builtin_amdgcn_s_sleep(kPollGap);
+        }
+        t0 = wave_sum_f64(t0);
+        t1 = wave_sum_f64(t1);
+        GS_STAMP(7);
+        if (lane == 0) { lds->total[0] = t0; lds->total[1] = t1; }
+    } else {
+        while (!have) {
+            request();
+            have = here();
+            if (have) break;
+            if (++spins > ab.spin_limit || ab.raised()) {      // (the caller's wait sees the flag and poisons the row)
+                if (lane == 0) ab.raise();
+                break;
+            }
+            __builtin_amdgcn_s_sleep(kPollGap);
+        }
+    }
+    lds_barrier();
     *s0 = lds->total[0];
     *s1 = lds->total[1];
-    return lds->ok != 0;
 }
 
 // MAXT = largest workgroup it is launched with: 512 leaves 256 VGPRs per lane (no spills in the prologue's 6x6 inverse)
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col, double *vals,
                                                         const double *__restrict__ rhs, const PcgParams prm, int iters,
-                                                        double *__restrict__ x, double *pub /* 2 x {u, v, t} x 6N */, double *part,
+                                                        double *__restrict__ x, double *ring /* 4 x {u, v, t} x 6N */, double *part,
                                                         unsigned *abort_flag, unsigned spin_limit, unsigned long long *abort_count,
                                                         double *__restrict__ update_dq, double update_step) {
     // update_dq != NULL: the row's wave also applies its twist, update_dq[a] <- exp(update_step * x_a) (x) update_dq[a]
-    // abort_flag: this solve's flag (zero before the launch); abort_count: the library's sticky per-device counter of
-    // timed-out solves, read by dfh_pcg_status() at the caller's next synchronisation point
+    // abort_count is read by dfh_pcg_status() at the caller's next synchronisation point
     __shared__ BarrierLds2 lds;
+    __shared__ WaveLds wlds[MAXT / 64];
+    const PcgAbort ab{abort_flag, abort_count, spin_limit};
     const int N = prm.N;
     const size_t N6 = 6 * (size_t)N;
     const int lane = threadIdx.x & 63;
@@ -1556,8 +1677,12 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
 #pragma unroll
         for (int j = 0; j < 6; ++j) Bc[c][j] = have ? vals[36 * (size_t)b + 6 * i + j] : 0.0;
         if (have && cj[c] == a) {
-            Bc[c][i] = Bc[c][i] + prm.lm_abs + prm.lm_rel * Bc[c][i];
-            vals[36 * (size_t)b + 7 * i] = Bc[c][i];           // (only this lane reads that element, and it has)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)                         // (static indices: a lane-dependent one would move Bc to scratch memory)
+                if (j == i) {
+                    Bc[c][j] = Bc[c][j] + prm.lm_abs + prm.lm_rel * Bc[c][j];
+                    vals[36 * (size_t)b + 7 * i] = Bc[c][j];   // (only this lane reads that element, and it has)
+                }
         }
     }
     // block-Jacobi preconditioner: the damped diagonal block, from the register cache when it is there (six lanes hold
@@ -1603,71 +1728,122 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
             Mi[j] = lead ? v : 0.0;
         }
     }
-    // y = A q for this row, q_j = what the closure returns for element i of neighbour j (lane (slot, i) asks for
-    // element i; the six lanes of a slot trade them); result in lanes 0..5
-    auto spmv = [&](auto &&elem) {
+    // The neighbours' published values of this lane's cached blocks (element i of node cj[c]); rows wider than the
+    // cache read the rest of their neighbours one at a time (wait_for).
+    double nu[kRowCache], nv[kRowCache], nt[kRowCache];
+    const bool wide = __any(slot < 10 && beg + slot + 10 * kRowCache < end);
+    auto request = [&](const double *P, bool with_vt) {
+#pragma unroll
+        for (int c = 0; c < kRowCache; ++c) {
+            const bool have = cj[c] >= 0;
+            const size_t j6 = 6 * (size_t)(have ? cj[c] : 0) + i;
+            nu[c] = have ? ld_agent(P + j6) : 1.0;
+            nv[c] = have && with_vt ? ld_agent(P + N6 + j6) : 1.0;
+            nt[c] = have && with_vt ? ld_agent(P + 2 * N6 + j6) : 1.0;
+        }
+    };
+    auto all_here = [&]() {
+        bool all = true;
+#pragma unroll
+        for (int c = 0; c < kRowCache; ++c) all = all && arrived(nu[c]) && arrived(nv[c]) && arrived(nt[c]);
+        return __all(all) != 0;
+    };
+    bool mine = true;                                           // false once one of this wave's waits was given up
+    auto await = [&](const double *P, bool with_vt) {          // checks the last request first
+        unsigned spins = 0;
+        while (!all_here()) {
+            if (++spins > spin_limit || ab.raised()) {
+                if (lane == 0) ab.raise();
+                mine = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            request(P, with_vt);
+        }
+    };
+    auto wait_for = [&](const double *p) {                      // one published value (wide rows' tail)
+        double v = ld_agent(p);
+        unsigned spins = 0;
+        while (!arrived(v)) {
+            if (++spins > spin_limit || ab.raised()) {
+                ab.raise();
+                mine = false;
+                return __builtin_nan("");
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = ld_agent(p);
+        }
+        return v;
+    };
+    // y = A q for this row: qc[c] = element i of neighbour cj[c]'s vector, tail(j6) = element j6 of the vector for the
+    // blocks beyond the cache.  Lanes trade values through the wave's own LDS scratch (a write, then wide reads: a
+    // quarter of the instructions the cross-lane shuffles took): the six lanes of a slot read that neighbour's six
+    // elements, lane i < 6 then reads and adds the ten slots' row-i partial sums (in slot order).  Result in lanes 0..5.
+    WaveLds &wl = wlds[threadIdx.x >> 6];
+    auto spmv = [&](const double (&qc)[kRowCache], auto &&tail) {
+#pragma unroll
+        for (int c = 0; c < kRowCache; ++c) wl.q[c][lane] = qc[c];
+        wave_lds_sync();
         double acc = 0.0;
 #pragma unroll
         for (int c = 0; c < kRowCache; ++c) {
-            const int j6 = 6 * (cj[c] >= 0 ? cj[c] : 0) + i;
-            const double qi = slot < 10 ? elem(j6) : 0.0;
-            const int base = 6 * slot;
-            const double q0 = __shfl(qi, base + 0, 64), q1 = __shfl(qi, base + 1, 64), q2 = __shfl(qi, base + 2, 64);
-            const double q3 = __shfl(qi, base + 3, 64), q4 = __shfl(qi, base + 4, 64), q5 = __shfl(qi, base + 5, 64);
+            const double2 *qs = reinterpret_cast<const double2 *>(&wl.q[c][6 * (slot < 10 ? slot : 0)]);
+            const double2 q01 = qs[0], q23 = qs[1], q45 = qs[2];
             if (cj[c] >= 0)
-                acc += ((Bc[c][0] * q0 + Bc[c][1] * q1) + (Bc[c][2] * q2 + Bc[c][3] * q3)) + (Bc[c][4] * q4 + Bc[c][5] * q5);
+                acc += ((Bc[c][0] * q01.x + Bc[c][1] * q01.y) + (Bc[c][2] * q23.x + Bc[c][3] * q23.y)) + (Bc[c][4] * q45.x + Bc[c][5] * q45.y);
         }
-        if (slot < 10) {
-            for (int b = beg + slot + 10 * kRowCache; b < end; b += 10) {      // rows wider than the cache
+        if (wide && slot < 10) {
+            for (int b = beg + slot + 10 * kRowCache; b < end; b += 10) {
                 const double *B = vals + 36 * (size_t)b + 6 * i;
-                const int j6 = 6 * col[b];
-                const double q0 = elem(j6 + 0), q1 = elem(j6 + 1), q2 = elem(j6 + 2), q3 = elem(j6 + 3), q4 = elem(j6 + 4), q5 = elem(j6 + 5);
+                const size_t j6 = 6 * (size_t)col[b];
+                const double q0 = tail(j6 + 0), q1 = tail(j6 + 1), q2 = tail(j6 + 2), q3 = tail(j6 + 3), q4 = tail(j6 + 4), q5 = tail(j6 + 5);
                 acc += ((B[0] * q0 + B[1] * q1) + (B[2] * q2 + B[3] * q3)) + (B[4] * q4 + B[5] * q5);
             }
         }
-        double y = acc;
-#pragma unroll
-        for (int k = 1; k < 10; ++k) {
-            const double o = __shfl(acc, lane + 6 * k, 64);
-            y += (lane + 6 * k < 60) ? o : 0.0;
-        }
-        return y;
+        if (slot < 10) wl.part[i][slot] = acc;
+        wave_lds_sync();
+        const double2 *ps = reinterpret_cast<const double2 *>(&wl.part[lane < 6 ? lane : 0][0]);
+        const double2 p01 = ps[0], p23 = ps[1], p45 = ps[2], p67 = ps[3], p89 = ps[4];
+        return ((((((((p01.x + p01.y) + p23.x) + p23.y) + p45.x) + p45.y) + p67.x) + p67.y) + p89.x) + p89.y;
     };
     auto minv = [&](double v) {                                 // (M^-1 v)_lane from the six entries in lanes 0..5
-        double o = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) o += Mi[j] * __shfl(v, j, 64);
-        return o;
+        if (lane < 6) wl.w[lane] = v;
+        wave_lds_sync();
+        const double2 *ws = reinterpret_cast<const double2 *>(&wl.w[0]);
+        const double2 w01 = ws[0], w23 = ws[1], w45 = ws[2];
+        return ((((Mi[0] * w01.x + Mi[1] * w01.y) + Mi[2] * w23.x) + Mi[3] * w23.y) + Mi[4] * w45.x) + Mi[5] * w45.y;
     };
-    auto dot2 = [&](double a0, double b0, double &g, double &d) {   // lanes 0..5 -> lane 0
-        g = lead ? a0 : 0.0;
-        d = lead ? b0 : 0.0;
-        g += __shfl_down(g, 4, 64); d += __shfl_down(d, 4, 64);
-        g += __shfl_down(g, 2, 64); d += __shfl_down(d, 2, 64);
-        g += __shfl_down(g, 1, 64); d += __shfl_down(d, 1, 64);
-    };
-    double *set[2] = {pub, pub + 3 * N6};                       // parity sets: u at +0, v at +N6, t at +2 N6
+    // phase regions: u at +0, v at +N6, t at +2 N6 (pointer arithmetic, not a table of pointers: the accesses stay
+    // global_load/global_store; a generic pointer's flat accesses would also count on lgkmcnt and stall the LDS barriers)
+    auto region = [&](int k) { return ring + (size_t)(k & 3) * 3 * N6; };
     double xi = 0.0, ri = lead ? -rhs[6 * a + lane] : 0.0, pi = 0.0, si = 0.0, ti = 0.0;
     double ui = minv(ri);
-    if (lead) st_agent(set[0] + 6 * a + lane, ui);
-    double g, d, gamma = 0.0, delta = 0.0;
-    bool ok = grid_sum2(part, abort_flag, spin_limit, &lds, 0.0, 0.0, &g, &d);          // plain barrier: u0 is out
-    part += 2 * gridDim.x;
-    double wi = 0.0, vi = 0.0;
-    if (ok) {
-        const double *u0 = set[0];
-        wi = spmv([&](int j6) { return ld_agent(u0 + j6); });
-        vi = minv(wi);
-        if (lead) {
-            st_agent(set[0] + N6 + 6 * a + lane, vi);
-            st_agent(set[0] + 2 * N6 + 6 * a + lane, 0.0);
-        }
-        dot2(ri * ui, wi * ui, g, d);
+    if (lead) st_agent(region(0) + 6 * a + lane, nz_bits(ui));
+    request(region(0), false);
+    await(region(0), false);
+    double wi = spmv(nu, [&](size_t j6) { return wait_for(region(0) + j6); });
+    double vi = minv(wi);
+    if (lead) {
+        st_agent(region(0) + N6 + 6 * a + lane, nz_bits(vi));
+        st_agent(region(0) + 2 * N6 + 6 * a + lane, -0.0);
     }
+    if (!mine) ui = __builtin_nan("");
+    double gamma = 0.0, delta = 0.0;
+    double g = sum6_f64(lead ? ri * ui : 0.0), d = sum6_f64(lead ? wi * ui : 0.0);
     double gamma_prev = 0.0, alpha_prev = 0.0;
-    for (int it = 0; it < iters && ok; ++it) {
-        ok = grid_sum2(part + (size_t)it * 2 * gridDim.x, abort_flag, spin_limit, &lds, g, d, &gamma, &delta);
-        if (!ok) break;
+#ifdef DFH_PCG_TRACE
+    const int tw = (threadIdx.x >> 6) == (DFH_PCG_TRACE) && blockIdx.x < 64 ? (int)blockIdx.x : -1;
+#endif
+    for (int it = 0; it < iters; ++it) {
+        const double *cur = region(it);
+        const bool last = it == iters - 1;
+        PCG_STAMP(0);
+        grid_sum2(part + (size_t)it * 2 * gridDim.x, ab, &lds, g, d, &gamma, &delta, !last, [&]() { request(cur, true); }, all_here
+#ifdef DFH_PCG_TRACE
+                  , tw >= 0 && it < 16 ? &g_pcg_trace[tw][it][0] : nullptr
+#endif
+        );
+        PCG_STAMP(1);
         const double beta = gamma_prev != 0.0 ? gamma / gamma_prev : 0.0;
         const double denom = alpha_prev != 0.0 ? delta - (beta * gamma) / alpha_prev : delta;
         const double alpha = denom != 0.0 ? gamma / denom : 0.0;
@@ -1679,23 +1855,36 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
             ri = ri - alpha * si;
             ui = ui - alpha * ti;
         }
-        if (it == iters - 1) break;
-        const double *cur = set[it & 1];
-        double *nxt = set[(it & 1) ^ 1];
-        wi = spmv([&](int j6) { return ld_agent(cur + j6) - alpha * (ld_agent(cur + N6 + j6) + beta * ld_agent(cur + 2 * N6 + j6)); });
-        vi = minv(wi);
-        if (lead) {
-            st_agent(nxt + 6 * a + lane, ui);
-            st_agent(nxt + N6 + 6 * a + lane, vi);
-            st_agent(nxt + 2 * N6 + 6 * a + lane, ti);
+        if (last) break;
+        if (it >= 1 && lead) {                                  // region (it - 1) % 4: every reader is done with it
+            double *old = region(it - 1);
+            st_agent(old + 6 * a + lane, 0.0);
+            st_agent(old + N6 + 6 * a + lane, 0.0);
+            st_agent(old + 2 * N6 + 6 * a + lane, 0.0);
         }
-        dot2(ri * ui, wi * ui, g, d);
+        PCG_STAMP(2);
+        await(cur, true);
+        PCG_STAMP(3);
+        double qc[kRowCache];
+#pragma unroll
+        for (int c = 0; c < kRowCache; ++c) qc[c] = nu[c] - alpha * (nv[c] + beta * nt[c]);
+        wi = spmv(qc, [&](size_t j6) { return wait_for(cur + j6) - alpha * (wait_for(cur + N6 + j6) + beta * wait_for(cur + 2 * N6 + j6)); });
+        vi = minv(wi);
+        double *nxt = region(it + 1);
+        if (lead) {
+            st_agent(nxt + 6 * a + lane, nz_bits(ui));
+            st_agent(nxt + N6 + 6 * a + lane, nz_bits(vi));
+            st_agent(nxt + 2 * N6 + 6 * a + lane, nz_bits(ti));
+        }
+        if (!mine) ui = __builtin_nan("");
+        g = sum6_f64(lead ? ri * ui : 0.0);
+        d = sum6_f64(lead ? wi * ui : 0.0);
+        PCG_STAMP(4);
         gamma_prev = gamma;
         alpha_prev = alpha;
     }
-    if (lead) x[6 * a + lane] = ok ? xi : __builtin_nan("");
-    if (!ok && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(abort_count, 1ull);     // one count per timed-out solve
-    if (update_dq && ok) {
+    if (lead) x[6 * a + lane] = xi;
+    if (update_dq && !__any(xi != xi)) {
         const double xs = update_step * xi;
         const double t0 = __shfl(xs, 0, 64), t1 = __shfl(xs, 1, 64), t2 = __shfl(xs, 2, 64);
         const double t3 = __shfl(xs, 3, 64), t4 = __shfl(xs, 4, 64), t5 = __shfl(xs, 5, 64);
@@ -2096,9 +2285,10 @@ int dfh_gn_build_planned_assoc(const double *sample_pos, const double *sample_nr
 
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
     if (n_nodes <= 0 || iters < 0) return 0;
-    // Minv (36N) + r,pA,Ap,z,pB (5*6N) + scalars (3 per iteration + 6) + per-workgroup partial sums
+    // Minv (36N) + r,pA,Ap,z,pB (5*6N) + scalars (3 per iteration + 6) + per-workgroup partial sums + the persistent
+    // kernel's ring of published vectors (4 x 3 x 6N)
     return sizeof(double) * ((size_t)36 * n_nodes + (size_t)30 * n_nodes + 3 * ((size_t)iters + 2) +
-                             2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4));
+                             2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4) + (size_t)72 * n_nodes);
 }
 
 // ---- persistent-PCG bookkeeping ---------------------------------------------------------------------------------
@@ -2161,7 +2351,8 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
     double *pB = ws; ws += N6;
     double *pA = ws; ws += N6;                    // pA and the scalars are adjacent: one memset zeroes both
     double *scal = ws;                            // (beta = 0 in iteration 0 must not meet NaN garbage in pA)
-    DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + 3 * ((size_t)iters + 2) + 2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4)), s));
+    const size_t n_scal = 3 * ((size_t)iters + 2) + 2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4);
+    double *ring = scal + n_scal;                 // persistent kernel only; zero bits = "not yet published"
     PcgParams p{n_nodes, lm_abs, lm_rel};
     dim3 grid((n_nodes + 255) / 256), block(256);
     // One persistent launch when every row can have its own co-resident wave (N <= 16 waves x #CUs / 2)
@@ -2209,20 +2400,21 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
         }
     }
     if (persistent) {
+        DFH_HIP_CHECK(hipMemsetAsync(scal, 0, sizeof(double) * (n_scal + 12 * N6), s));
         unsigned spin_limit = kSpinLimit;
         if (const char *e = getenv("DFH_PCG_SPIN_LIMIT")) spin_limit = (unsigned)strtoul(e, nullptr, 10);
         unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
         double *part = scal + 3 * ((size_t)iters + 2);                                    // (2 per iteration + 1) reductions x nblk slots
-        // Minv's 36 N doubles hold the two sets of published {u, v, t}
         if (wpb <= 8)
-            hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
+            hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, ring, part,
                                flag, spin_limit, abort_count, update_dq, update_step);
         else
-            hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, Minv, part,
+            hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, ring, part,
                                flag, spin_limit, abort_count, update_dq, update_step);
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }
+    DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + n_scal), s));
     // scal[0..2] belongs to the init (rz0 in scal[2] so that iteration 0 reads it as "rz_next")
     hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, z, scal + 2);
     double *p_prev = pA, *p_cur = pB;
@@ -2239,6 +2431,12 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }
+
+#ifdef DFH_PCG_TRACE
+int dfh_debug_pcg_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dfh::g_pcg_trace), sizeof(unsigned long long) * 64 * 16 * 12) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int dfh_pcg_solve(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
                   double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, void *stream) {

@@ -709,6 +709,13 @@ struct AssocArgs {
     const float *depth;
 };
 
+#ifdef DFH_BUILD_TRACE   // experiment builds only: wall-clock stamps of every tile's phases
+__device__ unsigned long long g_build_trace[8192][8];
+#define BT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_build_trace[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define BT_STAMP(k) do {} while (0)
+#endif
+
 template <int K, bool PLANNED, bool ASSOC>
 __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
                                                              const int *__restrict__ nbr, const double *__restrict__ wts,
@@ -725,6 +732,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
                      rhs, cost_count, rt.partial_reg);
         return;
     }
+    BT_STAMP(0);
     constexpr int NJ = 6 * K;                   // Jacobian entries per sample
     constexpr int LD = NJ + 1;                  // + residual
     __shared__ double sJ[kTile * LD];
@@ -754,6 +762,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         valid[s] = a_ok ? 1 : 0;
     }
     const bool act = ASSOC ? a_ok : (tid < tile_n && valid[s] != 0);
+    BT_STAMP(1);
     __shared__ int sWaveCnt[4];
     const unsigned long long bal = __ballot(act);
     const int lane = tid & 63, wv = tid >> 6;
@@ -762,11 +771,12 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     int pos = __popcll(bal & ((1ull << lane) - 1ull));
     for (int w_ = 0; w_ < wv; ++w_) pos += sWaveCnt[w_];
     const int n_valid = sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
-    constexpr int NE_ = gn_row_entries(K), ST_ = gn_row_stride(K);  // live flag at [NE_]: 0 = row not written this iteration
+    constexpr int ST_ = gn_row_stride(K);
+    double *live = PLANNED ? tile_cost + 2 * (size_t)rt.n_tiles : nullptr;      // one flag per row, dense: 0 = row not written this iteration
     const int row_first = PLANNED ? run_id[blockIdx.x * kTile] : 0;
     const int rows_tile = PLANNED ? run_id[blockIdx.x * kTile + tile_n - 1] - row_first + 1 : 0;
     if (n_valid == 0) {                                              // tiles without a valid sample contribute nothing:
-        if (PLANNED && tid < rows_tile) partial[(size_t)(row_first + tid) * ST_ + NE_] = 0.0;    // their rows are dead
+        if (PLANNED && tid < rows_tile) live[row_first + tid] = 0.0;                                 // their rows are dead
         if (PLANNED && tid == 0) { tile_cost[2 * blockIdx.x] = 0.0; tile_cost[2 * blockIdx.x + 1] = 0.0; }
         return;
     }
@@ -805,6 +815,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         for (int j = 0; j < NJ; ++j) sJ[pos * LD + j] = Jrow[j];
         sJ[pos * LD + NJ] = r;
     }
+    BT_STAMP(2);
     if (PLANNED) {                                                   // the tile's objective, added in a fixed order
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) obj += __shfl_xor(obj, o, 64);
@@ -842,6 +853,10 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         __syncthreads();
     }
     const int n_runs = sNRuns;
+    BT_STAMP(3);
+#ifdef DFH_BUILD_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_build_trace[blockIdx.x][6] = (unsigned long long)n_valid | ((unsigned long long)n_runs << 16);
+#endif
     // block index of every (slot a, slot b) node pair of every run, searched once, in parallel
     constexpr bool kBlkTable = K <= 4 && !PLANNED;         // 256 runs x K^2 ints must fit next to sJ
     __shared__ int sBlk[kBlkTable ? kTile * K * K : 1];
@@ -865,7 +880,66 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         __syncthreads();
         if (tid < n_runs) sTouched[sRow[sRun[tid]] - row_first] = 1;
         __syncthreads();
-        if (tid < rows_tile) partial[(size_t)(row_first + tid) * ST_ + NE_] = sTouched[tid] ? 1.0 : 0.0;
+        if (tid < rows_tile) live[row_first + tid] = sTouched[tid] ? 1.0 : 0.0;
+    }
+    BT_STAMP(4);
+    if constexpr (PLANNED) {
+        // Gram matrix of every run on the matrix cores: G = X^T X with X = the run's rows of [J | r] (n x (6K + 1)), as 16 x 16
+        // tiles of v_mfma_f64_16x16x4_f64 (four samples per step, A and B fragments straight from the compacted rows in
+        // LDS: two reads per lane and step where the scalar loop read two values per sample and ENTRY).  One wave per
+        // run, runs dealt round-robin; the accumulation order (sample order, fused multiply-add) is fixed, so the bits are
+        // the same every launch.  Each lane then stores its accumulator elements straight to their places in the scratch
+        // row (a 16-lane group writes three 48-byte runs; the row is written whole by this wave).
+        constexpr int NC = NJ + 1;                                   // columns: Jacobian + residual
+        constexpr int NT = (NC + 15) / 16;                           // 16-column tiles per side
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        const int li = lane & 15, lk = lane >> 4;
+        for (int rn = wv; rn < n_runs; rn += kTile / 64) {
+            const int t0 = sRun[rn], t1 = sRun[rn + 1];
+            d4 acc[NT * (NT + 1) / 2];
+#pragma unroll
+            for (int q = 0; q < NT * (NT + 1) / 2; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+            for (int t = t0; t < t1; t += 4) {
+                double x[NT];                                        // A[i = li][k = lk] = B[k = lk][j = li] = X[t + lk][16 b + li]
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int c = 16 * b + li;
+                    const double *src = sJ + (t + lk) * LD + c;
+                    x[b] = (t + lk < t1 && c < NC) ? *src : 0.0;
+                }
+                int q = 0;
+#pragma unroll
+                for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+                    for (int bj = bi; bj < NT; ++bj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[bi], x[bj], acc[q], 0, 0, 0);
+            }
+            double *dst = partial + (size_t)sRow[t0] * ST_;
+            int q = 0;
+#pragma unroll
+            for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+                for (int bj = bi; bj < NT; ++bj, ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                    // C/D: column = lane & 15, row = (lane >> 4) + 4 r
+                        const int pa = 16 * bi + lk + 4 * r, pb = 16 * bj + li;
+                        const double v = acc[q][r];
+                        if (pa < NJ && pb < NJ) {
+                            const int sa = pa / 6, sb = pb / 6;
+                            if (sa <= sb) {
+                                dst[36 * gn_sub(K, sa, sb) + 6 * (pa - 6 * sa) + (pb - 6 * sb)] = v;
+                                // a diagonal sub-block that straddles two tiles: its lower entries lie in the tile that is
+                                // not computed; the product is symmetric bit for bit
+                                if (bi != bj && sa == sb) dst[36 * gn_sub(K, sa, sa) + 6 * (pb - 6 * sb) + (pa - 6 * sa)] = v;
+                            }
+                        } else if (pa < NJ && pb == NJ) {
+                            dst[NUP + pa] = v;                       // J^T r
+                        } else if (pa == NJ && pb == NJ) {
+                            dst[NUP + NJ] = 0.5 * v;                 // cost
+                        }
+                    }
+        }
+        BT_STAMP(5);
+        return;
     }
     for (int e = tid; e < NUP + NJ + 1; e += 256) {
         int pa, pb;                              // Jacobian columns of this entry (pb == NJ: residual)
@@ -919,6 +993,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
             }
         }
     }
+    BT_STAMP(5);
 }
 
 // Second half of the planned build.  Workgroups [0, ceil(n_blocks/4)): one WAVE per 6x6 block (a,b), lanes 0..35 own
@@ -930,8 +1005,9 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
 
 // one wave: sum over block b's list of entry (ia, ib) of the rows' Gram matrices (lanes 0..35; others return 0)
 template <int K>
-__device__ __forceinline__ double gather_block_list(const double *__restrict__ partial, const int *__restrict__ blk_ptr,
-                                                    const int *__restrict__ blk_ent, int b, int lane, int wv) {
+__device__ __forceinline__ double gather_block_list(const double *__restrict__ partial, const double *__restrict__ live,
+                                                    const int *__restrict__ blk_ptr, const int *__restrict__ blk_ent, int b, int lane,
+                                                    int wv) {
     constexpr int NJ = 6 * K, NE = gn_row_stride(K), kLive = gn_row_entries(K);
     const int beg = blk_ptr[b], end = blk_ptr[b + 1];
     const int ia = (lane % 36) / 6, ib = lane % 6;
@@ -950,7 +1026,10 @@ __device__ __forceinline__ double gather_block_list(const double *__restrict__ p
 #pragma unroll
         for (int u = 0; u < 4; ++u) ent[u] = base + 64 * u + lane < end ? blk_ent[base + 64 * u + lane] : -1;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) on[u] = ent[u] >= 0 && partial[(size_t)(ent[u] / (K * K)) * NE + kLive] != 0.0;
+        for (int u = 0; u < 4; ++u) {
+            const double flag = ent[u] >= 0 ? (live ? live[ent[u] / (K * K)] : partial[(size_t)(ent[u] / (K * K)) * NE + kLive]) : 0.0;
+            on[u] = flag != 0.0;
+        }
         int nl = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -982,89 +1061,165 @@ __device__ __forceinline__ double gather_block_list(const double *__restrict__ p
     return acc;
 }
 
+#ifdef DFH_GATHER_TRACE  // experiment builds only: wall-clock stamps of every block wave's hops
+__device__ unsigned long long g_gather_trace[8192][8];
+#define GT_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0 && b < 8192) g_gather_trace[b][k] = wall_clock64(); } while (0)
+#else
+#define GT_STAMP(k) do {} while (0)
+#endif
+
 // The data rows' list and the regulariser's list of one block walked TOGETHER: the walk is a chain of dependent hops (list
-// bounds -> entries -> live flags -> values) and doing the two lists one after the other doubles the chain (8 hops; the gather
-// is latency-bound: ~12 entries per block).  Here every hop is issued for both lists at once (4 hops).  Same sums, same order:
-// data entries in list order, then the regulariser's in list order, value = data sum + regulariser sum.  Regulariser lists
-// longer than 64 entries or data lists longer than 256 take the sequential walk (same result).
+// bounds -> entries -> live flags -> values) and doing the two lists one after the other doubles the chain.  Here every
+// hop is issued for both lists at once (4 hops).  Values are added in rounds of 16 loads in flight per lane (absent
+// entries add 0.0).  A list with more than kCoopList live entries (the diagonal blocks: every row that touches the node,
+// ~170) is split into four contiguous quarters, one per wave of the workgroup, and the quarters' sums are added in order
+// -- walked by one wave alone it was eleven dependent rounds of ~2 us and set the whole launch's duration.
+// Regulariser lists longer than 64 entries or data lists longer than 256 take the sequential walk.
+#ifndef DFH_GATHER_DEPTH
+#define DFH_GATHER_DEPTH 4
+#endif
+constexpr int kGatherDepth = DFH_GATHER_DEPTH;   // value loads in flight per lane and round
+constexpr int kCoopList = 3 * kGatherDepth;
+
+struct GatherLds {
+    int liveD[4][256];
+    int liveR[4][64];
+    int coop[4];
+    double part[4][4][36];
+    double comb[4][3][2][36];
+};
+
+// lanes 0..35: sum of entry (ia, ib) = lane / 6, lane % 6 over list[q0, q1).  A list entry's sub-block is 36 contiguous
+// doubles, so 18 lanes take it with one 16-byte load each and a load instruction covers THREE entries (lane group g takes
+// entries q0 + g, q0 + g + 3, ...): kGatherDepth instructions in flight = 48 entries a round (a round costs ~3 us of
+// latency whatever it carries).  Entries whose sub-block is stored transposed (tuple slots sa > sb) are added up in
+// stored orientation on their own and transposed once at the end; the three groups' sums are added in group order.
+// `comb` = this wave's scratch (3 x 2 x 36 doubles).  Order of the additions: fixed, not list order.
 template <int K>
-__device__ __forceinline__ double gather_block_both(const double *__restrict__ partial, const int *__restrict__ blk_ptr,
+__device__ __forceinline__ double gather_rounds(const double *__restrict__ partial, const int *list, int q0, int q1, int lane,
+                                                double (*comb)[2][36]) {
+    constexpr int NE = gn_row_stride(K);
+    const int g = lane / 18, h = lane - 18 * g;                     // lanes 54..63: g == 3, idle
+    double2 sd{0.0, 0.0}, st{0.0, 0.0};
+    for (int q = q0; q < q1; q += 3 * kGatherDepth) {
+        int e[kGatherDepth];
+#pragma unroll
+        for (int u = 0; u < kGatherDepth; ++u) e[u] = list[min(q + 3 * u + g, q1 - 1)];
+        double2 v[kGatherDepth];
+        bool tr[kGatherDepth];
+#pragma unroll
+        for (int u = 0; u < kGatherDepth; ++u) {
+            const int row = e[u] / (K * K), pr = e[u] - row * (K * K);
+            const int sa = pr / K, sb = pr - sa * K;
+            tr[u] = sa > sb;
+            const double2 *src = reinterpret_cast<const double2 *>(partial + (size_t)row * NE + 36 * (tr[u] ? gn_sub(K, sb, sa) : gn_sub(K, sa, sb))) + h;
+            v[u] = (g < 3 && q + 3 * u + g < q1) ? *src : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < kGatherDepth; ++u) {
+            sd.x += tr[u] ? 0.0 : v[u].x; sd.y += tr[u] ? 0.0 : v[u].y;
+            st.x += tr[u] ? v[u].x : 0.0; st.y += tr[u] ? v[u].y : 0.0;
+        }
+    }
+    if (g < 3) {
+        comb[g][0][2 * h] = sd.x; comb[g][0][2 * h + 1] = sd.y;
+        comb[g][1][2 * h] = st.x; comb[g][1][2 * h + 1] = st.y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    double tot = 0.0;
+    if (lane < 36) {
+        const int m = lane, mt = 6 * (lane % 6) + lane / 6;
+        tot = ((comb[0][0][m] + comb[1][0][m]) + comb[2][0][m]) + ((comb[0][1][mt] + comb[1][1][mt]) + comb[2][1][mt]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();                               // (the scratch is reused by the wave's next call)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    return tot;
+}
+
+// one workgroup = four blocks, one wave each; every wave of the workgroup must call this (it synchronises)
+template <int K>
+__device__ __forceinline__ double gather_block_both(const double *__restrict__ partial, const double *__restrict__ live,
+                                                    const int *__restrict__ blk_ptr,
                                                     const int *__restrict__ blk_ent, const double *__restrict__ rpartial,
-                                                    const int *__restrict__ rblk_ptr, const int *__restrict__ rblk_ent, int b, int lane,
-                                                    int wv) {
+                                                    const int *__restrict__ rblk_ptr, const int *__restrict__ rblk_ent, int b, bool real,
+                                                    int lane, int wv, GatherLds &L) {
     constexpr int NE = gn_row_stride(K), kLive = gn_row_entries(K);
     constexpr int NE2 = gn_row_stride(2), kLive2 = gn_row_entries(2);
-    // hop 1
-    const int beg = blk_ptr[b], end = blk_ptr[b + 1];
-    const int rbeg = rblk_ptr[b], rend = rblk_ptr[b + 1];
-    if (end - beg > 256 || rend - rbeg > 64)
-        return gather_block_list<K>(partial, blk_ptr, blk_ent, b, lane, wv) + gather_block_list<2>(rpartial, rblk_ptr, rblk_ent, b, lane, wv);
     const int ia = (lane % 36) / 6, ib = lane % 6;
-    __shared__ int sLiveD[4][256];
-    __shared__ int sLiveR[4][64];
-    // hop 2: entries
-    int ent[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) ent[u] = beg + 64 * u + lane < end ? blk_ent[beg + 64 * u + lane] : -1;
-    const int rent = rbeg + lane < rend ? rblk_ent[rbeg + lane] : -1;
-    // hop 3: live flags
-    bool on[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) on[u] = ent[u] >= 0 && partial[(size_t)(ent[u] / (K * K)) * NE + kLive] != 0.0;
-    const bool ron = rent >= 0 && rpartial[(size_t)(rent / 4) * NE2 + kLive2] != 0.0;
-    int nl = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const unsigned long long m = __ballot(on[u]);
-        if (on[u]) sLiveD[wv][nl + __popcll(m & ((1ull << lane) - 1ull))] = ent[u];
-        nl += __popcll(m);
-    }
-    const unsigned long long rm = __ballot(ron);
-    if (ron) sLiveR[wv][__popcll(rm & ((1ull << lane) - 1ull))] = rent;
-    const int rnl = __popcll(rm);
-    __builtin_amdgcn_wave_barrier();
     double acc = 0.0, racc = 0.0;
-    if (lane < 36) {
-        auto value = [&](int e) {
-            const int row = e / (K * K), pr = e - row * (K * K);
-            return partial[(size_t)row * NE + gn_gram_index(K, pr / K, pr % K, ia, ib)];
-        };
-        auto rvalue = [&](int e) {
-            const int row = e / 4, pr = e - row * 4;
-            return rpartial[(size_t)row * NE2 + gn_gram_index(2, pr / 2, pr % 2, ia, ib)];
-        };
-        // hop 4: values of both lists in flight together (regulariser: at most 4 per batch; usually 1-2 entries)
-        double rv[4];
-        const int r0 = rnl < 4 ? rnl : 4;
+    int nl = 0;
+    bool coop = false;
+    if (real) {
+        // hop 1
+        GT_STAMP(0);
+        const int beg = blk_ptr[b], end = blk_ptr[b + 1];
+        const int rbeg = rpartial ? rblk_ptr[b] : 0, rend = rpartial ? rblk_ptr[b + 1] : 0;
+        GT_STAMP(1);
+        if (end - beg > 256 || rend - rbeg > 64) {
+            acc = gather_block_list<K>(partial, live, blk_ptr, blk_ent, b, lane, wv);
+            if (rpartial) racc = gather_block_list<2>(rpartial, nullptr, rblk_ptr, rblk_ent, b, lane, wv);
+        } else {
+            // hop 2: entries
+            int ent[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rv[u] = u < r0 ? rvalue(sLiveR[wv][u]) : 0.0;
-        int q = 0;
-        for (; q + 15 < nl; q += 16) {
-            double v[16];
+            for (int u = 0; u < 4; ++u) ent[u] = beg + 64 * u + lane < end ? blk_ent[beg + 64 * u + lane] : -1;
+            const int rent = rbeg + lane < rend ? rblk_ent[rbeg + lane] : -1;
+            GT_STAMP(2);
+            // hop 3: live flags
+            // (flags first, tests after: `ent >= 0 && flag != 0` in one expression makes every load wait for the one before)
+            double flag[4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = value(sLiveD[wv][q + u]);
+            for (int u = 0; u < 4; ++u) flag[u] = ent[u] >= 0 ? (live ? live[ent[u] / (K * K)] : partial[(size_t)(ent[u] / (K * K)) * NE + kLive]) : 0.0;
+            const double rflag = rent >= 0 ? rpartial[(size_t)(rent / 4) * NE2 + kLive2] : 0.0;
+            bool on[4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc += v[u];
+            for (int u = 0; u < 4; ++u) on[u] = flag[u] != 0.0;
+            const bool ron = rflag != 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long m = __ballot(on[u]);
+                if (on[u]) L.liveD[wv][nl + __popcll(m & ((1ull << lane) - 1ull))] = ent[u];
+                nl += __popcll(m);
+            }
+            const unsigned long long rm = __ballot(ron);
+            if (ron) L.liveR[wv][__popcll(rm & ((1ull << lane) - 1ull))] = rent;
+            const int rnl = __popcll(rm);
+            __builtin_amdgcn_wave_barrier();
+            GT_STAMP(3);
+            coop = nl > kCoopList;
+            // hop 4: values of both lists in flight together (regulariser: usually 1-2 entries)
+            if (rnl > 0) racc = gather_rounds<2>(rpartial, L.liveR[wv], 0, rnl, lane, L.comb[wv]);
+            if (!coop && nl > 0) acc = gather_rounds<K>(partial, L.liveD[wv], 0, nl, lane, L.comb[wv]);
+#ifdef DFH_GATHER_TRACE
+            if (lane == 0 && b < 8192)
+                g_gather_trace[b][5] = (unsigned long long)(end - beg) | ((unsigned long long)nl << 16) | ((unsigned long long)(rend - rbeg) << 32) | ((unsigned long long)rnl << 48);
+#endif
         }
-        for (; q + 3 < nl; q += 4) {
-            double v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = value(sLiveD[wv][q + u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc += v[u];
-        }
-        for (; q < nl; ++q) acc += value(sLiveD[wv][q]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (u < r0) racc += rv[u];
-        for (int u = 4; u < rnl; ++u) racc += rvalue(sLiveR[wv][u]);
     }
-    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) L.coop[wv] = coop ? nl : 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int n = L.coop[w];
+        if (n > 0) {                                              // (workgroup-uniform)
+            const int seg = (n + 3) / 4, q0 = wv * seg, q1 = min(n, q0 + seg);
+            const double sum = q0 < q1 ? gather_rounds<K>(partial, L.liveD[w], q0, q1, lane, L.comb[wv]) : 0.0;
+            if (lane < 36) L.part[w][wv][lane] = sum;
+        }
+    }
+    __syncthreads();
+    if (coop && lane < 36) acc = ((L.part[wv][0][lane] + L.part[wv][1][lane]) + L.part[wv][2][lane]) + L.part[wv][3][lane];
+    GT_STAMP(4);
     return acc + racc;
 }
 
 // one wave: J^T r of node a from its list; the total for unknown i ends up in lanes 0..5
 template <int K>
-__device__ __forceinline__ double gather_node_list(const double *__restrict__ partial, const int *__restrict__ node_ptr,
+__device__ __forceinline__ double gather_node_list(const double *__restrict__ partial, const double *__restrict__ live,
+                                                   const int *__restrict__ node_ptr,
                                                    const int *__restrict__ node_ent, int a, int lane, int wv) {
     constexpr int NUP = gn_row_gram(K), NE = gn_row_stride(K), kLive = gn_row_entries(K);
     double acc = 0.0;
@@ -1076,16 +1231,26 @@ __device__ __forceinline__ double gather_node_list(const double *__restrict__ pa
         // ten at a time (lane group j takes the j-th of each ten) -- one value hop per ten entries
         const int n = min(64, end - base);
         int mine = lane < n ? node_ent[base + lane] : -1;
-        if (mine >= 0 && partial[(size_t)(mine / K) * NE + kLive] == 0.0) mine = -1;
+        const double flag = mine >= 0 ? (live ? live[mine / K] : partial[(size_t)(mine / K) * NE + kLive]) : 0.0;
+        if (flag == 0.0) mine = -1;
         const unsigned long long live = __ballot(mine >= 0);
         if (mine >= 0) sLive[wv][__popcll(live & ((1ull << lane) - 1ull))] = mine;
         __builtin_amdgcn_wave_barrier();
         const int nl = __popcll(live);
         if (j < 10) {
-            for (int m = j; m < nl; m += 10) {
-                const int ent = sLive[wv][m];
-                const int row = ent / K, slot = ent - row * K;
-                acc += partial[(size_t)row * NE + NUP + slot * 6 + i];
+            for (int m0 = j; m0 < nl; m0 += 80) {               // eight loads in flight per lane (absent entries add 0.0)
+                int e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = sLive[wv][min(m0 + 10 * u, nl - 1)];
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = e[u] / K, slot = e[u] - row * K;
+                    const double *src = partial + (size_t)row * NE + NUP + slot * 6 + i;
+                    v[u] = m0 + 10 * u < nl ? *src : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1125,7 +1290,8 @@ struct RegLists {
 };
 
 template <int K>
-__global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict__ partial, int n_rows, const int *__restrict__ blk_ptr,
+__global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict__ partial, const double *__restrict__ live, int n_rows,
+                                                        const int *__restrict__ blk_ptr,
                                                         const int *__restrict__ blk_ent, int n_blocks,
                                                         const int *__restrict__ node_ptr, const int *__restrict__ node_ent,
                                                         int n_nodes, double *__restrict__ vals, double *__restrict__ rhs,
@@ -1143,20 +1309,21 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
         if (part_of != only_part) return;
     }
     if ((int)blockIdx.x < nbw) {
-        const int b = (int)blockIdx.x * 4 + wv;
-        if (b >= n_blocks) return;
-        double acc;
-        if (rl.partial) acc = gather_block_both<K>(partial, blk_ptr, blk_ent, rl.partial, rl.blk_ptr, rl.blk_ent, b, lane, wv);
-        else acc = gather_block_list<K>(partial, blk_ptr, blk_ent, b, lane, wv);
-        if (lane < 36) {
+        __shared__ GatherLds L;
+        // a workgroup's four blocks are a quarter of the block range apart: neighbouring blocks are the same node's row
+        // and have long lists together, which one workgroup would walk alone
+        const int b = wv * nbw + (int)blockIdx.x;
+        const bool real = b < n_blocks;
+        const double acc = gather_block_both<K>(partial, live, blk_ptr, blk_ent, rl.partial, rl.blk_ptr, rl.blk_ent, b, real, lane, wv, L);
+        if (real && lane < 36) {
             double *dst = vals + 36 * (size_t)b + lane;
             *dst = accumulate ? *dst + acc : acc;
         }
     } else if ((int)blockIdx.x < nbw + nrw) {
         const int a = ((int)blockIdx.x - nbw) * 4 + wv;
         if (a >= n_nodes) return;
-        double tot = gather_node_list<K>(partial, node_ptr, node_ent, a, lane, wv);
-        if (rl.partial) tot = tot + gather_node_list<2>(rl.partial, rl.node_ptr, rl.node_ent, a, lane, wv);
+        double tot = gather_node_list<K>(partial, live, node_ptr, node_ent, a, lane, wv);
+        if (rl.partial) tot = tot + gather_node_list<2>(rl.partial, nullptr, rl.node_ptr, rl.node_ent, a, lane, wv);
         if (lane < 6) rhs[6 * a + lane] = accumulate ? rhs[6 * a + lane] + tot : tot;
     } else {
         double c0, c1;
@@ -2128,7 +2295,7 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
     const int n_tiles = (n_samples + kTile - 1) / kTile;
     // planned build: the regulariser's pair rows ride along in the data-row launch (they only write partial_reg)
     const bool reg_in_data_launch = planned_reg && node_nbr && rw != 0.0 && n_samples > 0 && !getenv("DFH_GN_REG_OWN_LAUNCH");
-    double *tile_cost = planned && partial ? partial + (size_t)n_rows * gn_row_stride(knn) : nullptr;   // 2 doubles per tile, behind the rows
+    double *tile_cost = planned && partial ? partial + (size_t)n_rows * gn_row_stride(knn) : nullptr;   // 2 doubles per tile, behind the rows; then one live flag per row
     if (planned) {
         // every block / rhs entry / cost is written by the gather, and every row of `partial` by the tile pass (rows
         // without a valid sample this iteration are zeroed there): nothing to clear
@@ -2183,7 +2350,7 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
         dim3 grid((unsigned)((n_blocks + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
 #define DFH_GATHER(KK)                                                                                              \
     case KK:                                                                                                        \
-        hipLaunchKernelGGL(gn_gather_kernel<KK>, grid, block, 0, s, partial, n_rows, blk_ptr, blk_ent, n_blocks, node_ptr,  \
+        hipLaunchKernelGGL(gn_gather_kernel<KK>, grid, block, 0, s, partial, tile_cost + 2 * (size_t)n_tiles, n_rows, blk_ptr, blk_ent, n_blocks, node_ptr,  \
                            node_ent, n_nodes, vals, rhs, cost_count, tile_cost, n_tiles, 2, false, dbg_part, rl);   \
         break
         switch (knn) {
@@ -2199,7 +2366,7 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
                                node_w, rw, row_ptr, col, vals, rhs, cost_count, planned_reg ? partial_reg : nullptr);
         if (planned_reg && !reg_in_gather) {
             dim3 grid((unsigned)((n_blocks + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
-            hipLaunchKernelGGL(gn_gather_kernel<2>, grid, block, 0, s, partial_reg, n, rblk_ptr, rblk_ent, n_blocks, rnode_ptr,
+            hipLaunchKernelGGL(gn_gather_kernel<2>, grid, block, 0, s, partial_reg, (const double *)nullptr, n, rblk_ptr, rblk_ent, n_blocks, rnode_ptr,
                                rnode_ent, n_nodes, vals, rhs, cost_count, partial_reg + gn_row_gram(2) + 12, n, gn_row_stride(2), true, dbg_part,
                                RegLists{});
         }
@@ -2431,6 +2598,18 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }
+
+#ifdef DFH_BUILD_TRACE
+int dfh_debug_build_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dfh::g_build_trace), sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef DFH_GATHER_TRACE
+int dfh_debug_gather_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dfh::g_gather_trace), sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef DFH_PCG_TRACE
 int dfh_debug_pcg_trace(unsigned long long *out) {

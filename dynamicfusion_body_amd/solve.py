@@ -406,7 +406,7 @@ class WarpSolver:
                                               self.node_ent.data_ptr(), unc.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                                               current_stream_ptr()), "dfh_gn_plan_build")
         ne = int(self.lib.dfh_gn_partial_doubles(k))
-        self.partial = torch.empty(max(1, R * ne) + 2 * n_tiles, dtype=torch.float64, device=dev)   # rows | {cost, count} per tile
+        self.partial = torch.empty(max(1, R * ne) + 2 * n_tiles + R, dtype=torch.float64, device=dev)   # rows | {cost, count} per tile | live flag per row
         self._pair_keys = None                                         # (computed on demand: only a growing pattern needs them)
         if reg:
             self._build_reg_plan(keys)
@@ -465,7 +465,7 @@ class WarpSolver:
         if reg:
             self._build_reg_plan(keys)
         ne = int(self.lib.dfh_gn_partial_doubles(k))
-        self.partial = torch.empty(max(1, R * ne) + 2 * ((S + 255) // 256), dtype=torch.float64, device=dev)   # rows | {cost, count} per tile
+        self.partial = torch.empty(max(1, R * ne) + 2 * ((S + 255) // 256) + R, dtype=torch.float64, device=dev)   # rows | {cost, count} per tile | live flag per row
         if R * k * k >= 2 ** 31:
             raise ValueError("too many sample runs for 32-bit plan entries")
         return bool(covered) if not reg else True          # (reg=True is the call that follows a pattern build: covered by construction)

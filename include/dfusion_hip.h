@@ -246,13 +246,13 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
  * callers that prepare a plan once per frame (samples and their node tuples are static while the warp field
  * moves).  Samples sorted by node tuple; a "row" = a maximal run of equal tuples inside one 256-sample tile:
  *   run_id[s]           row of sample s (n_rows rows);  partial: scratch of n_rows x dfh_gn_partial_doubles(knn)
- *                       + 2 x ceil(n_samples / 256) doubles
+ *                       + 2 x ceil(n_samples / 256) + n_rows doubles (the rows | {cost, count} per tile | one live flag per row)
  *   blk_ptr (n_blocks+1), blk_ent   for block b the entries row * knn^2 + sa * knn + sb (slots sa, sb of the
  *                                   row's tuple hold the block's row node and column node), any fixed order
  *   node_ptr (n_nodes+1), node_ent  for node a the entries row * knn + slot
  * The tile pass stores each row's {Gram matrix as whole 6x6 sub-blocks for the slot pairs sa <= sb, 36 contiguous doubles each |
- * J^T r | cost | count | live flag} (rows padded to whole 64-byte lines; rows without a valid sample in this iteration are flagged
- * dead and skipped); a gather pass adds them per block, reading one contiguous sub-block per list entry.
+ * J^T r | cost | count} (rows padded to whole 64-byte lines; rows without a valid sample in this iteration are flagged dead in the
+ * dense flag array and skipped); a gather pass adds them per block, reading one contiguous sub-block per list entry.
  * partial_reg (n_nodes * knn rows of dfh_gn_partial_doubles(2) doubles) + rblk_ptr / rblk_ent / rnode_ptr / rnode_ent: the same for the
  * regulariser, a pair (i, node_nbr[i*knn+slot]) being a 2-node row (entries row * 4 + sa * 2 + sb, row * 2 + slot);
  * partial_reg == NULL keeps the regulariser on atomics.

@@ -200,6 +200,72 @@ def test_pcg_paths_agree_and_are_deterministic(golden, monkeypatch):
     assert torch.equal(x1, sv.dx)
 
 
+@pytest.mark.parametrize("multilaunch", [False, True])
+def test_pcg_rows_wider_than_the_register_cache(multilaunch, monkeypatch):
+    """dfh_pcg_solve through the C ABI on a synthetic block-sparse SPD system whose rows have 6 .. 48 blocks: the
+    persistent kernel keeps 30 blocks of a row in registers (three per lane slot) and walks the rest from memory,
+    waiting for every neighbour value on its own -- the golden systems have no such row.  Checked against a dense solve."""
+    import ctypes
+    from dynamicfusion_body_amd import _lib
+    from dynamicfusion_body_amd.device import current_stream_ptr
+    lib = _lib.load()
+    if multilaunch:
+        monkeypatch.setenv("DFH_PCG_MULTILAUNCH", "1")
+    else:
+        monkeypatch.delenv("DFH_PCG_MULTILAUNCH", raising=False)
+    rng = np.random.default_rng(11)
+    N = 48
+    adj = np.eye(N, dtype=bool)
+    adj[:4, :] = True                                            # four hubs: rows of 48 blocks
+    for a in range(N):
+        adj[a, (a + 1) % N] = adj[a, (a - 1) % N] = True         # a ring
+    adj[10, 5:30] = True                                         # 25-ish blocks: two full cache rounds and a part of the third
+    adj[20, 32:40] = True                                        # 15-ish blocks
+    adj = adj | adj.T
+    A = np.zeros((6 * N, 6 * N))
+    for a in range(N):
+        for b in range(a + 1, N):
+            if adj[a, b]:
+                blk = rng.standard_normal((6, 6))
+                A[6 * a:6 * a + 6, 6 * b:6 * b + 6] = blk
+                A[6 * b:6 * b + 6, 6 * a:6 * a + 6] = blk.T
+    for a in range(N):
+        d = rng.standard_normal((6, 6))
+        A[6 * a:6 * a + 6, 6 * a:6 * a + 6] = d @ d.T
+    A += np.diag(np.abs(A).sum(axis=1) * 0.6)                    # SPD, condition number of a few tens
+    rhs = rng.standard_normal(6 * N)
+    row_ptr, col, vals = [0], [], []
+    for a in range(N):
+        for b in np.flatnonzero(adj[a]):
+            col.append(int(b))
+            vals.append(A[6 * a:6 * a + 6, 6 * b:6 * b + 6].copy())
+        row_ptr.append(len(col))
+    widths = np.diff(row_ptr)
+    assert widths.max() == 48 and widths.min() <= 8 and ((widths > 10) & (widths <= 20)).any() and ((widths > 20) & (widths <= 30)).any()
+    dev = "cuda"
+    rp = torch.tensor(row_ptr, dtype=torch.int32, device=dev)
+    cl = torch.tensor(col, dtype=torch.int32, device=dev)
+    vl = torch.from_numpy(np.stack(vals)).to(dev).contiguous()
+    rh = torch.from_numpy(rhs).to(dev)
+    iters = 120
+    nbytes = lib.dfh_pcg_workspace_bytes(N, iters)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
+    xs = []
+    for _ in range(2):
+        x = torch.full((6 * N,), float("nan"), dtype=torch.float64, device=dev)
+        _lib.check(lib.dfh_pcg_solve(rp.data_ptr(), cl.data_ptr(), vl.data_ptr(), rh.data_ptr(), N, iters, 0.0, 0.0, x.data_ptr(),
+                                     ws.data_ptr(), ws.numel() * 8, current_stream_ptr()), "dfh_pcg_solve")
+        torch.cuda.synchronize()
+        xs.append(x.cpu().numpy())
+    xo = np.linalg.solve(A, -rhs)
+    assert np.abs(xs[0] - xo).max() <= 1e-9 * np.abs(xo).max()
+    if not multilaunch:
+        assert np.array_equal(xs[0], xs[1])                      # the persistent path has no atomics: same bits
+    aborted = ctypes.c_long(-1)
+    _lib.check(lib.dfh_pcg_status(current_stream_ptr(), ctypes.byref(aborted)), "dfh_pcg_status")
+    assert aborted.value == 0
+
+
 def test_persistent_pcg_timeout_is_reported(golden, monkeypatch):
     """A grid barrier of the persistent PCG that does not complete within its spin bound makes every workgroup leave
     (x = NaN, node_dq untouched) -- and the host must hear about it: the next synchronising call raises DfhTimeout,
@@ -236,6 +302,41 @@ def test_persistent_pcg_timeout_is_reported(golden, monkeypatch):
         assert (sv.dx - x_fallback).abs().max() <= 1e-9 * x_fallback.abs().max()
     finally:
         lib.dfh_pcg_set_mode(0)
+
+
+def test_planned_gather_walks_lists_of_every_length():
+    """Few nodes and many samples: the block lists of the planned build run from a handful of rows to thousands (the
+    golden scene's longest has a few dozen).  Lists of up to 12 live rows are added by their own wave, longer ones by the
+    four waves of the workgroup together, those beyond 256 entries by the chunked walk -- all against the dense oracle."""
+    rng = np.random.default_rng(21)
+    N, k, S = 40, 4, 24000
+    npos = rng.uniform(0, 40, size=(N, 3))
+    nw = rng.uniform(8, 14, size=N)
+    tw = rng.standard_normal((N, 6)) * np.array([0.02, 0.02, 0.02, 0.3, 0.3, 0.3])
+    ndq = G.apply_twists(np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1)), tw)
+    verts = np.concatenate([npos, rng.uniform(0, 40, size=(S - N, 3))])          # the first N samples are the nodes: nbr[:N] = node graph
+    norms = rng.standard_normal((S, 3)); norms /= np.linalg.norm(norms, axis=1, keepdims=True)
+    corr = verts + rng.standard_normal((S, 3)) * 0.3
+    nbr = O.knn_bruteforce(verts, npos, k)
+    vidx = np.arange(N)
+    lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+    valid = rng.random(S) < 0.6
+    sv = make_solver(npos, ndq, nw, nbr, vidx, verts, norms, corr, k, valid=valid)
+    sv.build(lw, 0.0)
+    lens = np.diff(sv.blk_ptr.cpu().numpy())
+    assert lens.max() > 256 and ((lens > 12) & (lens <= 256)).any() and (lens <= 12).any()
+    A, b = sv.dense_normal_equations()
+    cost, cnt = sv.cost()
+    r, J = G.data_residual_jacobian(ndq, verts, norms, corr, nbr, npos, nw, lw)
+    rho, nb, Ji, Jj = G.reg_residual_jacobian(ndq, vidx, nbr, npos, nw, 1.0)
+    Ao, bo, co = G.assemble_dense(N, r, J, nbr, rho * 0, nb, Ji * 0, Jj * 0, valid=valid)
+    assert cnt == int(valid.sum())
+    assert abs(cost - co) <= 1e-12 * co
+    assert np.abs(A - Ao).max() <= 1e-11 * np.abs(Ao).max()
+    assert np.abs(b - bo).max() <= 1e-11 * np.abs(bo).max()
+    s1 = sv.system.clone()
+    sv.build(lw, 0.0)
+    assert torch.equal(s1, sv.system)                                             # no atomics anywhere: same bits
 
 
 def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, monkeypatch):

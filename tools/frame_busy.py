@@ -24,3 +24,16 @@ for w, b, n, by in out[-4:]:
 w, b, n, by = out[-1]
 for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:14]:
     print("   %-42s %.3f ms" % (k, v / 1e6))
+# idle gaps of the last frame: where the device waits for the host
+seg = rows[fstart[-2]:fstart[-1] + 1]
+gaps = []
+for a, b in zip(seg[:-1], seg[1:]):
+    g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3
+    if g > 8.0:
+        short = lambda r: r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "")[-34:]
+        gaps.append((g, short(a), short(b)))
+print("idle gaps > 8 us in the last frame: %d, total %.0f us" % (len(gaps), sum(g for g, _, _ in gaps)))
+for g, a, b in gaps:
+    print("   %6.1f us after %-36s before %s" % (g, a, b))
+small = sum(max(0.0, (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3) for a, b in zip(seg[:-1], seg[1:])) - sum(g for g, _, _ in gaps)
+print("   all other gaps together: %.0f us over %d launches" % (small, len(seg) - 1))

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "dfh_pcg_solve_update": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp, _dbl, _vp]),
     "dfh_pcg_set_mode": (_int, [_int]),
     "dfh_pcg_status": (_int, [_vp, ctypes.POINTER(ctypes.c_long)]),
+    "dfh_pcg_status_peek": (_int, [_vp, ctypes.POINTER(ctypes.c_long)]),
     "dfh_apply_twist": (_int, [_vp, _vp, _int, _dbl, _vp]),
     "dfh_surface_workspace_bytes": (ctypes.c_size_t, [_c_int_p]),
     "dfh_surface_count": (_int, [_vp, _vp, _int, _c_int_p, _dbl, _vp, ctypes.c_size_t, _vp, _vp]),
@@ -134,12 +135,23 @@ def check(rc, what):
         raise DfhError("%s failed (%d): %s" % (what, rc, msg))
 
 
+_darr_cache = {}
+
+
 def darr(values, n):
+    """n doubles as a ctypes array.  The same small numpy arrays (intrinsics, poses) are passed on every launch of a frame:
+    conversions are remembered by content (a few entries; the returned arrays are read-only by convention)."""
     import numpy as np
     a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))
     if a.size != n:
         raise ValueError("expected %d values, got %d" % (n, a.size))
-    return (ctypes.c_double * n)(*a.tolist())
+    key = a.tobytes()
+    hit = _darr_cache.get(key)
+    if hit is None:
+        if len(_darr_cache) > 256:
+            _darr_cache.clear()
+        hit = _darr_cache[key] = (ctypes.c_double * n).from_buffer_copy(key)
+    return hit
 
 
 def iarr(values):

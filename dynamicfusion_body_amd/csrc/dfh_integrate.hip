@@ -595,6 +595,22 @@ __global__ __launch_bounds__(256) void integrate_depth_multi_brick_kernel(float 
     }
 }
 
+// Parameters of up to kParamChunk views from the kernel-argument segment into device memory (see dfh_integrate_depth_multi)
+constexpr int kParamChunk = 6;
+struct ParamChunk {
+    IntegrateParams v[kParamChunk];
+};
+static_assert(sizeof(IntegrateParams) % 8 == 0 && sizeof(ParamChunk) + 24 <= 4096, "the chunk must fit the kernel-argument segment");
+__global__ __launch_bounds__(256) void upload_params_kernel(IntegrateParams *dst, const ParamChunk c, int n) {
+    // (read through the segment pointer: indexing the by-value struct dynamically would copy it to scratch memory first)
+    typedef const unsigned long long __attribute__((address_space(4))) *KernArgWords;
+    KernArgWords ka = (KernArgWords)__builtin_amdgcn_kernarg_segment_ptr() + 1;                                          // behind `dst`
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(dst);
+    const int words = n * (int)(sizeof(IntegrateParams) / 8);
+    for (int i = threadIdx.x; i < words; i += 256) out[i] = ka[i];
+    (void)c;
+}
+
 // Max-depth pyramid of up to kMaxViews depth maps: blockIdx.z = view, one workgroup per 32 x 32 pixel tile, levels 1..5.
 struct PyrViews {
     const void *depth[kMaxViews];
@@ -1019,7 +1035,14 @@ extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype
     }
     vp.n = n_views;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    DFH_HIP_CHECK(hipMemcpyAsync(workspace, hp, sizeof(IntegrateParams) * n_views, hipMemcpyHostToDevice, s));   // pageable source: staged before the call returns
+    // the views' parameters travel as kernel arguments of a tiny launch that writes them into the workspace: a hipMemcpyAsync
+    // from this (pageable) stack array is staged by the runtime and left the device idle for ~40 us per call
+    for (int v0 = 0; v0 < n_views; v0 += kParamChunk) {
+        ParamChunk c;
+        const int n = n_views - v0 < kParamChunk ? n_views - v0 : kParamChunk;
+        for (int v = 0; v < n; ++v) c.v[v] = hp[v0 + v];
+        hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, s, static_cast<IntegrateParams *>(workspace) + v0, c, n);
+    }
     const IntegrateParams &p = hp[0];
     const IntegrateParams *dv = static_cast<const IntegrateParams *>(workspace);
     if (bricks) {

@@ -1720,11 +1720,15 @@ __device__ __forceinline__ double sum6_f64(double v) {         // lanes 0..5 -> 
 struct PcgAbort {
     unsigned *flag;                      // this solve's abort flag (zero before the launch); flag[1]: "already counted"
     unsigned long long *count;           // the library's sticky per-device counter of timed-out solves
+    unsigned *host_flag;                 // word in pinned host memory, set when the counter is bumped (dfh_pcg_status_peek)
     unsigned spin_limit;
     __device__ __forceinline__ bool raised() const { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
     __device__ __forceinline__ void raise() const {                                        // one count per timed-out solve
         __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (atomicExch(flag + 1, 1u) == 0u) atomicAdd(count, 1ull);
+        if (atomicExch(flag + 1, 1u) == 0u) {
+            atomicAdd(count, 1ull);
+            if (host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 };
 
@@ -1817,12 +1821,12 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
                                                         const double *__restrict__ rhs, const PcgParams prm, int iters,
                                                         double *__restrict__ x, double *ring /* 4 x {u, v, t} x 6N */, double *part,
                                                         unsigned *abort_flag, unsigned spin_limit, unsigned long long *abort_count,
-                                                        double *__restrict__ update_dq, double update_step) {
+                                                        unsigned *abort_host, double *__restrict__ update_dq, double update_step) {
     // update_dq != NULL: the row's wave also applies its twist, update_dq[a] <- exp(update_step * x_a) (x) update_dq[a]
     // abort_count is read by dfh_pcg_status() at the caller's next synchronisation point
     __shared__ BarrierLds2 lds;
     __shared__ WaveLds wlds[MAXT / 64];
-    const PcgAbort ab{abort_flag, abort_count, spin_limit};
+    const PcgAbort ab{abort_flag, abort_count, abort_host, spin_limit};
     const int N = prm.N;
     const size_t N6 = 6 * (size_t)N;
     const int lane = threadIdx.x & 63;
@@ -2461,8 +2465,11 @@ size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
 // ---- persistent-PCG bookkeeping ---------------------------------------------------------------------------------
 // g_pcg_mode: 0 = auto (persistent kernel when co-residency holds, see pcg_solve_impl), 2 = always the two-launches-per-
 // iteration path.  g_abort_count[dev]: device counter the persistent kernel bumps when a barrier times out.
-namespace dfh { int g_pcg_mode = 0; unsigned long long *g_abort_count[64] = {nullptr}; }
+// g_abort_host[dev]: a word of pinned host memory the kernel sets with the counter, so that the host can ask "anything
+// timed out?" without a device call (dfh_pcg_status_peek).
+namespace dfh { int g_pcg_mode = 0; unsigned long long *g_abort_count[64] = {nullptr}; unsigned *g_abort_host[64] = {nullptr}; }
 using dfh::g_abort_count;
+using dfh::g_abort_host;
 
 static int pcg_abort_counter(unsigned long long **out) {
     int dev = 0;
@@ -2472,6 +2479,13 @@ static int pcg_abort_counter(unsigned long long **out) {
         unsigned long long *p = nullptr;
         DFH_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), sizeof(unsigned long long)));
         DFH_HIP_CHECK(hipMemset(p, 0, sizeof(unsigned long long)));
+        unsigned *h = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&h), sizeof(unsigned), hipHostMallocMapped) == hipSuccess && h) {
+            *h = 0u;
+            g_abort_host[dev] = h;                          // (without it the peek always takes the synchronising path)
+        } else {
+            (void)hipGetLastError();
+        }
         g_abort_count[dev] = p;
     }
     *out = g_abort_count[dev];
@@ -2493,12 +2507,24 @@ int dfh_pcg_status(void *stream, long *aborted_solves_out) {
     if (dev >= 0 && dev < 64 && g_abort_count[dev]) {
         DFH_HIP_CHECK(hipMemcpy(&n, g_abort_count[dev], sizeof(n), hipMemcpyDeviceToHost));
         if (n) DFH_HIP_CHECK(hipMemset(g_abort_count[dev], 0, sizeof(n)));
+        if (g_abort_host[dev]) *g_abort_host[dev] = 0u;
     }
     if (aborted_solves_out) *aborted_solves_out = (long)n;
     if (n)
         return fail(DFH_E_TIMEOUT, "persistent PCG: %llu solve(s) timed out in a grid barrier (workgroups not co-resident?); x = NaN, "
                                    "node_dq was left unchanged", n);
     return DFH_OK;
+}
+
+int dfh_pcg_status_peek(void *stream, long *aborted_solves_out) {
+    using namespace dfh;
+    int dev = 0;
+    DFH_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && (!g_abort_count[dev] || (g_abort_host[dev] && *static_cast<volatile unsigned *>(g_abort_host[dev]) == 0u))) {
+        if (aborted_solves_out) *aborted_solves_out = 0;    // no persistent solve yet, or none that has completed timed out
+        return DFH_OK;
+    }
+    return dfh_pcg_status(stream, aborted_solves_out);
 }
 
 static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
@@ -2566,7 +2592,15 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
             }
         }
     }
+    unsigned *abort_host = nullptr;
     if (persistent) {
+        int dev = 0;
+        DFH_HIP_CHECK(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && g_abort_host[dev] &&
+            hipHostGetDevicePointer(reinterpret_cast<void **>(&abort_host), g_abort_host[dev], 0) != hipSuccess) {
+            (void)hipGetLastError();
+            abort_host = nullptr;
+        }
         DFH_HIP_CHECK(hipMemsetAsync(scal, 0, sizeof(double) * (n_scal + 12 * N6), s));
         unsigned spin_limit = kSpinLimit;
         if (const char *e = getenv("DFH_PCG_SPIN_LIMIT")) spin_limit = (unsigned)strtoul(e, nullptr, 10);
@@ -2574,10 +2608,10 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
         double *part = scal + 3 * ((size_t)iters + 2);                                    // (2 per iteration + 1) reductions x nblk slots
         if (wpb <= 8)
             hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, ring, part,
-                               flag, spin_limit, abort_count, update_dq, update_step);
+                               flag, spin_limit, abort_count, abort_host, update_dq, update_step);
         else
             hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, ring, part,
-                               flag, spin_limit, abort_count, update_dq, update_step);
+                               flag, spin_limit, abort_count, abort_host, update_dq, update_step);
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }

@@ -11,8 +11,16 @@ def require_gpu():
         raise _lib.DfhError("no HIP device visible: this path only runs on the GPU (no CPU fallback)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def current_stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device (every launch asks: torch.cuda.current_stream() builds a
+    Stream object, ~8 us; the raw queries are well under 1 us)."""
+    if _raw_stream is None or _raw_device is None:
+        return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(_raw_device())
 
 
 def dtype_code(t):

@@ -261,7 +261,7 @@ class SlabFrame:
         mark("tsdf_update")
         n = self.refresh_samples()
         mark("samples")
-        self.fs.solver.check_status()          # the sample count's read-back has synchronised: a timed-out PCG raises here
+        self.fs.solver.check_status(completed_only=True)   # the sample count's read-back has synchronised: a timed-out PCG raises here
         if update_graph:
             if self.update_graph():
                 n = self.fs.solver.S

@@ -205,13 +205,16 @@ class WarpSolver:
             # persistent PCG's workgroups is not guaranteed across processes -> two launches per iteration, no grid barrier
             _lib.check(self.lib.dfh_pcg_set_mode(2), "dfh_pcg_set_mode")
 
-    def check_status(self):
+    def check_status(self, completed_only=False):
         """Raise DfhError if a persistent PCG solve since the last check timed out in its grid barrier (x = NaN, node_dq
-        left as it was).  Synchronises; called where the host synchronises anyway (cost(), the end of SlabFrame.step).
-        After a time-out this process takes the multi-launch PCG path."""
+        left as it was).  Synchronises; called where the host synchronises anyway (cost()).  completed_only: look only at
+        the solves that have already completed and do not touch the device when none of them timed out (the end of
+        SlabFrame.step, right after the sample count's read-back).  After a time-out this process takes the multi-launch
+        PCG path."""
         import ctypes
         n = ctypes.c_long(0)
-        rc = self.lib.dfh_pcg_status(current_stream_ptr(), ctypes.byref(n))
+        fn = self.lib.dfh_pcg_status_peek if completed_only else self.lib.dfh_pcg_status
+        rc = fn(current_stream_ptr(), ctypes.byref(n))
         if rc != 0:
             self.lib.dfh_pcg_set_mode(2)
             _lib.check(rc, "dfh_pcg_status")

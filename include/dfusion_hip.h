@@ -326,6 +326,10 @@ int dfh_pcg_solve_update(const int *row_ptr, const int *col, double *vals, const
  * (*aborted_solves_out = how many; may be NULL).  Call it wherever the host synchronises anyway. */
 int dfh_pcg_set_mode(int mode);
 int dfh_pcg_status(void *stream, long *aborted_solves_out);
+/* The same answer for the solves that have COMPLETED, without touching the device when none of them timed out (the kernel
+ * also sets a word of pinned host memory): for callers that have just synchronised for a reason of their own (a count
+ * read back) and do not want a second device round trip per frame.  Falls back to dfh_pcg_status() when the word is set. */
+int dfh_pcg_status_peek(void *stream, long *aborted_solves_out);
 
 /* node_dq[a] <- exp(step * xi[a]) (x) node_dq[a]; exp = rotation exp(omega), translation v. */
 int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream);

@@ -289,6 +289,19 @@ def test_persistent_pcg_timeout_is_reported(golden, monkeypatch):
             sv.cost()
         assert torch.isnan(sv.dx).all() and torch.equal(sv.node_dq, dq0)  # no update was applied
         sv.check_status()                                                # the counter was cleared by the raise
+        sv.check_status(completed_only=True)
+        # the same through the host-side flag (what SlabFrame.step asks after its own synchronisation): silent while the
+        # timed-out solve is still in flight or none has happened, raising once it has completed
+        lib.dfh_pcg_set_mode(0)
+        sv.vals.copy_(v0)
+        monkeypatch.setenv("DFH_PCG_SPIN_LIMIT", "0")
+        sv.step(lw, rw, 0.5, 1e-3)
+        monkeypatch.delenv("DFH_PCG_SPIN_LIMIT")
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.DfhTimeout):
+            sv.check_status(completed_only=True)
+        sv.check_status(completed_only=True)                             # cleared
+        sv.check_status()
         # the process has fallen back to the multi-launch PCG: same system, sound answer
         sv.vals.copy_(v0)
         sv.build(lw, rw)

@@ -747,6 +747,11 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     double a_bh[8], a_nb = 1.0, a_pf[3] = {0, 0, 0}, a_c[3] = {0, 0, 0};
     D3 a_xp{0, 0, 0};
     bool a_ok = false;
+    // the sample's normal is only needed for its Jacobian row, but asking for it here takes a memory round trip out of that phase
+    double a_n[3] = {0.0, 0.0, 0.0};
+    if (ASSOC && tid < tile_n) {
+        a_n[0] = snrm[3 * (size_t)s]; a_n[1] = snrm[3 * (size_t)s + 1]; a_n[2] = snrm[3 * (size_t)s + 2];
+    }
     if (ASSOC && tid < tile_n) {
 #pragma unroll
         for (int j = 0; j < kKMaxS; ++j) {
@@ -789,8 +794,8 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         double Jrow[NJ];
         double r;
         if (ASSOC) {
-            r = data_row_from(node_dq, idx, w, K, p.lw.q, a_bh, a_nb, a_pf[0], a_pf[1], a_pf[2], a_xp, snrm[3 * (size_t)s],
-                              snrm[3 * (size_t)s + 1], snrm[3 * (size_t)s + 2], a_c[0], a_c[1], a_c[2], Jrow);
+            r = data_row_from(node_dq, idx, w, K, p.lw.q, a_bh, a_nb, a_pf[0], a_pf[1], a_pf[2], a_xp, a_n[0], a_n[1], a_n[2], a_c[0], a_c[1],
+                              a_c[2], Jrow);
         } else {
 #pragma unroll
             for (int j = 0; j < kKMaxS; ++j) {

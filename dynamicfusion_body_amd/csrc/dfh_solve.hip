@@ -1741,9 +1741,11 @@ struct PcgAbort {
 __device__ unsigned long long g_pcg_trace[64][16][12];
 #define PCG_STAMP(k) do { if (lane == 0 && tw >= 0 && it < 16) { g_pcg_trace[tw][it][k] = wall_clock64(); if (k == 0) { g_pcg_trace[tw][it][9] = clock64(); g_pcg_trace[tw][it][10] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); } } } while (0)
 #define GS_STAMP(k) do { if ((threadIdx.x & 63) == 0 && tr) tr[k] = wall_clock64(); } while (0)
+#define PRO_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == (DFH_PCG_TRACE) && blockIdx.x < 64) g_pcg_trace[blockIdx.x][15][k] = wall_clock64(); } while (0)
 #else
 #define PCG_STAMP(k) do {} while (0)
 #define GS_STAMP(k) do {} while (0)
+#define PRO_STAMP(k) do {} while (0)
 #endif
 
 // Two grid-wide sums in one pass; slots = 2 * gridDim.x doubles (workgroup b: 2b, 2b+1), zero bits before the launch.
@@ -1841,6 +1843,8 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
     const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63 idle in the SpMV
     const int beg = row ? row_ptr[a] : 0, end = row ? row_ptr[a + 1] : 0;
     const bool lead = row && lane < 6;
+    const double rhs_i = lead ? rhs[6 * a + lane] : 0.0;      // (asked for now: needed after the 6x6 inverse)
+    PRO_STAMP(0);
     // register cache of this row's blocks: lane (slot, i) holds row i of blocks beg+slot+10c; the diagonal block gets
     // its damping here (the damping lives in the matrix: it is also written back below)
     double Bc[kRowCache][6];
@@ -1861,6 +1865,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
                 }
         }
     }
+    PRO_STAMP(1);
     // block-Jacobi preconditioner: the damped diagonal block, from the register cache when it is there (six lanes hold
     // its rows: 36 shuffles instead of a binary search and a reload), else found and loaded the slow way
     double D[36];
@@ -1892,6 +1897,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
             vals[36 * (size_t)dblk + 7 * lane] = dv;
         }
     }
+    PRO_STAMP(2);
     double Mi[6];
     {
         double Di[36];
@@ -1904,6 +1910,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
             Mi[j] = lead ? v : 0.0;
         }
     }
+    PRO_STAMP(3);
     // The neighbours' published values of this lane's cached blocks (element i of node cj[c]); rows wider than the
     // cache read the rest of their neighbours one at a time (wait_for).
     double nu[kRowCache], nv[kRowCache], nt[kRowCache];
@@ -1992,11 +1999,13 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
     // phase regions: u at +0, v at +N6, t at +2 N6 (pointer arithmetic, not a table of pointers: the accesses stay
     // global_load/global_store; a generic pointer's flat accesses would also count on lgkmcnt and stall the LDS barriers)
     auto region = [&](int k) { return ring + (size_t)(k & 3) * 3 * N6; };
-    double xi = 0.0, ri = lead ? -rhs[6 * a + lane] : 0.0, pi = 0.0, si = 0.0, ti = 0.0;
+    double xi = 0.0, ri = lead ? -rhs_i : 0.0, pi = 0.0, si = 0.0, ti = 0.0;
     double ui = minv(ri);
     if (lead) st_agent(region(0) + 6 * a + lane, nz_bits(ui));
+    PRO_STAMP(4);
     request(region(0), false);
     await(region(0), false);
+    PRO_STAMP(5);
     double wi = spmv(nu, [&](size_t j6) { return wait_for(region(0) + j6); });
     double vi = minv(wi);
     if (lead) {
@@ -2006,6 +2015,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
     if (!mine) ui = __builtin_nan("");
     double gamma = 0.0, delta = 0.0;
     double g = sum6_f64(lead ? ri * ui : 0.0), d = sum6_f64(lead ? wi * ui : 0.0);
+    PRO_STAMP(6);
     double gamma_prev = 0.0, alpha_prev = 0.0;
 #ifdef DFH_PCG_TRACE
     const int tw = (threadIdx.x >> 6) == (DFH_PCG_TRACE) && blockIdx.x < 64 ? (int)blockIdx.x : -1;

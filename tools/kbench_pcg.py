@@ -68,6 +68,13 @@ if hasattr(sv.lib, "dfh_debug_pcg_trace") or os.environ.get("DFH_LIB_PATH"):
     tr = np.frombuffer(buf, dtype=np.uint64).reshape(64, 16, 12).astype(np.int64)
     print("shader clock during the solve: %.0f MHz (s_memtime ticks per s_memrealtime tick x 100 MHz)" % (
         100.0 * (tr[0, 8, 9] - tr[0, 1, 9]) / (tr[0, 8, 0] - tr[0, 1, 0])))
+    pro = tr[:, 15, :7]
+    ok = pro[:, 6] > 0
+    d = np.diff(pro[ok], axis=1) / 100.0
+    print("prologue, one wave per workgroup, median / max us: block loads %.2f / %.2f | diagonal block to registers %.2f / %.2f | 6x6 inverse %.2f / %.2f | "
+          "M^-1 r + publish %.2f / %.2f | first hand-off %.2f / %.2f | first SpMV %.2f / %.2f ; kernel start to loop %.2f" % (
+              np.median(d[:, 0]), d[:, 0].max(), np.median(d[:, 1]), d[:, 1].max(), np.median(d[:, 2]), d[:, 2].max(), np.median(d[:, 3]), d[:, 3].max(),
+              np.median(d[:, 4]), d[:, 4].max(), np.median(d[:, 5]), d[:, 5].max(), (pro[ok][:, 6].max() - pro[ok][:, 0].min()) / 100.0))
     it = 4
     print("iteration %d, one wave of every workgroup, us: start skew | to LDS barrier 1 | publish+request | wait | update | await | spmv+publish | iteration ; xcc se cu" % it)
     t00 = tr[:, it, 0].min()

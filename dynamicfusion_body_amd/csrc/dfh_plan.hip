@@ -12,6 +12,15 @@
 
 namespace dfh {
 
+// rocPRIM takes its merge sort below a million items; its default block sort handles 1 024 items, i.e. nine merge passes of
+// two small launches each for the 520 000 sample keys of a frame (23 launches, ~6 us each: bound by launches, not bytes).
+// 4 096 items per sorted block: seven passes.  (The Onesweep radix path was slower at this size: profiles/r2_gn_experiments.txt.)
+#ifndef DFH_SORT_BLOCK_ITEMS
+#define DFH_SORT_BLOCK_ITEMS 8
+#endif
+using SortCfg = rocprim::radix_sort_config<rocprim::default_config,
+                                           rocprim::merge_sort_config<512, 512, DFH_SORT_BLOCK_ITEMS, 128, 256, 8>,
+                                           rocprim::default_config>;
 constexpr int kPlanTile = 256;          // == kTile of dfh_solve.hip: a row never spans two tiles
 constexpr int kKMaxP = 8;
 
@@ -167,13 +176,13 @@ static size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 
 static size_t sort_temp_bytes_u64(int n) {
     size_t t = 0;
-    if (rocprim::radix_sort_pairs(nullptr, t, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int *)nullptr, (int *)nullptr,
+    if (rocprim::radix_sort_pairs<SortCfg>(nullptr, t, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int *)nullptr, (int *)nullptr,
                                   (size_t)n) != hipSuccess) t = 0;
     return t;
 }
 static size_t sort_temp_bytes_i32(long n) {
     size_t t = 0;
-    if (rocprim::radix_sort_pairs(nullptr, t, (int *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr, (size_t)n) != hipSuccess) t = 0;
+    if (rocprim::radix_sort_pairs<SortCfg>(nullptr, t, (int *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr, (size_t)n) != hipSuccess) t = 0;
     return t;
 }
 
@@ -209,7 +218,7 @@ int dfh_gn_sort_samples(const double *pos, const double *nrm, const int *nbr, co
     const dim3 grid((unsigned)((n_samples + 255) / 256)), block(256);
     hipLaunchKernelGGL(plan_pack_keys_kernel, grid, block, 0, s, nbr, n_samples, knn, (unsigned long long)n_nodes, key_in, idx_in);
     const unsigned end_bit = bits_for((unsigned long long)(span - 1.0) + 1ull);
-    DFH_HIP_CHECK(rocprim::radix_sort_pairs(w, temp, key_in, reinterpret_cast<unsigned long long *>(key_out), idx_in, order,
+    DFH_HIP_CHECK(rocprim::radix_sort_pairs<SortCfg>(w, temp, key_in, reinterpret_cast<unsigned long long *>(key_out), idx_in, order,
                                             (size_t)n_samples, 0u, end_bit > 64u ? 64u : end_bit, s));
     hipLaunchKernelGGL(plan_permute_kernel, grid, block, 0, s, order, n_samples, knn, pos, nrm, nbr, weights, pos_out, nrm_out, nbr_out,
                        weights_out);
@@ -261,10 +270,10 @@ int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const
     hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, row_first, n_rows, knn, row_ptr, col,
                        n_blocks, bk_in, bv_in, nk_in, nv_in, uncovered_out);
     DFH_HIP_CHECK(hipGetLastError());
-    DFH_HIP_CHECK(rocprim::radix_sort_pairs(w, temp, bk_in, bk_out, bv_in, blk_ent, E, 0u, bits_for((unsigned long long)n_blocks + 1ull), s));
+    DFH_HIP_CHECK(rocprim::radix_sort_pairs<SortCfg>(w, temp, bk_in, bk_out, bv_in, blk_ent, E, 0u, bits_for((unsigned long long)n_blocks + 1ull), s));
     size_t temp2 = sort_temp_bytes_i32((long)E2);
     DFH_REQUIRE(temp2 <= temp, "dfh_gn_plan_build: scratch of the node sort exceeds the block sort's");
-    DFH_HIP_CHECK(rocprim::radix_sort_pairs(w, temp2, nk_in, nk_out, nv_in, node_ent, E2, 0u, bits_for((unsigned long long)n_nodes), s));
+    DFH_HIP_CHECK(rocprim::radix_sort_pairs<SortCfg>(w, temp2, nk_in, nk_out, nv_in, node_ent, E2, 0u, bits_for((unsigned long long)n_nodes), s));
     hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((n_blocks + 1 + 255) / 256)), dim3(256), 0, s, bk_out, (int)E, n_blocks, blk_ptr);
     hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((n_nodes + 1 + 255) / 256)), dim3(256), 0, s, nk_out, (int)E2, n_nodes, node_ptr);
     DFH_HIP_CHECK(hipGetLastError());

@@ -242,12 +242,28 @@ class SlabFrame:
         if len(depth_list) != len(lw_list):
             raise ValueError('length of camera matrix array must equal that of depth maps')
         depth, lw_cam = depth_list[0], lw_list[0]
-        self.live.fill_(self.tvox)
-        self.live_w.zero_()
-        if self.ws_views is None:
-            self.ws_views = kernels.integrate_workspace(min(len(depth_list), 16), depth.shape[0], depth.shape[1], (R, R, R), (self.a, self.b), self.live.device)
-        kernels.integrate_depth_views(self.live, self.live_w, depth_list, self.K, self.Kinv, lw_list, self.scale, self.center,
-                                      self.tdist_world, tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_views)
+        done = set()
+
+        def clear_live():
+            done.add("clear")
+            self.live.fill_(self.tvox)
+            self.live_w.zero_()
+
+        def sweep_live():
+            done.add("sweep")
+            if "clear" not in done:
+                clear_live()
+            if self.ws_views is None:
+                self.ws_views = kernels.integrate_workspace(min(len(depth_list), 16), depth.shape[0], depth.shape[1], (R, R, R), (self.a, self.b), self.live.device)
+            kernels.integrate_depth_views(self.live, self.live_w, depth_list, self.K, self.Kinv, lw_list, self.scale, self.center,
+                                          self.tdist_world, tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_views)
+        # The solver's per-frame plan depends on the samples only, not on the live volume: it is prepared first, and the
+        # live-volume work is launched at the two points where the host waits for a count of the plan (the device would
+        # otherwise idle twice for the ~35 us the host needs to issue its next launch after a read-back)
+        if stage_ms is None:
+            self.fs.solver.prepare(overlap=(clear_live, sweep_live))
+        if "sweep" not in done:
+            sweep_live()
         mark("live_tsdf")
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
         mark("allgather")

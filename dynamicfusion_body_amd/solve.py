@@ -180,6 +180,28 @@ class _LazyLong:
         return self._i64
 
 
+class _AsyncScalar:
+    """A device scalar on its way to the host: the copy is queued now (into pinned memory, behind an event), the host waits
+    only in get().  Whatever is launched in between runs while the host would otherwise sit in a stream synchronisation --
+    after `.item()` the device idles for the ~35 us the host needs to issue its next launch."""
+    _pool = {}
+
+    def __init__(self, dev_scalar):
+        key = dev_scalar.dtype
+        free = _AsyncScalar._pool.setdefault(key, [])
+        self._host = free.pop() if free else torch.empty(1, dtype=key).pin_memory()
+        self._host.copy_(dev_scalar.reshape(1), non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+
+    def get(self):
+        self._event.synchronize()
+        v = int(self._host[0])
+        _AsyncScalar._pool[self._host.dtype].append(self._host)
+        self._host = None
+        return v
+
+
 # ------------------------------------------------------------------------------ non-rigid solver
 class WarpSolver:
     """Gauss-Newton / LM solver for the node dual quaternions.
@@ -312,7 +334,15 @@ class WarpSolver:
             key = key // self.N
         return torch.stack(cols[::-1], dim=1)
 
-    def _build_pattern(self):
+    def prepare(self, overlap=()):
+        """Build whatever the next build() needs (block pattern, data plan) now instead of inside the first build().
+        overlap: up to two callables that launch device work independent of the solver (the frame loop passes the clearing
+        of the live volume and the live-volume sweep); they are called at the two points where the host has to wait for a
+        count from the device, so that the device has work while the host catches up.  Not all of them need be called."""
+        if self._pattern is None:
+            self._build_pattern(overlap)
+
+    def _build_pattern(self, overlap=()):
         """Block pattern of J^T J (diagonal, node pairs sharing a sample, regularisation pairs) and everything sized by
         it.  The pattern only GROWS while the graph stays: if the new samples' node pairs are all in the current
         pattern (the usual case from one frame to the next) it is kept -- blocks without contributions are exact
@@ -326,7 +356,7 @@ class WarpSolver:
             nbytes = self.lib.dfh_pcg_workspace_bytes(N, self.pcg_iters)          # pcg_iters may have been raised
             if self.pcg_ws.numel() * 8 < nbytes:
                 self.pcg_ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device="cuda")
-            covered = self._build_plan(old, reg=False)
+            covered = self._build_plan(old, reg=False, overlap=overlap)
             if (_dist.all_ranks(covered) if self.distributed else covered):
                 self._pattern = True
                 return
@@ -375,7 +405,7 @@ class WarpSolver:
         self._build_plan(keys)
         self._pattern = True
 
-    def _build_plan(self, keys, reg=True):
+    def _build_plan(self, keys, reg=True, overlap=()):
         """Static part of the data term (dfh_gn_build_planned): rows = runs of equal node tuples inside a
         256-sample tile, and for every block / node the rows (and tuple slots) that contribute to it.
         reg=False keeps the regularisation lists (they depend on the pattern and the graph only).
@@ -390,7 +420,10 @@ class WarpSolver:
         n_rows_d = torch.empty(1, dtype=torch.int32, device=dev)
         _lib.check(self.lib.dfh_gn_plan_count(self.snbr.data_ptr(), S, k, tile_off.data_ptr(), n_rows_d.data_ptr(), current_stream_ptr()),
                    "dfh_gn_plan_count")
-        R = int(n_rows_d.item())                                       # (the one read-back: sizes of the plan arrays)
+        pending = _AsyncScalar(n_rows_d)                               # (the read-back that sizes the plan arrays)
+        if len(overlap) > 0:
+            overlap[0]()
+        R = pending.get()
         self.n_rows = R
         if R * k * k >= 2 ** 31:
             raise ValueError("too many sample runs for 32-bit plan entries")
@@ -414,7 +447,10 @@ class WarpSolver:
         if reg:
             self._build_reg_plan(keys)
             return True
-        return int(unc.item()) == 0
+        pending = _AsyncScalar(unc)
+        if len(overlap) > 1:
+            overlap[1]()
+        return pending.get() == 0
 
     def _pair_keys_of_rows(self):
         """Node-pair keys a * N + b of every row's tuple (what the block pattern has to contain)."""

@@ -1437,6 +1437,63 @@ __global__ __launch_bounds__(256) void gn_build_reg_kernel(const int *__restrict
 // ------------------------------------------------------------------------------- PCG
 // Solves (A + lm_abs I + lm_rel diag(A)) x = -rhs with block-Jacobi preconditioning; one thread
 // per node row; scalars live in `scal` (3 doubles per iteration: rz, pAp, rz_next).
+// Row `r` (r = 0..5, may differ between lanes) of the same inverse, the same bits as inv6's row r, without the 36 outputs: the
+// persistent PCG wants one row per lane and was spilling registers around the full inverse in its 1 024-thread form.
+// (A^-1)[r][j] = sum_k Li[k][r] Li[k][j] over k >= max(r, j); Li[k][r] is picked from the k-th row with compares (no dynamic
+// index), and is exactly 0 for k < r, so the sum may start at k = j: the extra terms add +0.0 to a +0.0.
+__device__ __forceinline__ void inv6_row(const double *A, int r, double *row) {
+    double L[6][6], Li[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { L[i][j] = 0.0; Li[i][j] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[6 * j + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= L[j][k] * L[j][k];
+        d = d > 0.0 ? sqrt(d) : 1.0;
+        L[j][j] = d;
+        const double id = 1.0 / d;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i > j) {
+                double v = A[6 * i + j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if (k < j) v -= L[i][k] * L[j][k];
+                L[i][j] = v * id;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i >= c) {
+                double v = i == c ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if (k >= c && k < i) v -= L[i][k] * Li[k][c];
+                Li[i][c] = v / L[i][i];
+            }
+        }
+    }
+    double lr[6];                                               // Li[k][r]
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double v = Li[k][0];
+#pragma unroll
+        for (int c = 1; c < 6; ++c) v = r == c ? Li[k][c] : v;
+        lr[k] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k >= j) v += lr[k] * Li[k][j];
+        row[j] = v;
+    }
+}
+
 __device__ __forceinline__ void inv6(const double *A, double *Ainv) {
     // A = L L^T (SPD after damping), A^-1 = L^-T L^-1; every loop has compile-time bounds so the
     // 6x6 arrays live in registers.  A non-positive pivot (rank-deficient block) is replaced by 1:
@@ -1900,15 +1957,10 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
     PRO_STAMP(2);
     double Mi[6];
     {
-        double Di[36];
-        inv6(D, Di);                                            // lanes 0..5 redundantly: same cost as one lane
+        double mr[6];
+        inv6_row(D, lane < 6 ? lane : 0, mr);                   // every lane runs the factorisation: same cost as one lane
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            double v = Di[j];
-#pragma unroll
-            for (int rr = 1; rr < 6; ++rr) v = lane == rr ? Di[6 * rr + j] : v;
-            Mi[j] = lead ? v : 0.0;
-        }
+        for (int j = 0; j < 6; ++j) Mi[j] = lead ? mr[j] : 0.0;
     }
     PRO_STAMP(3);
     // The neighbours' published values of this lane's cached blocks (element i of node cj[c]); rows wider than the

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void plan_runid_kernel(const int *__restrict__
 __global__ __launch_bounds__(256) void plan_keys_kernel(const int *__restrict__ nbr, const int *__restrict__ row_first, int n_rows, int k,
                                                          const int *__restrict__ row_ptr, const int *__restrict__ col, int B,
                                                          int *__restrict__ blk_key, int *__restrict__ blk_val, int *__restrict__ node_key,
-                                                         int *__restrict__ node_val, int *__restrict__ uncovered) {
+                                                         int *__restrict__ node_val, int *__restrict__ uncovered,
+                                                         int *__restrict__ blk_cnt, int *__restrict__ node_cnt) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     const int kk = k * k;
     if (e >= (long)n_rows * kk) return;
@@ -147,11 +148,138 @@ __global__ __launch_bounds__(256) void plan_keys_kernel(const int *__restrict__ 
     int blk = plan_find_block(row_ptr, col, na, nb);
     if (blk < 0) { blk = B; atomicOr(uncovered, 1); }
     blk_key[e] = blk;
-    blk_val[e] = (int)e;
+    // counting pass of the lists: the count's old value is this entry's slot inside its list (any order: the lists are
+    // sorted afterwards, each on its own)
+    blk_val[e] = blk < B ? atomicAdd(blk_cnt + blk, 1) : 0;
     if (sa == 0) {
         node_key[(size_t)row * k + sb] = nb;
-        node_val[(size_t)row * k + sb] = row * k + sb;
+        node_val[(size_t)row * k + sb] = atomicAdd(node_cnt + nb, 1);
     }
+}
+
+// zero two integer ranges in one launch
+__global__ __launch_bounds__(256) void plan_zero2_kernel(int *__restrict__ a, int na, int *__restrict__ b, int nb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < na) a[i] = 0;
+    else if (i - na < nb) b[i - na] = 0;
+}
+
+// exclusive scans of the two count arrays in place (workgroup 0: a[0..na), total to a[na]; workgroup 1: b likewise)
+__global__ __launch_bounds__(1024) void plan_scan2_kernel(int *__restrict__ a, int na, int *__restrict__ b, int nb) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    int *v_ = blockIdx.x == 0 ? a : b;
+    const int n = blockIdx.x == 0 ? na : nb;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? v_[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        int off = carry_s;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        if (i < n) v_[i] = off + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) v_[n] = carry_s;
+}
+
+// every entry to its slot: ent[ptr[key] + rank]
+__global__ __launch_bounds__(256) void plan_fill_kernel(const int *__restrict__ blk_key, const int *__restrict__ blk_rank, long E, int B,
+                                                         const int *__restrict__ blk_ptr, int *__restrict__ blk_ent,
+                                                         const int *__restrict__ node_key, const int *__restrict__ node_rank, long E2,
+                                                         const int *__restrict__ node_ptr, int *__restrict__ node_ent) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < E) {
+        const int blk = blk_key[e];
+        if (blk < B) blk_ent[blk_ptr[blk] + blk_rank[e]] = (int)e;
+    }
+    if (e < E2) node_ent[node_ptr[node_key[e]] + node_rank[e]] = (int)e;
+}
+
+// Every list sorted ascending (= the order a stable sort of the entries by key gives, the fixed summation order of the
+// bit-reproducible build): one WAVE per list, lists [0, B) = blocks, [B, B + N) = nodes.  Up to 64 entries: a bitonic network
+// on registers; up to kListLds: the same in the wave's LDS; longer (few nodes and very many rows): every entry's rank counted
+// against a copy of the list in `tmp` (quadratic, a fallback).
+constexpr int kListLds = 2048;
+__global__ __launch_bounds__(256) void plan_sort_lists_kernel(const int *__restrict__ blk_ptr, int *__restrict__ blk_ent, int B,
+                                                               const int *__restrict__ node_ptr, int *__restrict__ node_ent, int N,
+                                                               int *__restrict__ blk_tmp, int *__restrict__ node_tmp) {
+    __shared__ int sl[4][kListLds];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int L = blockIdx.x * 4 + wv;
+    if (L >= B + N) return;
+    const bool isb = L < B;
+    const int id = isb ? L : L - B;
+    const int *ptr = isb ? blk_ptr : node_ptr;
+    int *ent = isb ? blk_ent : node_ent;
+    int *tmp = isb ? blk_tmp : node_tmp;
+    const int beg = ptr[id], n = ptr[id + 1] - beg;
+    if (n <= 1) return;
+    constexpr int kBig = 0x7fffffff;
+    if (n <= 64) {
+        int v = lane < n ? ent[beg + lane] : kBig;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int o = __shfl_xor(v, j, 64);
+                const bool up = (lane & k) == 0, low = (lane & j) == 0;
+                v = (low == up) ? min(v, o) : max(v, o);
+            }
+        if (lane < n) ent[beg + lane] = v;
+        return;
+    }
+    if (n <= kListLds) {
+        int P = 128;
+        while (P < n) P <<= 1;
+        int *a = sl[wv];
+        for (int i = lane; i < P; i += 64) a[i] = i < n ? ent[beg + i] : kBig;
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+                for (int t = lane; t < P / 2; t += 64) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // t with a 0 inserted at bit log2(j)
+                    const int x = a[i], y = a[i | j];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[i | j] = x; }
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        for (int i = lane; i < n; i += 64) ent[beg + i] = a[i];
+        return;
+    }
+    for (int i = lane; i < n; i += 64) tmp[beg + i] = ent[beg + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");              // (the wave reads other lanes' copies below)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int i = lane; i < n; i += 64) {
+        const int x = tmp[beg + i];
+        int r = 0;
+        for (int q = 0; q < n; ++q) r += tmp[beg + q] < x ? 1 : 0;
+        ent[beg + r] = x;                                           // entries are distinct: ranks are a permutation
+    }
+}
+
+// values 0..n-1 of the two radix sorts (A/B path)
+__global__ __launch_bounds__(256) void plan_iota_kernel(int *__restrict__ a, long na, int *__restrict__ b, long nb) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < na) a[i] = (int)i;
+    if (i < nb) b[i] = (int)i;
 }
 
 // ptr[v] = first position of a key >= v in the sorted keys, v = 0..n_keys (CSR offsets of the lists)
@@ -267,16 +395,37 @@ int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const
     const int n_tiles = (n_samples + kPlanTile - 1) / kPlanTile;
     DFH_HIP_CHECK(hipMemsetAsync(uncovered_out, 0, sizeof(int), s));
     hipLaunchKernelGGL(plan_runid_kernel, dim3(n_tiles), dim3(256), 0, s, nbr, n_samples, knn, tile_off, run_id, row_first);
+    if (getenv("DFH_PLAN_RADIX")) {              // the lists through two stable device radix sorts (round 2, first half): kept for A/B
+        hipLaunchKernelGGL(plan_zero2_kernel, dim3((unsigned)((n_blocks + n_nodes + 2 + 255) / 256)), dim3(256), 0, s, blk_ptr, n_blocks + 1,
+                           node_ptr, n_nodes + 1);
+        hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, row_first, n_rows, knn, row_ptr, col,
+                           n_blocks, bk_in, bk_out, nk_in, nk_out, uncovered_out, blk_ptr, node_ptr);
+        hipLaunchKernelGGL(plan_iota_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, bv_in, (long)E, nv_in, (long)E2);
+        DFH_HIP_CHECK(hipGetLastError());
+        DFH_HIP_CHECK(rocprim::radix_sort_pairs<SortCfg>(w, temp, bk_in, bk_out, bv_in, blk_ent, E, 0u, bits_for((unsigned long long)n_blocks + 1ull), s));
+        size_t temp2 = sort_temp_bytes_i32((long)E2);
+        DFH_REQUIRE(temp2 <= temp, "dfh_gn_plan_build: scratch of the node sort exceeds the block sort's");
+        DFH_HIP_CHECK(rocprim::radix_sort_pairs<SortCfg>(w, temp2, nk_in, nk_out, nv_in, node_ent, E2, 0u, bits_for((unsigned long long)n_nodes), s));
+        hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((n_blocks + 1 + 255) / 256)), dim3(256), 0, s, bk_out, (int)E, n_blocks, blk_ptr);
+        hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((n_nodes + 1 + 255) / 256)), dim3(256), 0, s, nk_out, (int)E2, n_nodes, node_ptr);
+        DFH_HIP_CHECK(hipGetLastError());
+        return DFH_OK;
+    }
+    // The lists by counting: every entry takes a slot in its list while the lists are counted (atomic increments: any order),
+    // an exclusive scan turns the counts into offsets, the entries go to offset + slot, and every list is then sorted on its
+    // own by one wave (lists are short: ~36 entries per block, ~200 per node).  Six launches where the two library sorts
+    // took 26; the result is the same as a stable sort of the entries by key, element for element.
+    hipLaunchKernelGGL(plan_zero2_kernel, dim3((unsigned)((n_blocks + n_nodes + 2 + 255) / 256)), dim3(256), 0, s, blk_ptr, n_blocks + 1,
+                       node_ptr, n_nodes + 1);
     hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, row_first, n_rows, knn, row_ptr, col,
-                       n_blocks, bk_in, bv_in, nk_in, nv_in, uncovered_out);
+                       n_blocks, bk_in, bv_in, nk_in, nv_in, uncovered_out, blk_ptr, node_ptr);
+    hipLaunchKernelGGL(plan_scan2_kernel, dim3(2), dim3(1024), 0, s, blk_ptr, n_blocks, node_ptr, n_nodes);
+    hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, bk_in, bv_in, (long)E, n_blocks, blk_ptr, blk_ent,
+                       nk_in, nv_in, (long)E2, node_ptr, node_ent);
+    hipLaunchKernelGGL(plan_sort_lists_kernel, dim3((unsigned)((n_blocks + n_nodes + 3) / 4)), dim3(256), 0, s, blk_ptr, blk_ent, n_blocks,
+                       node_ptr, node_ent, n_nodes, bk_out, nk_out);
     DFH_HIP_CHECK(hipGetLastError());
-    DFH_HIP_CHECK(rocprim::radix_sort_pairs<SortCfg>(w, temp, bk_in, bk_out, bv_in, blk_ent, E, 0u, bits_for((unsigned long long)n_blocks + 1ull), s));
-    size_t temp2 = sort_temp_bytes_i32((long)E2);
-    DFH_REQUIRE(temp2 <= temp, "dfh_gn_plan_build: scratch of the node sort exceeds the block sort's");
-    DFH_HIP_CHECK(rocprim::radix_sort_pairs<SortCfg>(w, temp2, nk_in, nk_out, nv_in, node_ent, E2, 0u, bits_for((unsigned long long)n_nodes), s));
-    hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((n_blocks + 1 + 255) / 256)), dim3(256), 0, s, bk_out, (int)E, n_blocks, blk_ptr);
-    hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((n_nodes + 1 + 255) / 256)), dim3(256), 0, s, nk_out, (int)E2, n_nodes, node_ptr);
-    DFH_HIP_CHECK(hipGetLastError());
+    (void)temp;
     return DFH_OK;
 }
 

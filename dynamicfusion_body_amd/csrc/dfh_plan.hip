@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void plan_zero2_kernel(int *__restrict__ a, in
     else if (i - na < nb) b[i - na] = 0;
 }
 
-// exclusive scans of the two count arrays in place (workgroup 0: a[0..na), total to a[na]; workgroup 1: b likewise)
+// exclusive scans of the two count arrays in place (workgroup 0: a[0..na), total to a[na]; workgroup 1: b likewise).
+// Every thread takes a contiguous chunk of up to 16 counts (one pass for up to 16 K lists, three barriers; more lists: rounds).
 __global__ __launch_bounds__(1024) void plan_scan2_kernel(int *__restrict__ a, int na, int *__restrict__ b, int nb) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
@@ -173,10 +174,18 @@ __global__ __launch_bounds__(1024) void plan_scan2_kernel(int *__restrict__ a, i
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? v_[i] : 0;
-        int x = v;
+    constexpr int C = 16;
+    for (int base = 0; base < n; base += 1024 * C) {
+        const int per = min(C, (min(n - base, 1024 * C) + 1023) / 1024);       // counts per thread in this round
+        const int i0 = base + (int)threadIdx.x * per;
+        int v[C];
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            v[j] = (j < per && i0 + j < n) ? v_[i0 + j] : 0;
+            sum += v[j];
+        }
+        int x = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int y = __shfl_up(x, o, 64);
@@ -186,7 +195,12 @@ __global__ __launch_bounds__(1024) void plan_scan2_kernel(int *__restrict__ a, i
         __syncthreads();
         int off = carry_s;
         for (int w = 0; w < wv; ++w) off += wsum[w];
-        if (i < n) v_[i] = off + x - v;
+        int run = off + x - sum;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            if (j < per && i0 + j < n) v_[i0 + j] = run;
+            run += v[j];
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = off + x;
         __syncthreads();

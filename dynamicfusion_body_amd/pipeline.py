@@ -6,6 +6,8 @@ solve -> updateTSDF) with projective association in place of marching cubes + KD
 `extract_surface_samples` runs the HIP band-compaction kernels of csrc/dfh_extract.hip (the
 first "next" row of SURVEY.md §8(f)); `extract_surface_samples_torch` is the same computation on
 torch ops, kept for CPU-side tests of the sample definition."""
+import os
+
 import numpy as np
 import torch
 
@@ -138,6 +140,7 @@ class SlabFrame:
         self.fs.set_graph(node_pos, ident, node_w)
         self.ws_dqb = kernels.dqb_workspace((R, R, R), (self.a, self.b), knn=knn, n_nodes=N)
         self.ws_views = None                     # dfh_integrate_depth_multi's scratch (parameters + depth pyramids): sized on first use
+        self._side = None                        # side stream of step(): the live-volume sweep beside the plan build
         self.knn_bricks = None
         if self.b > self.a:
             kernels.dqb_build_candidates(self.ws_dqb, (R, R, R), node_pos, knn, (self.a, self.b))
@@ -242,27 +245,26 @@ class SlabFrame:
         if len(depth_list) != len(lw_list):
             raise ValueError('length of camera matrix array must equal that of depth maps')
         depth, lw_cam = depth_list[0], lw_list[0]
-        done = set()
-
-        def clear_live():
-            done.add("clear")
+        def sweep_live():
             self.live.fill_(self.tvox)
             self.live_w.zero_()
-
-        def sweep_live():
-            done.add("sweep")
-            if "clear" not in done:
-                clear_live()
             if self.ws_views is None:
                 self.ws_views = kernels.integrate_workspace(min(len(depth_list), 16), depth.shape[0], depth.shape[1], (R, R, R), (self.a, self.b), self.live.device)
             kernels.integrate_depth_views(self.live, self.live_w, depth_list, self.K, self.Kinv, lw_list, self.scale, self.center,
                                           self.tdist_world, tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_views)
-        # The solver's per-frame plan depends on the samples only, not on the live volume: it is prepared first, and the
-        # live-volume work is launched at the two points where the host waits for a count of the plan (the device would
-        # otherwise idle twice for the ~35 us the host needs to issue its next launch after a read-back)
-        if stage_ms is None:
-            self.fs.solver.prepare(overlap=(clear_live, sweep_live))
-        if "sweep" not in done:
+        # The solver's per-frame plan depends on the samples only and the live volume on the depth maps only: the live-volume
+        # sweep (bandwidth-bound) runs on a side stream beside the plan's launches (bound by latency and atomics, with two
+        # read-backs in between); the streams join before the first GN iteration.  With stage timing the order is sequential.
+        if stage_ms is None and not os.environ.get("DFH_NO_SIDE_STREAM"):
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)             # the previous frame's TSDF update has read the live volume
+            with torch.cuda.stream(self._side):
+                sweep_live()
+            self.fs.solver.prepare()
+            main.wait_stream(self._side)
+        else:
             sweep_live()
         mark("live_tsdf")
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live

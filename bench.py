@@ -219,11 +219,22 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
 
     stages = {}
 
+    mesh_stream = torch.cuda.Stream() if world == 1 else None
+
     def frame(f, timed=False):
+        if mesh_stream is not None:
+            torch.cuda.current_stream().wait_stream(mesh_stream)     # the previous frame's mesh has read the canonical volume
         info["samples"] = sf.step(depths[f], lw_cam, gn_iters=iters, stage_ms=stages if timed else None)
         if world == 1:
             t1 = _t.perf_counter()
-            v, fc, n, val = mesh.marching_cubes(sf.T, 0.0)
+            if timed:
+                v, fc, n, val = mesh.marching_cubes(sf.T, 0.0)
+            else:
+                # the mesh needs the updated canonical volume only: it is extracted on a second stream from the moment the
+                # TSDF update is done, beside the sample refresh (count -> read-back -> emit -> node search -> sort) on the first
+                with torch.cuda.stream(mesh_stream):
+                    mesh_stream.wait_event(sf.updated)
+                    v, fc, n, val = mesh.marching_cubes(sf.T, 0.0)
             info["vertices"], info["faces"] = int(v.shape[0]), int(fc.shape[0])
             if timed:
                 torch.cuda.synchronize()
@@ -251,7 +262,8 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
             "exchange": "none" if world == 1 else "per frame: all-gather of the live volume (%.0f MB) + face-plane halo; per GN "
                                                   "iteration: one all-reduce of the normal equations" % (R ** 3 * 4 / 1e6),
             "workload": "%d^3 grid in %d axis-0 slab(s), %d nodes: live TSDF (%d views of %dx%d, one sweep) + %d GN iterations + DQB "
-                        "TSDF update + sample refresh%s, per frame" % (R, world, N, len(lws), W, H, iters, " + marching cubes" if world == 1 else "")}
+                        "TSDF update + sample refresh%s, per frame" % (R, world, N, len(lws), W, H, iters,
+                                                                     " + marching cubes (on a second stream beside the sample refresh)" if world == 1 else "")}
 
 
 def pmc_traffic(kernel_substr, res):

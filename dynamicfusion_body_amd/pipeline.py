@@ -141,6 +141,7 @@ class SlabFrame:
         self.ws_dqb = kernels.dqb_workspace((R, R, R), (self.a, self.b), knn=knn, n_nodes=N)
         self.ws_views = None                     # dfh_integrate_depth_multi's scratch (parameters + depth pyramids): sized on first use
         self._side = None                        # side stream of step(): the live-volume sweep beside the plan build
+        self.updated = None                      # event recorded by step() right after the TSDF update
         self.knn_bricks = None
         if self.b > self.a:
             kernels.dqb_build_candidates(self.ws_dqb, (R, R, R), node_pos, knn, (self.a, self.b))
@@ -276,7 +277,10 @@ class SlabFrame:
         kernels.fuse_volume_dqb(self.T, self.Wt, live_full, sv.node_pos, sv.node_dq, sv.node_w, self.knn, self.ident_lw, self.tvox,
                                 res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_dqb, rebuild_candidates=self._first)
         self._first = False
-        mark("tsdf_update")
+        if self.updated is None:
+            self.updated = torch.cuda.Event()
+        self.updated.record()                  # the canonical slab of this frame is final from here on (a consumer on another
+        mark("tsdf_update")                    # stream, e.g. mesh extraction, need not wait for the sample refresh below)
         n = self.refresh_samples()
         mark("samples")
         self.fs.solver.check_status(completed_only=True)   # the sample count's read-back has synchronised: a timed-out PCG raises here

@@ -387,9 +387,10 @@ def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, mon
 def test_device_plan_builder_equals_the_torch_plan(monkeypatch):
     """dfh_gn_sort_samples / dfh_gn_plan_count / dfh_gn_plan_build (run scan, block look-up, two stable radix sorts) against the
     same bookkeeping assembled from torch ops: sample order, tuple keys, run ids, and all four CSR arrays, element for
-    element -- ragged sample counts, several tiles, a pattern that covers the pairs and one that does not."""
+    element -- ragged sample counts, several tiles, a pattern that covers the pairs and one that does not; lists short enough
+    for the per-list sort's register and LDS networks and lists beyond them (five nodes, 800 000 samples)."""
     rng = np.random.default_rng(11)
-    for N, k, S in ((40, 4, 1000), (300, 4, 70000), (9, 2, 257), (64, 3, 256)):
+    for N, k, S in ((40, 4, 1000), (300, 4, 70000), (9, 2, 257), (64, 3, 256), (5, 4, 800000)):   # the last: lists of thousands of entries
         npos = rng.uniform(0, 60, size=(N, 3)); nw = rng.uniform(3, 6, size=N)
         ndq = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
         pts = rng.uniform(0, 60, size=(S, 3)); nrm = rng.normal(size=(S, 3))

@@ -1671,7 +1671,7 @@ __global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double 
 // and an abort flag makes every wave leave if one ever times out (x is then NaN, never a hang).  Reductions: every
 // workgroup adds its waves' values in LDS (fixed order) and publishes the partial; wave 0 reads all workgroups'
 // partials and adds them in a fixed order: same bits every run and on every rank, no floating-point atomics, no
-// counters, no cache-wide fences.  Measured (512 rows, tools/kbench_pcg.py): 3.5 us per iteration, of which ~1.9 us
+// counters, no cache-wide fences.  Measured (512 rows, tools/kbench_pcg.py): 3.0 us per iteration, of which ~1.8 us
 // is the hand-off (stores becoming visible across the XCDs + one agent-scope load round trip of ~0.9 us).
 constexpr int kRowCache = 3;               // blocks per lane slot held in registers (rows <= 30 blocks)
 constexpr unsigned kSpinLimit = 1u << 22;  // default bound of a barrier's spin (~seconds); DFH_PCG_SPIN_LIMIT overrides (tests)
@@ -2094,12 +2094,6 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
             ui = ui - alpha * ti;
         }
         if (last) break;
-        if (it >= 1 && lead) {                                  // region (it - 1) % 4: every reader is done with it
-            double *old = region(it - 1);
-            st_agent(old + 6 * a + lane, 0.0);
-            st_agent(old + N6 + 6 * a + lane, 0.0);
-            st_agent(old + 2 * N6 + 6 * a + lane, 0.0);
-        }
         PCG_STAMP(2);
         await(cur, true);
         PCG_STAMP(3);
@@ -2113,6 +2107,14 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
             st_agent(nxt + 6 * a + lane, nz_bits(ui));
             st_agent(nxt + N6 + 6 * a + lane, nz_bits(vi));
             st_agent(nxt + 2 * N6 + 6 * a + lane, nz_bits(ti));
+        }
+        // region (it - 1) % 4: every reader was done with it before reduction `it`.  Cleared here, behind the publishing stores
+        // (issued before the check of the neighbours' values, the clears' acknowledgements were waited for with the loads).
+        if (it >= 1 && lead) {
+            double *old = region(it - 1);
+            st_agent(old + 6 * a + lane, 0.0);
+            st_agent(old + N6 + 6 * a + lane, 0.0);
+            st_agent(old + 2 * N6 + 6 * a + lane, 0.0);
         }
         if (!mine) ui = __builtin_nan("");
         g = sum6_f64(lead ? ri * ui : 0.0);

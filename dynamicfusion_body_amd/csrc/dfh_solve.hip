@@ -763,9 +763,15 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         const D3 x1 = dqb_warp_exact(a_bh, a_pf[0], a_pf[1], a_pf[2]);
         a_xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
         a_ok = associate_point<float>(aa.ap, aa.depth, a_xp, a_c);
-        corr[3 * (size_t)s] = a_c[0]; corr[3 * (size_t)s + 1] = a_c[1]; corr[3 * (size_t)s + 2] = a_c[2];
-        valid[s] = a_ok ? 1 : 0;
     }
+    // corr / valid are outputs only: stored after the last global load of the kernel (stored here, every later s_waitcnt for a
+    // load also waited for these stores' acknowledgements)
+    auto store_assoc = [&]() {
+        if (ASSOC && tid < tile_n) {
+            corr[3 * (size_t)s] = a_c[0]; corr[3 * (size_t)s + 1] = a_c[1]; corr[3 * (size_t)s + 2] = a_c[2];
+            valid[s] = a_ok ? 1 : 0;
+        }
+    };
     const bool act = ASSOC ? a_ok : (tid < tile_n && valid[s] != 0);
     BT_STAMP(1);
     __shared__ int sWaveCnt[4];
@@ -781,6 +787,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     const int row_first = PLANNED ? run_id[blockIdx.x * kTile] : 0;
     const int rows_tile = PLANNED ? run_id[blockIdx.x * kTile + tile_n - 1] - row_first + 1 : 0;
     if (n_valid == 0) {                                              // tiles without a valid sample contribute nothing:
+        store_assoc();
         if (PLANNED && tid < rows_tile) live[row_first + tid] = 0.0;                                 // their rows are dead
         if (PLANNED && tid == 0) { tile_cost[2 * blockIdx.x] = 0.0; tile_cost[2 * blockIdx.x + 1] = 0.0; }
         return;
@@ -820,6 +827,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         for (int j = 0; j < NJ; ++j) sJ[pos * LD + j] = Jrow[j];
         sJ[pos * LD + NJ] = r;
     }
+    store_assoc();
     BT_STAMP(2);
     if (PLANNED) {                                                   // the tile's objective, added in a fixed order
 #pragma unroll

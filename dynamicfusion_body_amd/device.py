@@ -1,5 +1,8 @@
 """Device-memory plumbing on PyTorch-ROCm tensors (torch is the allocator / stream
 provider here, not the compute path)."""
+import os
+import time
+
 import numpy as np
 import torch
 
@@ -21,6 +24,51 @@ def current_stream_ptr():
     if _raw_stream is None or _raw_device is None:
         return torch.cuda.current_stream().cuda_stream
     return _raw_stream(_raw_device())
+
+
+class HostScalar:
+    """A non-negative integer that a kernel stores straight into pinned host memory (the pointer is handed to the C-ABI where it
+    asks for a device scalar: pinned memory is device-accessible at its host address).  The host pre-sets -1 and get() spins on
+    the word until the kernel's store lands -- a few microseconds after the kernel ends, where a queued device-to-host copy
+    behind an event took ~30 us during which the device had nothing to do (profiles/r2_gn_experiments.txt section 6).
+    Only for scalars written by ONE plain store of the launch sequence's last writer (no atomics across PCIe).
+    DFH_NO_HOST_SCALARS=1 goes back to a device scalar and .item()."""
+    _pool = {}
+    enabled = not os.environ.get("DFH_NO_HOST_SCALARS")
+
+    def __init__(self, dtype=torch.int32):
+        self._dtype = dtype
+        if HostScalar.enabled:
+            free = HostScalar._pool.setdefault(dtype, [])
+            self._t = free.pop() if free else torch.empty(1, dtype=dtype).pin_memory()
+            self._np = self._t.numpy()
+            self._np[0] = -1
+        else:
+            self._t = torch.empty(1, dtype=dtype, device="cuda")
+
+    def ptr(self):
+        return self._t.data_ptr()
+
+    def get(self, timeout=20.0):
+        if not HostScalar.enabled:
+            return int(self._t.item())
+        a = self._np
+        spins = 0
+        t_end = None
+        while a[0] == -1:
+            spins += 1
+            if spins & 0x3ff == 0:                     # (look at the clock every ~1000 reads only)
+                now = time.monotonic()
+                if t_end is None:
+                    t_end = now + timeout
+                elif now > t_end:
+                    torch.cuda.synchronize()           # raises if a launch of the sequence failed
+                    if a[0] == -1:
+                        raise _lib.DfhError("a kernel's host-visible scalar never arrived")
+        v = int(a[0])
+        HostScalar._pool[self._dtype].append(self._t)
+        self._t = self._np = None
+        return v
 
 
 def dtype_code(t):

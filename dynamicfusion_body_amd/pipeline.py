@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib, kernels
-from .device import current_stream_ptr, dtype_code, require_gpu
+from .device import HostScalar, current_stream_ptr, dtype_code, require_gpu
 from .solve import WarpSolver, sample_knn
 
 
@@ -30,10 +30,10 @@ def extract_surface_samples(T, Wt, band, x0=0, max_samples=None):
     res = _lib.iarr(T.shape)
     nbytes = lib.dfh_surface_workspace_bytes(res)
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=T.device)
-    total = torch.zeros(1, dtype=torch.int64, device=T.device)
+    total = HostScalar(torch.int64)                    # (the scan kernel stores the count straight into pinned host memory)
     _lib.check(lib.dfh_surface_count(T.data_ptr(), Wt.data_ptr(), dtype_code(T), res, float(band), ws.data_ptr(),
-                                     ws.numel() * 8, total.data_ptr(), current_stream_ptr()), "dfh_surface_count")
-    n = int(total.item())
+                                     ws.numel() * 8, total.ptr(), current_stream_ptr()), "dfh_surface_count")
+    n = total.get()
     cap = n if max_samples is None else min(n, int(max_samples))
     pos = torch.empty((cap, 3), dtype=torch.float64, device=T.device)
     nrm = torch.empty((cap, 3), dtype=torch.float64, device=T.device)

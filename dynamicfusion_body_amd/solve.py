@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib, dist as _dist
-from .device import current_stream_ptr, dtype_code, require_gpu
+from .device import HostScalar, current_stream_ptr, dtype_code, require_gpu
 
 
 def _f64(a, shape_tail=None):
@@ -417,10 +417,14 @@ class WarpSolver:
         N, k, S, dev = self.N, self.knn, self.S, "cuda"
         n_tiles = (S + 255) // 256
         tile_off = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
-        n_rows_d = torch.empty(1, dtype=torch.int32, device=dev)
-        _lib.check(self.lib.dfh_gn_plan_count(self.snbr.data_ptr(), S, k, tile_off.data_ptr(), n_rows_d.data_ptr(), current_stream_ptr()),
+        # (the row count sizes the plan arrays: the scan kernel stores it straight into pinned host memory)
+        n_rows_d = None if HostScalar.enabled else torch.empty(1, dtype=torch.int32, device=dev)
+        pending = HostScalar(torch.int32) if HostScalar.enabled else None
+        _lib.check(self.lib.dfh_gn_plan_count(self.snbr.data_ptr(), S, k, tile_off.data_ptr(),
+                                              pending.ptr() if pending is not None else n_rows_d.data_ptr(), current_stream_ptr()),
                    "dfh_gn_plan_count")
-        pending = _AsyncScalar(n_rows_d)                               # (the read-back that sizes the plan arrays)
+        if pending is None:
+            pending = _AsyncScalar(n_rows_d)
         if len(overlap) > 0:
             overlap[0]()
         R = pending.get()

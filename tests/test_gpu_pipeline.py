@@ -181,9 +181,11 @@ def test_composed_frame_loop_tracks_without_drift():
 def test_frame_loop_variants_give_the_same_bits(monkeypatch):
     """SlabFrame.step overlaps the live-volume sweep (side stream) with the plan build and reads the plan's counts back through
     pinned memory behind an event; the plan's lists are built by counting + per-list sorts.  The sequential loop
-    (DFH_NO_SIDE_STREAM), the radix-sort plan (DFH_PLAN_RADIX) and the stage-timed loop (a synchronisation after every stage) must
-    give the same warp field and the same canonical volume, bit for bit: a race between the streams would show here."""
+    (DFH_NO_SIDE_STREAM), the radix-sort plan (DFH_PLAN_RADIX), the stage-timed loop (a synchronisation after every stage) and the
+    loop that reads its counts through device scalars instead of host-visible words (HostScalar off) must give the same warp
+    field and the same canonical volume, bit for bit: a race between the streams, or a count read too early, would show here."""
     from dynamicfusion_body_amd.pipeline import SlabFrame
+    from dynamicfusion_body_amd.device import HostScalar
     R, N = 96, 160
     H, W, fx, cx, cy = scene.CAMERAS["C2"]
     K = scene.intrinsics(fx, cx, cy)
@@ -199,8 +201,10 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
     def run(env, timed):
         for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX"):
             monkeypatch.delenv(k, raising=False)
+        monkeypatch.setattr(HostScalar, "enabled", "NO_HOST_SCALARS" not in env)
         for k in env:
-            monkeypatch.setenv(k, "1")
+            if k.startswith("DFH_"):
+                monkeypatch.setenv(k, "1")
         sf = SlabFrame(K, scale, center, R, tdist / scale, node_pos, node_w, knn=4, pcg_iters=10, band=2.0, distributed=False)
         for d, lw in zip(first, lws):
             sf.integrate(d, lw)
@@ -209,7 +213,8 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
         torch.cuda.synchronize()
         return counts, sf.fs.solver.node_dq.clone(), sf.T.clone(), sf.Wt.clone()
     ref = run((), False)
-    for env, timed in ((("DFH_NO_SIDE_STREAM",), False), (("DFH_PLAN_RADIX",), False), ((), True), ((), False)):
+    assert HostScalar.enabled
+    for env, timed in ((("DFH_NO_SIDE_STREAM",), False), (("DFH_PLAN_RADIX",), False), (("NO_HOST_SCALARS",), False), ((), True), ((), False)):
         got = run(env, timed)
         assert got[0] == ref[0], (env, timed)
         for a, b in zip(got[1:], ref[1:]):

@@ -164,11 +164,17 @@ __global__ __launch_bounds__(256) void plan_zero2_kernel(int *__restrict__ a, in
     else if (i - na < nb) b[i - na] = 0;
 }
 
+__global__ void plan_flag_out_kernel(const int *__restrict__ flag_in, int *__restrict__ flag_out) { *flag_out = *flag_in; }
+
 // exclusive scans of the two count arrays in place (workgroup 0: a[0..na), total to a[na]; workgroup 1: b likewise).
 // Every thread takes a contiguous chunk of up to 16 counts (one pass for up to 16 K lists, three barriers; more lists: rounds).
-__global__ __launch_bounds__(1024) void plan_scan2_kernel(int *__restrict__ a, int na, int *__restrict__ b, int nb) {
+// flag_in -> *flag_out: the "pattern must grow" flag of the launch before (set there by atomics, in the workspace) goes to the
+// caller's word by ONE plain store, so that word may be pinned host memory the host spins on.
+__global__ __launch_bounds__(1024) void plan_scan2_kernel(int *__restrict__ a, int na, int *__restrict__ b, int nb,
+                                                           const int *__restrict__ flag_in, int *__restrict__ flag_out) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *flag_out = *flag_in;
     int *v_ = blockIdx.x == 0 ? a : b;
     const int n = blockIdx.x == 0 ? na : nb;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -406,14 +412,16 @@ int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const
     int *nv_in = reinterpret_cast<int *>(w); w += align16(sizeof(int) * E2);
     int *nk_out = reinterpret_cast<int *>(w); w += align16(sizeof(int) * E2);
     size_t temp = sort_temp_bytes_i32((long)E);
+    int *unc_ws = reinterpret_cast<int *>(w + align16(temp));     // (the 16 spare bytes of the workspace) the flag while atomics set it
     const int n_tiles = (n_samples + kPlanTile - 1) / kPlanTile;
-    DFH_HIP_CHECK(hipMemsetAsync(uncovered_out, 0, sizeof(int), s));
+    DFH_HIP_CHECK(hipMemsetAsync(unc_ws, 0, sizeof(int), s));
     hipLaunchKernelGGL(plan_runid_kernel, dim3(n_tiles), dim3(256), 0, s, nbr, n_samples, knn, tile_off, run_id, row_first);
     if (getenv("DFH_PLAN_RADIX")) {              // the lists through two stable device radix sorts (round 2, first half): kept for A/B
         hipLaunchKernelGGL(plan_zero2_kernel, dim3((unsigned)((n_blocks + n_nodes + 2 + 255) / 256)), dim3(256), 0, s, blk_ptr, n_blocks + 1,
                            node_ptr, n_nodes + 1);
         hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, row_first, n_rows, knn, row_ptr, col,
-                           n_blocks, bk_in, bk_out, nk_in, nk_out, uncovered_out, blk_ptr, node_ptr);
+                           n_blocks, bk_in, bk_out, nk_in, nk_out, unc_ws, blk_ptr, node_ptr);
+        hipLaunchKernelGGL(plan_flag_out_kernel, dim3(1), dim3(1), 0, s, unc_ws, uncovered_out);
         hipLaunchKernelGGL(plan_iota_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, bv_in, (long)E, nv_in, (long)E2);
         DFH_HIP_CHECK(hipGetLastError());
         DFH_HIP_CHECK(rocprim::radix_sort_pairs<SortCfg>(w, temp, bk_in, bk_out, bv_in, blk_ent, E, 0u, bits_for((unsigned long long)n_blocks + 1ull), s));
@@ -432,8 +440,8 @@ int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const
     hipLaunchKernelGGL(plan_zero2_kernel, dim3((unsigned)((n_blocks + n_nodes + 2 + 255) / 256)), dim3(256), 0, s, blk_ptr, n_blocks + 1,
                        node_ptr, n_nodes + 1);
     hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, row_first, n_rows, knn, row_ptr, col,
-                       n_blocks, bk_in, bv_in, nk_in, nv_in, uncovered_out, blk_ptr, node_ptr);
-    hipLaunchKernelGGL(plan_scan2_kernel, dim3(2), dim3(1024), 0, s, blk_ptr, n_blocks, node_ptr, n_nodes);
+                       n_blocks, bk_in, bv_in, nk_in, nv_in, unc_ws, blk_ptr, node_ptr);
+    hipLaunchKernelGGL(plan_scan2_kernel, dim3(2), dim3(1024), 0, s, blk_ptr, n_blocks, node_ptr, n_nodes, unc_ws, uncovered_out);
     hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, bk_in, bv_in, (long)E, n_blocks, blk_ptr, blk_ent,
                        nk_in, nv_in, (long)E2, node_ptr, node_ent);
     hipLaunchKernelGGL(plan_sort_lists_kernel, dim3((unsigned)((n_blocks + n_nodes + 3) / 4)), dim3(256), 0, s, blk_ptr, blk_ent, n_blocks,

@@ -437,13 +437,15 @@ class WarpSolver:
         self.blk_ent = torch.empty(R * k * k, dtype=torch.int32, device=dev)
         self.node_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.node_ent = torch.empty(R * k, dtype=torch.int32, device=dev)
-        unc = torch.empty(1, dtype=torch.int32, device=dev)
+        # (the "pattern must grow" flag: one plain store of the plan's scan launch, into pinned host memory where enabled)
+        unc_h = HostScalar(torch.int32) if HostScalar.enabled and not reg else None
+        unc = torch.empty(1, dtype=torch.int32, device=dev) if unc_h is None else None
         nbytes = self.lib.dfh_gn_plan_workspace_bytes(R, k)
         ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
         _lib.check(self.lib.dfh_gn_plan_build(self.snbr.data_ptr(), S, k, N, tile_off.data_ptr(), R, self.row_ptr.data_ptr(),
                                               self.col.data_ptr(), self.B, self.run_id.data_ptr(), self._row_first.data_ptr(),
                                               self.blk_ptr.data_ptr(), self.blk_ent.data_ptr(), self.node_ptr.data_ptr(),
-                                              self.node_ent.data_ptr(), unc.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                              self.node_ent.data_ptr(), unc.data_ptr() if unc_h is None else unc_h.ptr(), ws.data_ptr(), ws.numel() * 8,
                                               current_stream_ptr()), "dfh_gn_plan_build")
         ne = int(self.lib.dfh_gn_partial_doubles(k))
         self.partial = torch.empty(max(1, R * ne) + 2 * n_tiles + R, dtype=torch.float64, device=dev)   # rows | {cost, count} per tile | live flag per row
@@ -451,7 +453,7 @@ class WarpSolver:
         if reg:
             self._build_reg_plan(keys)
             return True
-        pending = _AsyncScalar(unc)
+        pending = _AsyncScalar(unc) if unc_h is None else unc_h
         if len(overlap) > 1:
             overlap[1]()
         return pending.get() == 0

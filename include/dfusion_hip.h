@@ -290,6 +290,8 @@ int dfh_gn_build_planned_assoc(const double *sample_pos, const double *sample_nr
  *   input index of the i-th sorted sample.
  * dfh_gn_plan_count:   rows = maximal runs of equal tuples inside 256-sample tiles of the SORTED nbr; tile_off
  *   (ceil(n_samples/256) + 1 ints) <- first row of every tile, *n_rows_out (device) <- number of rows.
+ *   (*n_rows_out, like *uncovered_out below and dfh_surface_count's *total_out, is written by ONE plain store of the sequence's
+ *   last writer: it may be device memory or pinned host memory, which the host can then watch instead of queueing a copy.)
  * dfh_gn_plan_build:   run_id (n_samples), row_first (n_rows: first sample of every row) and the CSR lists of
  *   dfh_gn_build_planned -- blk_ptr (n_blocks + 1) / blk_ent (n_rows * knn^2), node_ptr (n_nodes + 1) / node_ent (n_rows * knn),
  *   every list in ascending entry order; *uncovered_out (device int) <- 1 if some node pair of some row is not a block

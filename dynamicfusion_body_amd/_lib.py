@@ -34,6 +34,9 @@ _SIGNATURES = {
     "dfh_integrate_depth_multi": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _int, _int, ctypes.POINTER(ctypes.c_void_p), _int, _int,
                                          _int, _c_double_p, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp,
                                          ctypes.c_size_t, _vp]),
+    "dfh_integrate_depth_multi_fresh": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _int, _dbl, _int, ctypes.POINTER(ctypes.c_void_p), _int, _int,
+                                         _int, _c_double_p, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp,
+                                         ctypes.c_size_t, _vp]),
     "dfh_fuse_volume_rigid": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _vp, _int, _c_int_p,
                                      _c_double_p, _dbl, _dbl, _vp]),
     "dfh_dqb_workspace_bytes": (ctypes.c_size_t, [_c_int_p, _int, _int]),

@@ -561,19 +561,33 @@ __global__ __launch_bounds__(256) void integrate_depth_brick_kernel(float *__res
     *reinterpret_cast<P *>(tsdf_w + off) = w;
 }
 
-template <typename DepthT, bool PINHOLE>
+// FRESH: the volume is taken to be (fresh_t, 0) everywhere -- a live volume that starts from np.zeros + tdist / np.zeros
+// (core/fusion_dm.py:152-153) -- so nothing is loaded and EVERY pack is written: the fill and the sweep in one pass over the
+// volume (one write of it instead of a write, a read of the updated part and another write).
+template <typename DepthT, bool PINHOLE, bool FRESH>
 __global__ __launch_bounds__(256) void integrate_depth_multi_brick_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
                                                                            const IntegrateParams *__restrict__ views, const ViewPtrs vp,
-                                                                           const BrickGeom g, const unsigned short *__restrict__ mask) {
+                                                                           const BrickGeom g, const unsigned short *__restrict__ mask,
+                                                                           const float fresh_t) {
     int xl, y, z0, brick;
     brick_coords(views[0], g, xl, y, z0, brick);
     unsigned m = mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)mask[__builtin_amdgcn_readfirstlane(brick)]) : (1u << vp.n) - 1u;
-    if (m == 0) return;
     const bool in_grid = xl < views[0].nx && y < views[0].Y && z0 < views[0].Z;
     using P = Pack<float, 4>;
-    P t, w;
-    bool loaded = false;
     const size_t off = ((size_t)xl * views[0].Y + y) * views[0].Z + z0;
+    P t, w;
+    if (FRESH) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t.v[j] = fresh_t; w.v[j] = 0.0f; }
+    }
+    if (m == 0) {
+        if (FRESH && in_grid) {
+            *reinterpret_cast<P *>(tsdf + off) = t;
+            *reinterpret_cast<P *>(tsdf_w + off) = w;
+        }
+        return;
+    }
+    bool loaded = FRESH;
     while (m) {                                           // views in ascending order: the order of consecutive sweeps
         const int v = __builtin_ctz(m);
         m &= m - 1;
@@ -589,10 +603,15 @@ __global__ __launch_bounds__(256) void integrate_depth_multi_brick_kernel(float 
         }
         apply_pack<4>(t, w, ms, upd, p.wmax_f);
     }
-    if (loaded) {
+    if (loaded && in_grid) {
         *reinterpret_cast<P *>(tsdf + off) = t;
         *reinterpret_cast<P *>(tsdf_w + off) = w;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_pair_kernel(T *__restrict__ a, T va, T *__restrict__ b, T vb, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { a[i] = va; b[i] = vb; }
 }
 
 // Parameters of up to kParamChunk views from the kernel-argument segment into device memory (see dfh_integrate_depth_multi)
@@ -991,14 +1010,31 @@ extern "C" size_t dfh_integrate_multi_workspace_bytes(int n_views) {
     return n_views > 0 ? dfh::params_bytes(n_views) : 0;
 }
 
-extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
-                                         int n_views, const void *const *depth, int depth_dtype, int H, int W,
-                                         const double K[9], const double Kinv[9], const double *lw, double scale,
-                                         const double center[3], double tdist, double wmax, void *workspace,
-                                         size_t workspace_bytes, void *stream) {
+// fresh: the volumes start as (fresh_value, 0): filled here, or -- brick sweep -- by the sweep itself
+static int integrate_multi_fill(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int x0, int x1, double fresh_value, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(tsdf && tsdf_w && res, "dfh_integrate_depth_multi_fresh: null pointer");
+    DFH_REQUIRE(vol_dtype == DFH_F32 || vol_dtype == DFH_F64, "dfh_integrate_depth_multi_fresh: bad vol_dtype %d", vol_dtype);
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0 && 0 <= x0 && x0 <= x1 && x1 <= res[0], "dfh_integrate_depth_multi_fresh: bad grid or slab");
+    const size_t n = (size_t)(x1 - x0) * res[1] * res[2];
+    if (n == 0) return DFH_OK;
+    const unsigned nb = (unsigned)((n + 255) / 256 < 65536 * 16 ? (n + 255) / 256 : 65536 * 16);
+    if (vol_dtype == DFH_F32)
+        hipLaunchKernelGGL(fill_pair_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (float *)tsdf, (float)fresh_value, (float *)tsdf_w, 0.0f, n);
+    else
+        hipLaunchKernelGGL(fill_pair_kernel<double>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (double *)tsdf, fresh_value, (double *)tsdf_w, 0.0, n);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+static int integrate_multi_impl(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
+                                int n_views, const void *const *depth, int depth_dtype, int H, int W,
+                                const double K[9], const double Kinv[9], const double *lw, double scale,
+                                const double center[3], double tdist, double wmax, void *workspace,
+                                size_t workspace_bytes, void *stream, bool fresh, double fresh_value) {
     using namespace dfh;
     DFH_REQUIRE(n_views >= 0 && n_views <= kMaxViews, "dfh_integrate_depth_multi: %d views (at most %d per call)", n_views, kMaxViews);
-    if (n_views == 0) return DFH_OK;
+    if (n_views == 0) return fresh ? integrate_multi_fill(tsdf, tsdf_w, vol_dtype, res, x0, x1, fresh_value, stream) : DFH_OK;
     DFH_REQUIRE(tsdf && tsdf_w && depth && res && K && Kinv && lw && center, "dfh_integrate_depth_multi: null pointer");
     for (int v = 0; v < n_views; ++v) DFH_REQUIRE(depth[v], "dfh_integrate_depth_multi: depth map %d is null", v);
     DFH_REQUIRE(vol_dtype == DFH_F32 || vol_dtype == DFH_F64, "dfh_integrate_depth_multi: bad vol_dtype %d", vol_dtype);
@@ -1010,6 +1046,10 @@ extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype
                          workspace && workspace_bytes >= dfh_integrate_multi_workspace_bytes(n_views) && !getenv("DFH_K1_NO_MULTI");
     if (!fast_ok || n_views == 1 || x1 <= x0) {
         // one sweep per view: the same results (every argument is checked there)
+        if (fresh) {
+            const int rc = integrate_multi_fill(tsdf, tsdf_w, vol_dtype, res, x0, x1, fresh_value, stream);
+            if (rc != DFH_OK) return rc;
+        }
         for (int v = 0; v < n_views; ++v) {
             const int rc = dfh_integrate_depth(tsdf, tsdf_w, vol_dtype, res, tsdf_res, x0, x1, depth[v], depth_dtype, H, W, K, Kinv,
                                                lw + 12 * v, scale, center, tdist, wmax, workspace, workspace_bytes, stream);
@@ -1058,12 +1098,18 @@ extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype
             if (pinhole) hipLaunchKernelGGL((brick_classify_kernel<true, false>), cgrid, dim3(256), 0, s, dv, p, n_views, g, n_bricks, mask);
             else hipLaunchKernelGGL((brick_classify_kernel<false, false>), cgrid, dim3(256), 0, s, dv, p, n_views, g, n_bricks, mask);
         }
-#define DFH_MBRICK(DT, PH) hipLaunchKernelGGL((integrate_depth_multi_brick_kernel<DT, PH>), bgrid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, dv, vp, g, mask)
-        if (depth_dtype == DFH_F32) { if (pinhole) DFH_MBRICK(float, true); else DFH_MBRICK(float, false); }
-        else { if (pinhole) DFH_MBRICK(double, true); else DFH_MBRICK(double, false); }
+#define DFH_MBRICK(DT, PH, FR) hipLaunchKernelGGL((integrate_depth_multi_brick_kernel<DT, PH, FR>), bgrid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, dv, vp, g, mask, (float)fresh_value)
+#define DFH_MBRICK2(DT, PH) do { if (fresh) DFH_MBRICK(DT, PH, true); else DFH_MBRICK(DT, PH, false); } while (0)
+        if (depth_dtype == DFH_F32) { if (pinhole) DFH_MBRICK2(float, true); else DFH_MBRICK2(float, false); }
+        else { if (pinhole) DFH_MBRICK2(double, true); else DFH_MBRICK2(double, false); }
+#undef DFH_MBRICK2
 #undef DFH_MBRICK
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
+    }
+    if (fresh) {                                                    // (the plain multi-view sweep loads what it updates)
+        const int rc = integrate_multi_fill(tsdf, tsdf_w, vol_dtype, res, x0, x1, fresh_value, stream);
+        if (rc != DFH_OK) return rc;
     }
     dim3 grid((unsigned)(((long)p.Y * p.zpacks + 255) / 256), (unsigned)((p.nx + p.planes_per_block - 1) / p.planes_per_block)), block(256);
 #define DFH_MULTI(DT, VEC, PH) hipLaunchKernelGGL((integrate_depth_multi_kernel<DT, VEC, PH>), grid, block, 0, s, (float *)tsdf, (float *)tsdf_w, dv, vp)
@@ -1077,6 +1123,24 @@ extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype
 #undef DFH_MULTI
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
+}
+
+extern "C" int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
+                                         int n_views, const void *const *depth, int depth_dtype, int H, int W,
+                                         const double K[9], const double Kinv[9], const double *lw, double scale,
+                                         const double center[3], double tdist, double wmax, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+    return integrate_multi_impl(tsdf, tsdf_w, vol_dtype, res, tsdf_res, x0, x1, n_views, depth, depth_dtype, H, W, K, Kinv, lw, scale, center,
+                                tdist, wmax, workspace, workspace_bytes, stream, false, 0.0);
+}
+
+extern "C" int dfh_integrate_depth_multi_fresh(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
+                                               double fresh_value, int n_views, const void *const *depth, int depth_dtype, int H, int W,
+                                               const double K[9], const double Kinv[9], const double *lw, double scale,
+                                               const double center[3], double tdist, double wmax, void *workspace,
+                                               size_t workspace_bytes, void *stream) {
+    return integrate_multi_impl(tsdf, tsdf_w, vol_dtype, res, tsdf_res, x0, x1, n_views, depth, depth_dtype, H, W, K, Kinv, lw, scale, center,
+                                tdist, wmax, workspace, workspace_bytes, stream, true, fresh_value);
 }
 
 extern "C" int dfh_integrate_depth_ocl(float *tsdf, float *tsdf_w, const int res[3], int x0, int x1, const float *depth, int H, int W,

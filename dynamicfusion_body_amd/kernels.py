@@ -108,11 +108,13 @@ def integrate_depth_ocl(T, Wt, depth, proj, kinv_row2, tdist, wmax=100.0, res=No
 
 
 def integrate_depth_views(T, Wt, depths, K, Kinv, lws, scale, center, tdist, wmax=100.0, tsdf_res=None, res=None,
-                          x_range=None, workspace=None):
+                          x_range=None, workspace=None, fresh=None):
     """Several views in one sweep of the volume (dfh_integrate_depth_multi): same result, bit for bit, as
     integrate_depth called once per view in this order (what the reference's loops over fuseDepths do,
     core/fusion_dm.py:152-154,166-170), with T and w read and written once.  depths: list of (H, W) CUDA tensors of one
-    shape and dtype; lws: list of 3x4 extrinsics.  More than 16 views are taken 16 at a time."""
+    shape and dtype; lws: list of 3x4 extrinsics.  More than 16 views are taken 16 at a time.
+    fresh=value: T and Wt are first set to (value, 0) -- a live volume from scratch, core/fusion_dm.py:152-153 -- as part of the
+    same sweep (dfh_integrate_depth_multi_fresh): what T.fill_(value); Wt.zero_() in front of this call give, bit for bit."""
     require_gpu()
     lib = _lib.load()
     depths, lws = list(depths), list(lws)
@@ -125,7 +127,12 @@ def integrate_depth_views(T, Wt, depths, K, Kinv, lws, scale, center, tdist, wma
     if tsdf_res is None:
         tsdf_res = res[0]
     _check_volume_pair(T, Wt, res, x_range)
-    if x_range[1] == x_range[0] or not depths:
+    if x_range[1] == x_range[0]:
+        return T, Wt
+    if not depths:
+        if fresh is not None:
+            T.fill_(float(fresh))
+            Wt.zero_()
         return T, Wt
     for d in depths:
         if not (isinstance(d, torch.Tensor) and d.is_cuda and d.dim() == 2 and d.is_contiguous()):
@@ -141,12 +148,14 @@ def integrate_depth_views(T, Wt, depths, K, Kinv, lws, scale, center, tdist, wma
             integrate_workspace(n, H, W, res, x_range, T.device)
         ptrs = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dd])
         lw_flat = np.concatenate([np.asarray(l, dtype=np.float64).reshape(12) for l in ll])
-        rc = lib.dfh_integrate_depth_multi(T.data_ptr(), Wt.data_ptr(), dtype_code(T), _lib.iarr(res), int(tsdf_res), int(x_range[0]),
-                                           int(x_range[1]), n, ptrs, dtype_code(dd[0]), int(H), int(W), _lib.darr(K, 9),
-                                           _lib.darr(Kinv, 9), _lib.darr(lw_flat, 12 * n), float(scale),
-                                           _lib.darr(np.asarray(center, dtype=np.float64), 3), float(tdist), float(wmax),
-                                           ws.data_ptr(), ws.numel() * ws.element_size(), current_stream_ptr())
-        _lib.check(rc, "dfh_integrate_depth_multi")
+        tail = (n, ptrs, dtype_code(dd[0]), int(H), int(W), _lib.darr(K, 9), _lib.darr(Kinv, 9), _lib.darr(lw_flat, 12 * n), float(scale),
+                _lib.darr(np.asarray(center, dtype=np.float64), 3), float(tdist), float(wmax), ws.data_ptr(),
+                ws.numel() * ws.element_size(), current_stream_ptr())
+        head = (T.data_ptr(), Wt.data_ptr(), dtype_code(T), _lib.iarr(res), int(tsdf_res), int(x_range[0]), int(x_range[1]))
+        if fresh is not None and i == 0:
+            _lib.check(lib.dfh_integrate_depth_multi_fresh(*head, float(fresh), *tail), "dfh_integrate_depth_multi_fresh")
+        else:
+            _lib.check(lib.dfh_integrate_depth_multi(*head, *tail), "dfh_integrate_depth_multi")
     return T, Wt
 
 

@@ -247,12 +247,11 @@ class SlabFrame:
             raise ValueError('length of camera matrix array must equal that of depth maps')
         depth, lw_cam = depth_list[0], lw_list[0]
         def sweep_live():
-            self.live.fill_(self.tvox)
-            self.live_w.zero_()
             if self.ws_views is None:
                 self.ws_views = kernels.integrate_workspace(min(len(depth_list), 16), depth.shape[0], depth.shape[1], (R, R, R), (self.a, self.b), self.live.device)
             kernels.integrate_depth_views(self.live, self.live_w, depth_list, self.K, self.Kinv, lw_list, self.scale, self.center,
-                                          self.tdist_world, tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_views)
+                                          self.tdist_world, tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_views,
+                                          fresh=self.tvox)          # (the fill of the live volume is part of the sweep)
         # The solver's per-frame plan depends on the samples only and the live volume on the depth maps only: the live-volume
         # sweep (bandwidth-bound) runs on a side stream beside the plan's launches (bound by latency and atomics, with two
         # read-backs in between); the streams join before the first GN iteration.  With stage timing the order is sequential.

@@ -91,6 +91,18 @@ int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype, const int
                               const double center[3], double tdist, double wmax, void *workspace,
                               size_t workspace_bytes, void *stream);
 
+/* A live volume from scratch: the volumes are first set to (fresh_value, 0) -- the reference's np.zeros(...) + tdist and
+ * np.zeros(...) in front of its fuseDepths loops, core/fusion_dm.py:100-101,152-153 -- and the n_views depth maps are then fused as
+ * by dfh_integrate_depth_multi: the result is that of the two fills followed by that call, bit for bit (fresh_value is rounded to
+ * the volume's type).  With the brick sweep the fill is part of the sweep: nothing is read and every voxel of the slab is written
+ * once (a 256^3 live volume of three views: fills 38 + sweep 89 -> sweep 84 us); otherwise the slab is filled by a launch of its own first.
+ * n_views == 0 only fills. */
+int dfh_integrate_depth_multi_fresh(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
+                                    double fresh_value, int n_views, const void *const *depth, int depth_dtype, int H, int W,
+                                    const double K[9], const double Kinv[9], const double *lw, double scale,
+                                    const double center[3], double tdist, double wmax, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+
 /* A2 (optional)  the arithmetic of the reference's OpenCL kernel `fuse_depth`  core/fusion_dm.py:630-674 -- NOT that of the CPU
  * path above: index -> pixel through one float32 3x4 map proj = K lw IND (:640-646,:695), bilinear depth (:605-622), pixels without
  * or with near depth (pz <= tdist) carve free space (dz = -tdist, :652-653), dz = voxel depth - measured depth (:655-658), update

@@ -209,6 +209,41 @@ def test_multi_view_sweep_many_views_and_errors():
         kernels.integrate_depth_views(Te, We, [dms[0], dms[1].double()], K, Kinv, lws[:2], scale, center, tdist)
 
 
+def test_fresh_live_volume_equals_fill_then_sweep(monkeypatch):
+    """dfh_integrate_depth_multi_fresh (the fill of a live volume folded into the multi-view sweep, core/fusion_dm.py:152-153 +
+    :166-170) against T.fill_(value); W.zero_(); dfh_integrate_depth_multi -- every voxel, bit for bit: brick sweep (every brick is
+    written, culled or not), a slab with global plane indices, the plain sweep (DFH_K1_NO_BRICKS), one view, no view, more
+    than 16 views, a ragged grid and a float64 volume; the volumes start as garbage."""
+    rng = np.random.default_rng(21)
+    K = scene.intrinsics(150.3, 79.7, 59.6)
+    Kinv = np.linalg.inv(K)
+    H, W_ = 120, 160
+    for res, x_range, dtype, n_views, no_bricks in (((64, 64, 64), None, torch.float32, 3, False), ((20, 64, 64), (22, 42), torch.float32, 4, False),
+                                                    ((64, 64, 64), None, torch.float32, 3, True), ((32, 28, 30), None, torch.float32, 2, False),
+                                                    ((32, 32, 32), None, torch.float64, 2, False), ((48, 48, 48), None, torch.float32, 1, False),
+                                                    ((16, 32, 32), None, torch.float32, 0, False), ((24, 32, 32), None, torch.float32, 18, False)):
+        R = 64 if x_range else res[1]
+        scale = scene.GRID_SIDE / R
+        center, tdist = scene.SPHERE_C, 4.0 * scale
+        lws = [scene.view_extrinsic(float(a)) for a in rng.uniform(-60, 60, size=n_views)]
+        dms = [torch.from_numpy(scene.render_depth(K, lw, H, W_, dtype=np.float32, invalid_frac=0.02, seed=int(i))).cuda() for i, lw in enumerate(lws)]
+        grid = (R, res[1], res[2]) if x_range else res
+        kw = dict(wmax=7.0, tsdf_res=R, res=grid, x_range=x_range or (0, res[0]))
+        if no_bricks:
+            monkeypatch.setenv("DFH_K1_NO_BRICKS", "1")
+        else:
+            monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
+        fill = tdist / scale
+        Ta = torch.full(res, fill, dtype=dtype, device="cuda"); Wa = torch.zeros_like(Ta)
+        kernels.integrate_depth_views(Ta, Wa, dms, K, Kinv, lws, scale, center, tdist, **kw)
+        Tb = torch.from_numpy(rng.normal(size=res)).to("cuda", dtype=dtype); Wb = torch.from_numpy(rng.uniform(1, 9, size=res)).to("cuda", dtype=dtype)
+        kernels.integrate_depth_views(Tb, Wb, dms, K, Kinv, lws, scale, center, tdist, fresh=fill, **kw)
+        assert torch.equal(Ta, Tb) and torch.equal(Wa, Wb), (res, x_range, dtype, n_views, no_bricks)
+        if n_views:
+            assert int((Wa > 0).sum()) > 0 and int((Wa == 0).sum()) > 0
+    monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
+
+
 def test_slab_sweeps_equal_full_sweep():
     """Slab partition along axis 0 (multi-GPU layout): per-slab buffers with global indices
     reproduce the full sweep bit for bit."""

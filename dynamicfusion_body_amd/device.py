@@ -38,6 +38,7 @@ class HostScalar:
 
     def __init__(self, dtype=torch.int32):
         self._dtype = dtype
+        self._np = None
         if HostScalar.enabled:
             free = HostScalar._pool.setdefault(dtype, [])
             self._t = free.pop() if free else torch.empty(1, dtype=dtype).pin_memory()
@@ -49,8 +50,8 @@ class HostScalar:
     def ptr(self):
         return self._t.data_ptr()
 
-    def get(self, timeout=20.0):
-        if not HostScalar.enabled:
+    def get(self, timeout=2.0):
+        if self._np is None:                           # (a device scalar: created while the host-visible form was off)
             return int(self._t.item())
         a = self._np
         spins = 0
@@ -65,6 +66,9 @@ class HostScalar:
                     torch.cuda.synchronize()           # raises if a launch of the sequence failed
                     if a[0] == -1:
                         raise _lib.DfhError("a kernel's host-visible scalar never arrived")
+                    # it arrived with the synchronisation only (pinned memory that is not host-coherent in this process, or a
+                    # device busy for seconds): correct, but not worth spinning for again
+                    HostScalar.enabled = False
         v = int(a[0])
         HostScalar._pool[self._dtype].append(self._t)
         self._t = self._np = None

@@ -347,15 +347,19 @@ class FusionDM:
                     self.updateTSDF(T)
             T, Wt = self._T, self._Wt
         else:
-            T, Wt = self._new_volume_pair()
             dev = [self._depth_to_device(d) for d in depths]
             if len(dev) > 1 and len({(tuple(d.shape), d.dtype) for d in dev}) == 1 and \
                     all(np.asarray(l).shape == (3, 4) for l in lws):
-                # the loop below as ONE sweep of the volume (same bits: kernels.integrate_depth_views)
+                # the loop below as ONE sweep of the volume, the initial values (:100-101) included (same bits:
+                # kernels.integrate_depth_views with fresh=)
+                r = self._tsdf_res
+                T = torch.empty((r, r, r), dtype=self._vol_dtype, device="cuda")
+                Wt = torch.empty_like(T)
                 kernels.integrate_depth_views(T, Wt, dev, self._K, self._Kinv, [np.asarray(l, dtype=np.float64) for l in lws],
-                                              12 * std / res, avg, self._tdist, 100.0, tsdf_res=self._tsdf_res)
+                                              12 * std / res, avg, self._tdist, 100.0, tsdf_res=self._tsdf_res, fresh=self._tdist)
                 self._depthidx = len(depths) - 1
             else:
+                T, Wt = self._new_volume_pair()
                 for idx in range(len(depths)):                      # :166-170
                     self._depthidx = idx
                     self.fuseDepths(dev[idx], lws[idx], T, Wt, scale=12 * std / res, center=avg)

@@ -694,7 +694,13 @@ struct RegTail {
     double *partial_reg;
     double rw;
     int N, k, n_tiles;
+    // dfh_gn_iteration: doubles the launch's LAST workgroups set to zero (the solve's workspace: its clearing rides along here
+    // instead of being a launch of its own between gather and solve); first_zero_wg = index of the first such workgroup
+    double *zero_ptr;
+    unsigned long long zero_count;
+    int first_zero_wg;
 };
+constexpr int kZeroPerWg = 1024;                 // doubles one workgroup clears (256 threads x 4)
 __device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N, int k, const double *__restrict__ node_dq,
                              const double *__restrict__ node_pos, const double *__restrict__ node_w, double rw,
                              const int *__restrict__ row_ptr, const int *__restrict__ col, double *__restrict__ vals,
@@ -727,6 +733,13 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
                                                              double *__restrict__ cost_count, const int *__restrict__ run_id,
                                                              double *__restrict__ partial, double *__restrict__ tile_cost,
                                                              const RegTail rt, const AssocArgs aa) {
+    if (PLANNED && rt.zero_ptr && (int)blockIdx.x >= rt.first_zero_wg) {     // (workgroup-uniform) clearing that rides along
+        const unsigned long long i0 = (unsigned long long)((int)blockIdx.x - rt.first_zero_wg) * kZeroPerWg + 4ull * threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < rt.zero_count) rt.zero_ptr[i0 + j] = 0.0;
+        return;
+    }
     if (PLANNED && (int)blockIdx.x >= rt.n_tiles) {      // (workgroup-uniform) the regulariser's share of this launch
         gn_reg_pairs((int)blockIdx.x - rt.n_tiles, rt.node_nbr, rt.N, rt.k, node_dq, rt.node_pos, rt.node_w, rt.rw, row_ptr, col, vals,
                      rhs, cost_count, rt.partial_reg);
@@ -2357,8 +2370,10 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
                          double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
                          const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
                          const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
-                         void *stream, const dfh::AssocArgs *assoc = nullptr) {
+                         void *stream, const dfh::AssocArgs *assoc = nullptr, double *zero_ptr = nullptr, size_t zero_count = 0,
+                         bool *zeroed = nullptr) {
     using namespace dfh;
+    if (zeroed) *zeroed = false;
     const bool planned = blk_ptr != nullptr;
     DFH_REQUIRE(!assoc || planned, "dfh_gn_build: association inside the build needs a plan");
     DFH_REQUIRE(huber_delta >= 0.0, "dfh_gn_build: negative huber_delta");
@@ -2399,7 +2414,13 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
             rt.node_nbr = node_nbr; rt.node_pos = node_pos; rt.node_w = node_w; rt.partial_reg = partial_reg;
             rt.rw = rw; rt.N = n_nodes; rt.k = knn;
         }
-        dim3 grid((unsigned)(n_tiles + (reg_in_data_launch ? (n_nodes * knn + 3) / 4 : 0))), block(256);
+        unsigned n_wg = (unsigned)(n_tiles + (reg_in_data_launch ? (n_nodes * knn + 3) / 4 : 0));
+        if (planned && zero_ptr && zero_count > 0 && (zero_count + kZeroPerWg - 1) / kZeroPerWg < (1u << 20)) {
+            rt.zero_ptr = zero_ptr; rt.zero_count = zero_count; rt.first_zero_wg = (int)n_wg;
+            n_wg += (unsigned)((zero_count + kZeroPerWg - 1) / kZeroPerWg);
+            if (zeroed) *zeroed = true;
+        }
+        dim3 grid(n_wg), block(256);
         const AssocArgs aa = assoc ? *assoc : AssocArgs{};
 #define DFH_BUILD(KK)                                                                                               \
     case KK:                                                                                                        \
@@ -2604,9 +2625,18 @@ int dfh_pcg_status_peek(void *stream, long *aborted_solves_out) {
     return dfh_pcg_status(stream, aborted_solves_out);
 }
 
+// the part of the workspace a solve expects all-zero at its start: the multi-launch path's first direction and its scalars, the
+// persistent kernel's scalars, reduction slots and hand-off ring (zero bits = "not yet published")
+static void pcg_zero_range(void *workspace, int n_nodes, int iters, double **begin, size_t *count) {
+    const size_t N6 = 6 * (size_t)n_nodes;
+    const size_t n_scal = 3 * ((size_t)iters + 2) + 2 * ((size_t)iters + 1) * (((size_t)n_nodes + 3) / 4);
+    *begin = static_cast<double *>(workspace) + 36 * (size_t)n_nodes + 4 * N6;         // = pA
+    *count = N6 + n_scal + 12 * N6;
+}
+
 static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
                           double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, double *update_dq,
-                          double update_step, void *stream) {
+                          double update_step, void *stream, bool precleared = false) {
     using namespace dfh;
     DFH_REQUIRE(n_nodes >= 1 && iters >= 1, "dfh_pcg_solve: bad sizes");
     DFH_REQUIRE(row_ptr && col && vals && rhs && x_out && workspace, "dfh_pcg_solve: null pointer");
@@ -2678,7 +2708,7 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
             (void)hipGetLastError();
             abort_host = nullptr;
         }
-        DFH_HIP_CHECK(hipMemsetAsync(scal, 0, sizeof(double) * (n_scal + 12 * N6), s));
+        if (!precleared) DFH_HIP_CHECK(hipMemsetAsync(scal, 0, sizeof(double) * (n_scal + 12 * N6), s));
         unsigned spin_limit = kSpinLimit;
         if (const char *e = getenv("DFH_PCG_SPIN_LIMIT")) spin_limit = (unsigned)strtoul(e, nullptr, 10);
         unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
@@ -2692,7 +2722,7 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }
-    DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + n_scal), s));
+    if (!precleared) DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + n_scal), s));
     // scal[0..2] belongs to the init (rz0 in scal[2] so that iteration 0 reads it as "rz_next")
     hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, z, scal + 2);
     double *p_prev = pA, *p_cur = pB;
@@ -2739,6 +2769,40 @@ int dfh_pcg_solve_update(const int *row_ptr, const int *col, double *vals, const
     using namespace dfh;
     DFH_REQUIRE(node_dq, "dfh_pcg_solve_update: null node_dq");
     return pcg_solve_impl(row_ptr, col, vals, rhs, n_nodes, iters, lm_abs, lm_rel, x_out, workspace, workspace_bytes, node_dq, step, stream);
+}
+
+int dfh_gn_iteration(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                     double *corr_out, unsigned char *valid_out, int n_samples, int knn, double *node_dq,
+                     const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                     const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                     double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                     const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                     const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                     const float *depth, int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12],
+                     double scale, const double center[3], double half, double max_dist,
+                     int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
+                     double step, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(blk_ptr, "dfh_gn_iteration: null blk_ptr");
+    DFH_REQUIRE(depth && K && Kinv && lw_cam && center && lw_dq && corr_out && valid_out && node_dq, "dfh_gn_iteration: null pointer");
+    DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "dfh_gn_iteration: bad depth map / scale");
+    DFH_REQUIRE(n_nodes >= 1 && pcg_iters >= 1 && x_out && pcg_workspace, "dfh_gn_iteration: bad solve arguments");
+    DFH_REQUIRE(pcg_workspace_bytes >= dfh_pcg_workspace_bytes(n_nodes, pcg_iters), "dfh_gn_iteration: solve workspace too small");
+    AssocArgs aa;
+    int rc = fill_assoc_params(aa.ap, lw_dq, H, W, K, Kinv, lw_cam, scale, center, half, max_dist, knn);
+    if (rc != DFH_OK) return rc;
+    aa.depth = depth;
+    double *zbegin = nullptr;
+    size_t zcount = 0;
+    pcg_zero_range(pcg_workspace, n_nodes, pcg_iters, &zbegin, &zcount);
+    bool zeroed = false;
+    rc = gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
+                       n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
+                       blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream, &aa,
+                       getenv("DFH_GN_ITER_OWN_CLEAR") ? nullptr : zbegin, zcount, &zeroed);
+    if (rc != DFH_OK) return rc;
+    return pcg_solve_impl(row_ptr, col, vals, rhs, n_nodes, pcg_iters, lm_abs, lm_rel, x_out, pcg_workspace, pcg_workspace_bytes, node_dq,
+                          step, stream, zeroed);
 }
 
 int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream) {

@@ -97,9 +97,8 @@ class FrameSolver:
 
     def gn_iteration(self, depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.0):
         """associate -> build (+ all-reduce) -> PCG -> twist update; asynchronous."""
-        sv = self.solver
-        sv.build_associated(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, rw, max_dist, huber)
-        sv.solve_update(lm_abs, lm_rel)
+        self.solver.iterate_associated(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, rw, max_dist, huber,
+                                       lm_abs, lm_rel)
 
     def solve(self, depth, lw_cam, rw=5.0, iters=10, **kw):
         costs = []

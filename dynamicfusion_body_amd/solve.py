@@ -602,6 +602,34 @@ class WarpSolver:
         if self.distributed:
             _dist.allreduce_system(self.system)
 
+    def iterate_associated(self, depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist=0.0, huber=0.0, lm_abs=0.0, lm_rel=0.0):
+        """One GN iteration: build_associated + solve_update.  On one GPU (no all-reduce between the halves) through
+        dfh_gn_iteration, one call in which the clearing of the solve's workspace rides in the data-row launch: same bits."""
+        if self._pattern is None:
+            self._build_pattern()
+        one_call = (isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dim() == 2 and depth.is_contiguous() and
+                    depth.dtype == torch.float32 and self.S > 0 and not os.environ.get("DFH_GN_ATOMIC") and
+                    not os.environ.get("DFH_GN_NO_FUSED_ASSOC") and not os.environ.get("DFH_GN_NO_FUSED_ITER") and
+                    not (self.distributed and _dist.world()[1] > 1))
+        if not one_call:
+            self.build_associated(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist, huber)
+            return self.solve_update(lm_abs, lm_rel)
+        nn = 0 if (self.node_nbr is None or rw == 0.0) else self.node_nbr.data_ptr()
+        H, W = depth.shape
+        _lib.check(self.lib.dfh_gn_iteration(
+            self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.corr.data_ptr(),
+            self.valid.data_ptr(), self.S, self.knn, self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(),
+            nn, self.N, _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
+            self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(), self.run_id.data_ptr(), self.n_rows,
+            self.partial.data_ptr(), self.blk_ptr.data_ptr(), self.blk_ent.data_ptr(), self.node_ptr.data_ptr(),
+            self.node_ent.data_ptr(), *((self.partial_reg.data_ptr(), self.rblk_ptr.data_ptr(), self.rblk_ent.data_ptr(),
+                                         self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
+                                        if self.partial_reg is not None else (0, 0, 0, 0, 0)),
+            float(huber), depth.data_ptr(), int(H), int(W), _lib.darr(K, 9), _lib.darr(Kinv, 9), _lib.darr(lw_cam, 12), float(scale),
+            _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist),
+            self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(), self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, 1.0,
+            current_stream_ptr()), "dfh_gn_iteration")
+
     def solve_update(self, lm_abs=0.0, lm_rel=0.0):
         """PCG + twist update of the node DQs for the system of the last build (asynchronous)."""
         _lib.check(self.lib.dfh_pcg_solve_update(self.row_ptr.data_ptr(), self.col.data_ptr(), self.vals.data_ptr(), self.rhs.data_ptr(),

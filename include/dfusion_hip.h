@@ -330,6 +330,23 @@ int dfh_pcg_solve_update(const int *row_ptr, const int *col, double *vals, const
                          double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, double *node_dq,
                          double step, void *stream);
 
+/* One whole Gauss-Newton iteration of a single-GPU solve: dfh_gn_build_planned_assoc followed by dfh_pcg_solve_update on the
+ * system it produced (vals / rhs -> x_out, node_dq <- exp(step * x) node_dq) -- the same bits as the two calls.  Knowing both
+ * halves, the library lets the clearing of the solve's workspace ride in the data-row launch (its last workgroups) instead of
+ * being a 5 us fill between gather and solve.  Multi-GPU solves keep the two calls (the all-reduce of vals / rhs / cost_count
+ * goes between them).  Reference: the body of least_squares' iteration for Fusion.computef, core/fusion.py:356-389. */
+int dfh_gn_iteration(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                     double *corr_out, unsigned char *valid_out, int n_samples, int knn, double *node_dq,
+                     const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                     const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                     double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                     const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                     const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                     const float *depth, int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12],
+                     double scale, const double center[3], double half, double max_dist,
+                     int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
+                     double step, void *stream);
+
 /* The persistent PCG kernel (one launch per solve; its workgroups synchronise through grid-wide reductions) is used
  * when all its workgroups are co-resident: the occupancy query admits a workgroup per CU and the grid needs at most
  * half the CUs.  That cannot be known when several PROCESSES time-share one GPU: such callers declare it with

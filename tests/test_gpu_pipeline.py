@@ -182,7 +182,8 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
     """SlabFrame.step overlaps the live-volume sweep (side stream) with the plan build and reads the plan's counts back through
     pinned memory behind an event; the plan's lists are built by counting + per-list sorts.  The sequential loop
     (DFH_NO_SIDE_STREAM), the radix-sort plan (DFH_PLAN_RADIX), the stage-timed loop (a synchronisation after every stage) and the
-    loop that reads its counts through device scalars instead of host-visible words (HostScalar off) must give the same warp
+    loop that reads its counts through device scalars instead of host-visible words (HostScalar off) and the loop whose GN
+    iterations are two calls (build, solve) instead of dfh_gn_iteration (DFH_GN_NO_FUSED_ITER) must give the same warp
     field and the same canonical volume, bit for bit: a race between the streams, or a count read too early, would show here."""
     from dynamicfusion_body_amd.pipeline import SlabFrame
     from dynamicfusion_body_amd.device import HostScalar
@@ -199,7 +200,7 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
         frames.append([torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0, sphere_offset=off)).cuda() for lw in lws])
 
     def run(env, timed):
-        for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX"):
+        for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX", "DFH_GN_NO_FUSED_ITER"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setattr(HostScalar, "enabled", "NO_HOST_SCALARS" not in env)
         for k in env:
@@ -214,12 +215,13 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
         return counts, sf.fs.solver.node_dq.clone(), sf.T.clone(), sf.Wt.clone()
     ref = run((), False)
     assert HostScalar.enabled
-    for env, timed in ((("DFH_NO_SIDE_STREAM",), False), (("DFH_PLAN_RADIX",), False), (("NO_HOST_SCALARS",), False), ((), True), ((), False)):
+    for env, timed in ((("DFH_NO_SIDE_STREAM",), False), (("DFH_PLAN_RADIX",), False), (("NO_HOST_SCALARS",), False),
+                       (("DFH_GN_NO_FUSED_ITER",), False), ((), True), ((), False)):
         got = run(env, timed)
         assert got[0] == ref[0], (env, timed)
         for a, b in zip(got[1:], ref[1:]):
             assert torch.equal(a, b), (env, timed)
-    for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX"):
+    for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX", "DFH_GN_NO_FUSED_ITER"):
         monkeypatch.delenv(k, raising=False)
 
 

@@ -224,17 +224,24 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
     def frame(f, timed=False):
         if mesh_stream is not None:
             torch.cuda.current_stream().wait_stream(mesh_stream)     # the previous frame's mesh has read the canonical volume
-        info["samples"] = sf.step(depths[f], lw_cam, gn_iters=iters, stage_ms=stages if timed else None)
+        pending = []
+
+        def start_mesh():
+            # the mesh needs the updated canonical volume only: its count pass is queued on a second stream the moment the
+            # TSDF update is, beside the sample refresh (count -> emit -> node search -> sort) on the first; the emit
+            # passes follow when the frame's own launches are queued
+            with torch.cuda.stream(mesh_stream):
+                mesh_stream.wait_event(sf.updated)
+                pending.append(mesh.marching_cubes_begin(sf.T, 0.0))
+        info["samples"] = sf.step(depths[f], lw_cam, gn_iters=iters, stage_ms=stages if timed else None,
+                                  on_updated=None if (timed or mesh_stream is None) else start_mesh)
         if world == 1:
             t1 = _t.perf_counter()
             if timed:
                 v, fc, n, val = mesh.marching_cubes(sf.T, 0.0)
             else:
-                # the mesh needs the updated canonical volume only: it is extracted on a second stream from the moment the
-                # TSDF update is done, beside the sample refresh (count -> read-back -> emit -> node search -> sort) on the first
                 with torch.cuda.stream(mesh_stream):
-                    mesh_stream.wait_event(sf.updated)
-                    v, fc, n, val = mesh.marching_cubes(sf.T, 0.0)
+                    v, fc, n, val = pending[0].finish()
             info["vertices"], info["faces"] = int(v.shape[0]), int(fc.shape[0])
             if timed:
                 torch.cuda.synchronize()

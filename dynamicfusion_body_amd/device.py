@@ -36,27 +36,29 @@ class HostScalar:
     _pool = {}
     enabled = not os.environ.get("DFH_NO_HOST_SCALARS")
 
-    def __init__(self, dtype=torch.int32):
-        self._dtype = dtype
+    def __init__(self, dtype=torch.int32, n=1):
+        """n > 1: that many words (each written once by the launch sequence); get() then returns a tuple."""
+        self._dtype, self._n = dtype, int(n)
         self._np = None
         if HostScalar.enabled:
-            free = HostScalar._pool.setdefault(dtype, [])
-            self._t = free.pop() if free else torch.empty(1, dtype=dtype).pin_memory()
+            free = HostScalar._pool.setdefault((dtype, self._n), [])
+            self._t = free.pop() if free else torch.empty(self._n, dtype=dtype).pin_memory()
             self._np = self._t.numpy()
-            self._np[0] = -1
+            self._np[:] = -1
         else:
-            self._t = torch.empty(1, dtype=dtype, device="cuda")
+            self._t = torch.empty(self._n, dtype=dtype, device="cuda")
 
     def ptr(self):
         return self._t.data_ptr()
 
     def get(self, timeout=2.0):
         if self._np is None:                           # (a device scalar: created while the host-visible form was off)
-            return int(self._t.item())
+            v = self._t.tolist()
+            return int(v[0]) if self._n == 1 else tuple(int(x) for x in v)
         a = self._np
         spins = 0
         t_end = None
-        while a[0] == -1:
+        while (a[0] == -1) if self._n == 1 else bool((a == -1).any()):
             spins += 1
             if spins & 0x3ff == 0:                     # (look at the clock every ~1000 reads only)
                 now = time.monotonic()
@@ -64,13 +66,13 @@ class HostScalar:
                     t_end = now + timeout
                 elif now > t_end:
                     torch.cuda.synchronize()           # raises if a launch of the sequence failed
-                    if a[0] == -1:
+                    if (a == -1).any():
                         raise _lib.DfhError("a kernel's host-visible scalar never arrived")
                     # it arrived with the synchronisation only (pinned memory that is not host-coherent in this process, or a
                     # device busy for seconds): correct, but not worth spinning for again
                     HostScalar.enabled = False
-        v = int(a[0])
-        HostScalar._pool[self._dtype].append(self._t)
+        v = int(a[0]) if self._n == 1 else tuple(int(x) for x in a)
+        HostScalar._pool[(self._dtype, self._n)].append(self._t)
         self._t = self._np = None
         return v
 

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import current_stream_ptr, dtype_code, require_gpu
+from .device import HostScalar, current_stream_ptr, dtype_code, require_gpu
 
 
 def marching_cubes(volume, level=None, step_size=1, as_numpy=False, order="reference", visit_all_tiles=False):
@@ -20,50 +20,62 @@ def marching_cubes(volume, level=None, step_size=1, as_numpy=False, order="refer
     order="reference": skimage's numbering (faces cube by cube, vertices by first use, unused vertices
     dropped); order="lattice": vertices by owning lattice point (skips the renumbering pass).
     visit_all_tiles: emit passes over every tile instead of the compacted list (same result; for tests)."""
-    if order not in ("reference", "lattice"):
-        raise ValueError("order must be 'reference' or 'lattice'")
-    require_gpu()
-    lib = _lib.load()
-    if not (isinstance(volume, torch.Tensor) and volume.is_cuda and volume.dim() == 3 and volume.is_contiguous()):
-        raise ValueError("volume must be a contiguous 3-D CUDA tensor")
-    step = int(step_size)
-    if step < 1:
-        raise ValueError("step_size must be at least 1")                         # skimage raises ValueError too
-    if min(volume.shape) < 2:
-        raise ValueError("Input array must be at least 2x2x2.")
-    if level is None:
-        level = 0.5 * (float(volume.min()) + float(volume.max()))
-    level = float(level)
-    res = _lib.iarr(volume.shape)
-    nbytes = lib.dfh_mc_workspace_bytes(res, step)
-    ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=volume.device)
-    totals = torch.zeros(3, dtype=torch.int64, device=volume.device)
-    _lib.check(lib.dfh_mc_count(volume.data_ptr(), dtype_code(volume), res, step, level, ws.data_ptr(), ws.numel() * 8,
-                                totals.data_ptr(), current_stream_ptr()), "dfh_mc_count")
-    nv, nf, nactive = (int(v) for v in totals.tolist())
-    if nv >= (1 << 29) or nf >= (1 << 31) // 3:
-        raise ValueError("surface too large for 32-bit mesh indices (%d vertices, %d faces)" % (nv, nf))
-    dev = volume.device
-    verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
-    normals = torch.empty((nv, 3), dtype=torch.float32, device=dev)
-    values = torch.empty((nv,), dtype=torch.float32, device=dev)
-    faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
-    _lib.check(lib.dfh_mc_emit(volume.data_ptr(), dtype_code(volume), res, step, level, ws.data_ptr(), ws.numel() * 8,
-                               verts.data_ptr(), normals.data_ptr(), values.data_ptr(), faces.data_ptr(), nv, nf, -1 if visit_all_tiles else nactive,
-                               current_stream_ptr()), "dfh_mc_emit")
-    if order == "reference":
-        nbytes = lib.dfh_mc_reorder_workspace_bytes(nv, nf)
-        ws2 = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
-        v2, n2, val2 = torch.empty_like(verts), torch.empty_like(normals), torch.empty_like(values)
-        used = torch.zeros(1, dtype=torch.int64, device=dev)
-        _lib.check(lib.dfh_mc_reorder(verts.data_ptr(), normals.data_ptr(), values.data_ptr(), faces.data_ptr(), nv, nf,
-                                      v2.data_ptr(), n2.data_ptr(), val2.data_ptr(), used.data_ptr(), ws2.data_ptr(),
-                                      ws2.numel() * 8, current_stream_ptr()), "dfh_mc_reorder")
-        nu = int(used.item())
-        verts, normals, values = v2[:nu], n2[:nu], val2[:nu]
-    if as_numpy:
-        return verts.cpu().numpy(), faces.cpu().numpy(), normals.cpu().numpy(), values.cpu().numpy()
-    return verts, faces, normals, values
+    return marching_cubes_begin(volume, level, step_size).finish(as_numpy=as_numpy, order=order, visit_all_tiles=visit_all_tiles)
+
+
+class marching_cubes_begin:
+    """marching_cubes in two halves: the constructor launches the count pass (on the current stream) and returns; finish() waits
+    for the totals, launches the emit passes and returns the mesh.  A caller with other work to queue in between (a frame loop
+    that has just updated the canonical volume) starts the count early and collects the mesh later."""
+
+    def __init__(self, volume, level=None, step_size=1):
+        require_gpu()
+        self.lib = lib = _lib.load()
+        if not (isinstance(volume, torch.Tensor) and volume.is_cuda and volume.dim() == 3 and volume.is_contiguous()):
+            raise ValueError("volume must be a contiguous 3-D CUDA tensor")
+        step = int(step_size)
+        if step < 1:
+            raise ValueError("step_size must be at least 1")                         # skimage raises ValueError too
+        if min(volume.shape) < 2:
+            raise ValueError("Input array must be at least 2x2x2.")
+        if level is None:
+            level = 0.5 * (float(volume.min()) + float(volume.max()))
+        self.volume, self.step, self.level = volume, step, float(level)
+        self.res = _lib.iarr(volume.shape)
+        nbytes = lib.dfh_mc_workspace_bytes(self.res, step)
+        self.ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=volume.device)
+        self.totals = HostScalar(torch.int64, 3)      # (vertices, faces, active tiles: stored into pinned host memory by the scan)
+        _lib.check(lib.dfh_mc_count(volume.data_ptr(), dtype_code(volume), self.res, step, self.level, self.ws.data_ptr(),
+                                    self.ws.numel() * 8, self.totals.ptr(), current_stream_ptr()), "dfh_mc_count")
+
+    def finish(self, as_numpy=False, order="reference", visit_all_tiles=False):
+        if order not in ("reference", "lattice"):
+            raise ValueError("order must be 'reference' or 'lattice'")
+        lib, volume, ws = self.lib, self.volume, self.ws
+        nv, nf, nactive = self.totals.get()
+        if nv >= (1 << 29) or nf >= (1 << 31) // 3:
+            raise ValueError("surface too large for 32-bit mesh indices (%d vertices, %d faces)" % (nv, nf))
+        dev = volume.device
+        verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        normals = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        values = torch.empty((nv,), dtype=torch.float32, device=dev)
+        faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
+        _lib.check(lib.dfh_mc_emit(volume.data_ptr(), dtype_code(volume), self.res, self.step, self.level, ws.data_ptr(), ws.numel() * 8,
+                                   verts.data_ptr(), normals.data_ptr(), values.data_ptr(), faces.data_ptr(), nv, nf,
+                                   -1 if visit_all_tiles else nactive, current_stream_ptr()), "dfh_mc_emit")
+        if order == "reference":
+            nbytes = lib.dfh_mc_reorder_workspace_bytes(nv, nf)
+            ws2 = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+            v2, n2, val2 = torch.empty_like(verts), torch.empty_like(normals), torch.empty_like(values)
+            used = HostScalar(torch.int64)
+            _lib.check(lib.dfh_mc_reorder(verts.data_ptr(), normals.data_ptr(), values.data_ptr(), faces.data_ptr(), nv, nf,
+                                          v2.data_ptr(), n2.data_ptr(), val2.data_ptr(), used.ptr(), ws2.data_ptr(),
+                                          ws2.numel() * 8, current_stream_ptr()), "dfh_mc_reorder")
+            nu = used.get()
+            verts, normals, values = v2[:nu], n2[:nu], val2[:nu]
+        if as_numpy:
+            return verts.cpu().numpy(), faces.cpu().numpy(), normals.cpu().numpy(), values.cpu().numpy()
+        return verts, faces, normals, values
 
 
 def write_obj(fpath, verts, faces, normals, ind=None):

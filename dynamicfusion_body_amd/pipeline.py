@@ -222,12 +222,15 @@ class SlabFrame:
         return n_new
 
     def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5, stage_ms=None,
-             update_graph=False):
+             update_graph=False, on_updated=None):
         """Defaults (regulariser weight, LM damping, association gate and Huber threshold in voxels) are the ones under which the loop tracks
         a +-0.5 voxel oscillation of the bench scene for hundreds of frames without drift (tools/soak.py); with a 4-voxel
         gate and weak damping, nodes without data support wander and the TSDF update then corrupts the canonical volume.
         stage_ms: optional dict; when given, the device is synchronised after every stage and the stage's wall
-        time (ms) is added under its name (for breakdowns only: the syncs cost throughput)."""
+        time (ms) is added under its name (for breakdowns only: the syncs cost throughput).
+        on_updated: optional callable, called once the launches of this frame's TSDF update are queued and `self.updated` is
+        recorded -- the place where a consumer of the updated canonical slab (mesh extraction on another stream) queues its
+        first launches, ahead of the sample refresh's."""
         import time as _t
         t0 = [_t.perf_counter()]
 
@@ -278,7 +281,9 @@ class SlabFrame:
         if self.updated is None:
             self.updated = torch.cuda.Event()
         self.updated.record()                  # the canonical slab of this frame is final from here on (a consumer on another
-        mark("tsdf_update")                    # stream, e.g. mesh extraction, need not wait for the sample refresh below)
+        if on_updated is not None:             # stream, e.g. mesh extraction, need not wait for the sample refresh below)
+            on_updated()
+        mark("tsdf_update")
         n = self.refresh_samples()
         mark("samples")
         self.fs.solver.check_status(completed_only=True)   # the sample count's read-back has synchronised: a timed-out PCG raises here

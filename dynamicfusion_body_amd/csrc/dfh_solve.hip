@@ -1571,12 +1571,35 @@ struct PcgParams {
     double lm_abs, lm_rel;
 };
 
+// The multi-launch path's dot products without atomics: every workgroup of the producing launch stores ONE partial (its waves'
+// values added in a fixed order), every workgroup of the consuming launch adds all partials in the same fixed order -- the same
+// bits in every workgroup, every run and on every rank (with atomicAdd the order, hence the last bits, changed from run to run).
+__device__ __forceinline__ void wg_store_partial(double wave_value, double *slot) {     // all 256 threads; wave_value on lane 0
+    __shared__ double s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = wave_value;
+    __syncthreads();
+    if (threadIdx.x == 0) slot[blockIdx.x] = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+}
+__device__ __forceinline__ double wg_sum_partials(const double *__restrict__ part, int n) {   // all 256 threads
+    __shared__ double s_sum[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const double v = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+    __syncthreads();
+    return v;
+}
+
 __global__ __launch_bounds__(256) void pcg_init_kernel(const int *__restrict__ row_ptr, const int *__restrict__ col,
                                                         double *__restrict__ vals, const double *__restrict__ rhs,
                                                         const PcgParams p, double *__restrict__ Minv, double *__restrict__ x,
-                                                        double *__restrict__ r, double *__restrict__ pv, double *__restrict__ scal) {
+                                                        double *__restrict__ r, double *__restrict__ pv, double *__restrict__ rz_part) {
     const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= p.N) return;
+    double rz = 0.0;
+    if (a < p.N) {
     const int blk = find_block(row_ptr, col, a, a);
     double D[36];
     for (int i = 0; i < 36; ++i) D[i] = blk >= 0 ? vals[36 * (size_t)blk + i] : 0.0;
@@ -1585,7 +1608,6 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(const int *__restrict__ r
     double Di[36];
     inv6(D, Di);
     for (int i = 0; i < 36; ++i) Minv[36 * (size_t)a + i] = Di[i];
-    double rz = 0.0;
     double rl[6], zl[6];
     for (int i = 0; i < 6; ++i) { rl[i] = -rhs[6 * a + i]; x[6 * a + i] = 0.0; r[6 * a + i] = rl[i]; }
     for (int i = 0; i < 6; ++i) {
@@ -1595,7 +1617,10 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(const int *__restrict__ r
         pv[6 * a + i] = z;                 // z0; the first SpMV takes p = z (beta = 0)
         rz += rl[i] * z;
     }
-    atomicAdd(scal + 0, rz);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rz += __shfl_xor(rz, o, 64);
+    wg_store_partial(rz, rz_part);
 }
 
 // One 64-lane wave per node row: lane = (block slot b in 0..9) x (output component i in 0..5);
@@ -1608,20 +1633,19 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(const int *__restrict__ r
                                                         const double *__restrict__ vals, int N, const double *__restrict__ z,
                                                         const double *__restrict__ p_prev, double *__restrict__ p_cur,
                                                         double *__restrict__ Ap, const double *__restrict__ scal_prev,
-                                                        double *__restrict__ scal) {
+                                                        double *__restrict__ scal, const double *__restrict__ rz_part, int n_rz_part,
+                                                        double *__restrict__ pap_part) {
     const int lane = threadIdx.x & 63;
     const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
-    double beta = 0.0, rz_now = 0.0;
-    if (scal_prev) {
-        const double rz = scal_prev[0];
-        rz_now = scal_prev[2];
-        beta = rz != 0.0 ? rz_now / rz : 0.0;
-        if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = rz_now;      // rz of this iteration for update_xr
-    }
-    if (a >= N) return;
+    // r.z of this iteration = the partials of the launch that produced z (init or the previous update), added here
+    const double rz_now = wg_sum_partials(rz_part, n_rz_part);
+    const double rz = scal_prev[0];                                     // the previous iteration's r.z (0 in iteration 0: beta = 0)
+    const double beta = rz != 0.0 ? rz_now / rz : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = rz_now;         // rz of this iteration for update_xr and the next SpMV
+    const bool row = a < N;
     const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63: slot 10 (idle)
     double acc = 0.0;
-    const int beg = row_ptr[a], end = row_ptr[a + 1];
+    const int beg = row ? row_ptr[a] : 0, end = row ? row_ptr[a + 1] : 0;
     if (slot < 10) {
         for (int b = beg + slot; b < end; b += 10) {
             const double *B = vals + 36 * (size_t)b + 6 * i;
@@ -1639,7 +1663,7 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(const int *__restrict__ r
         y += (lane + 6 * k < 60) ? o : 0.0;
     }
     double contrib = 0.0;
-    if (lane < 6) {
+    if (row && lane < 6) {
         const double pn = z[6 * a + lane] + beta * p_prev[6 * a + lane];
         p_cur[6 * a + lane] = pn;
         Ap[6 * a + lane] = y;
@@ -1648,7 +1672,7 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(const int *__restrict__ r
     contrib += __shfl_down(contrib, 4, 64);
     contrib += __shfl_down(contrib, 2, 64);
     contrib += __shfl_down(contrib, 1, 64);
-    if (lane == 0) atomicAdd(scal + 1, contrib);
+    wg_store_partial(contrib, pap_part);                                 // p.Ap of this workgroup's four rows
 }
 
 // x += alpha p, r -= alpha Ap, z = Minv r, rz_next += r.z : one thread per unknown (6 per node; the
@@ -1656,13 +1680,14 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(const int *__restrict__ r
 __global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double *__restrict__ Minv, double *__restrict__ x,
                                                              double *__restrict__ r, const double *__restrict__ pv,
                                                              const double *__restrict__ Ap, double *__restrict__ z,
-                                                             double *__restrict__ scal) {
+                                                             const double *__restrict__ scal, const double *__restrict__ pap_part,
+                                                             int n_pap_part, double *__restrict__ rz_part) {
     // 60 of the 64 lanes of a wave are used: 10 nodes per wave, 40 per block
     const int lane = threadIdx.x & 63;
     const int grp = lane / 6, i = lane - 6 * grp;
     const int a = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 10 + grp;
     const bool act = grp < 10 && a < N;
-    const double rz = scal[0], pAp = scal[1];
+    const double rz = scal[0], pAp = wg_sum_partials(pap_part, n_pap_part);
     const double alpha = pAp != 0.0 ? rz / pAp : 0.0;
     double rn = 0.0;
     if (act) {
@@ -1681,7 +1706,7 @@ __global__ __launch_bounds__(256) void pcg_update_xr_kernel(int N, const double 
     if (act) { z[6 * a + i] = zz; contrib = rn * zz; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) contrib += __shfl_down(contrib, o, 64);
-    if (lane == 0 && contrib != 0.0) atomicAdd(scal + 2, contrib);
+    wg_store_partial(contrib, rz_part);                                  // r.z of this workgroup's 40 rows (the next iteration's)
 }
 
 // ---- persistent PCG: the whole iteration loop in one launch --------------------------------------
@@ -2723,15 +2748,21 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
         return DFH_OK;
     }
     if (!precleared) DFH_HIP_CHECK(hipMemsetAsync(pA, 0, sizeof(double) * (N6 + n_scal), s));
-    // scal[0..2] belongs to the init (rz0 in scal[2] so that iteration 0 reads it as "rz_next")
-    hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, z, scal + 2);
+    // dot products: per-workgroup partials in the slots the persistent kernel uses for its reductions (2 (iters + 1) slots of
+    // ceil(N / 4) doubles): slot 2 it = p.Ap of iteration it, 2 it + 1 = r.z after it, slot 2 iters = r.z of the init
+    const size_t nq = ((size_t)n_nodes + 3) / 4;
+    double *part = scal + 3 * ((size_t)iters + 2);
+    const int n_init = (int)grid.x, n_spmv = (n_nodes + 3) / 4, n_upd = (n_nodes + 39) / 40;
+    hipLaunchKernelGGL(pcg_init_kernel, grid, block, 0, s, row_ptr, col, vals, rhs, p, Minv, x_out, r, z, part + 2 * (size_t)iters * nq);
     double *p_prev = pA, *p_cur = pB;
     for (int it = 0; it < iters; ++it) {
         double *sc = scal + 3 * ((size_t)it + 1);
-        // iteration 0: beta = 0 but rz must still be forwarded -> scal_prev with rz = 0 gives beta = 0
-        hipLaunchKernelGGL(pcg_spmv_kernel, dim3((n_nodes + 3) / 4), block, 0, s, row_ptr, col, vals, n_nodes, z, p_prev, p_cur,
-                           Ap, sc - 3, sc);
-        hipLaunchKernelGGL(pcg_update_xr_kernel, dim3((n_nodes + 39) / 40), block, 0, s, n_nodes, Minv, x_out, r, p_cur, Ap, z, sc);
+        // iteration 0: the scalars in front of sc are zero (cleared above): rz_prev = 0 gives beta = 0
+        const double *rz_part = it == 0 ? part + 2 * (size_t)iters * nq : part + (2 * (size_t)it - 1) * nq;
+        hipLaunchKernelGGL(pcg_spmv_kernel, dim3(n_spmv), block, 0, s, row_ptr, col, vals, n_nodes, z, p_prev, p_cur,
+                           Ap, sc - 3, sc, rz_part, it == 0 ? n_init : n_upd, part + 2 * (size_t)it * nq);
+        hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(n_upd), block, 0, s, n_nodes, Minv, x_out, r, p_cur, Ap, z, sc,
+                           part + 2 * (size_t)it * nq, n_spmv, part + (2 * (size_t)it + 1) * nq);
         double *t = p_prev; p_prev = p_cur; p_cur = t;
     }
     if (update_dq)

@@ -171,8 +171,9 @@ def test_pcg_and_twist_vs_oracle(golden):
 
 def test_pcg_paths_agree_and_are_deterministic(golden, monkeypatch):
     """The persistent single-launch PCG and the two-launches-per-iteration PCG are the same algorithm
-    (same operation order per row; only the order of the dot-product sums differs), and the persistent
-    one has no floating-point atomics: two runs are bit-identical."""
+    (same operation order per row; only the order of the dot-product sums differs), and neither has
+    floating-point atomics (the two-launch path adds per-workgroup partials in a fixed order): two runs of
+    either are bit-identical."""
     g, verts, norms, corr, nbr, vidx, npos, ndq, nw, lw, rw = load(golden)
     runs = []
     for mode in ("persistent", "persistent", "multilaunch"):
@@ -198,6 +199,16 @@ def test_pcg_paths_agree_and_are_deterministic(golden, monkeypatch):
     sv.vals.copy_(v0)
     sv.solve_linear(0.5, 1e-3)
     assert torch.equal(x1, sv.dx)
+    # ... and through the two-launch path, five times (its dot products were atomic sums once: last bits differed run to run)
+    monkeypatch.setenv("DFH_PCG_MULTILAUNCH", "1")
+    xs = []
+    for _ in range(5):
+        sv.vals.copy_(v0)
+        sv.solve_linear(0.5, 1e-3)
+        xs.append(sv.dx.clone())
+    monkeypatch.delenv("DFH_PCG_MULTILAUNCH", raising=False)
+    assert all(torch.equal(xs[0], x) for x in xs[1:])
+    assert float((xs[0] - x1).abs().max()) <= 1e-9 * float(x1.abs().max())
 
 
 @pytest.mark.parametrize("multilaunch", [False, True])

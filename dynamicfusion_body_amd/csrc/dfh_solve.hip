@@ -129,11 +129,13 @@ __global__ __launch_bounds__(256) void residual_reg_kernel(const int *__restrict
 
 // Rigid 6-DoF normal equations for the global `_lw`: r_i as above, J_i = [ c_i x m_i | s m_i ]
 // (m = warped normal, s = |r_x|^2; derivation in oracle/gn_np.py).  out: 36 (J^T J) + 6 (J^T r)
-// + 1 (0.5|r|^2) + 1 (count) doubles, accumulated with one atomic per block and entry.
+// + 1 (0.5|r|^2) + 1 (count) doubles.  partial != NULL: every workgroup stores its 29 sums (row blockIdx.x of `partial`) and
+// gn_rigid_finish_kernel adds the rows in a fixed order -- same bits every run; partial == NULL (no scratch to be had): one
+// atomic per workgroup and entry into `out`.
 __global__ __launch_bounds__(256) void gn_build_rigid_kernel(const double *__restrict__ verts, const double *__restrict__ norms,
                                                               const double *__restrict__ corr,
                                                               const unsigned char *__restrict__ valid, int n, DQ x,
-                                                              double *__restrict__ out) {
+                                                              double *__restrict__ out, double *__restrict__ partial) {
     __shared__ double red[256];
     double acc[29];
     for (int e = 0; e < 29; ++e) acc[e] = 0.0;
@@ -159,7 +161,9 @@ __global__ __launch_bounds__(256) void gn_build_rigid_kernel(const double *__res
             if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
             __syncthreads();
         }
-        if (threadIdx.x == 0 && red[0] != 0.0) {
+        if (threadIdx.x == 0 && partial) {
+            partial[29 * (size_t)blockIdx.x + e] = red[0];
+        } else if (threadIdx.x == 0 && red[0] != 0.0) {
             if (e < 21) {
                 int a = 0, rem = e;
                 while (rem >= 6 - a) { rem -= 6 - a; ++a; }
@@ -168,6 +172,33 @@ __global__ __launch_bounds__(256) void gn_build_rigid_kernel(const double *__res
                 if (a != b) atomicAdd(out + 6 * b + a, red[0]);
             } else {
                 atomicAdd(out + 36 + (e - 21), red[0]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out (44 doubles, see above) = the workgroups' 29 sums added in workgroup order (thread t: rows t, t + 256, ...; then a fixed tree)
+__global__ __launch_bounds__(256) void gn_rigid_finish_kernel(const double *__restrict__ partial, int rows, double *__restrict__ out) {
+    __shared__ double red[256];
+    for (int e = 0; e < 29; ++e) {
+        double acc = 0.0;
+        for (int b = threadIdx.x; b < rows; b += 256) acc += partial[29 * (size_t)b + e];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (e < 21) {
+                int a = 0, rem = e;
+                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+                const int b = a + rem;
+                out[6 * a + b] = red[0];
+                out[6 * b + a] = red[0];
+            } else {
+                out[36 + (e - 21)] = red[0];
             }
         }
         __syncthreads();
@@ -2234,7 +2265,18 @@ int dfh_gn_build_rigid(const double *verts, const double *normals, const double 
     for (int i = 0; i < 8; ++i) q.q[i] = x[i];
     int blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(gn_build_rigid_kernel, dim3(blocks), dim3(256), 0, s, verts, normals, corr, valid, n, q, out44);
+    // per-workgroup sums in stream-ordered scratch, added in a fixed order by a second launch: the same bits every run.
+    // (No scratch -- allocation refused, e.g. inside a stream capture without pool support: atomics, last bits may vary.)
+    double *partial = nullptr;
+    if (getenv("DFH_RIGID_ATOMIC") || hipMallocAsync(reinterpret_cast<void **>(&partial), sizeof(double) * 29 * (size_t)blocks, s) != hipSuccess) {
+        (void)hipGetLastError();
+        partial = nullptr;
+    }
+    hipLaunchKernelGGL(gn_build_rigid_kernel, dim3(blocks), dim3(256), 0, s, verts, normals, corr, valid, n, q, out44, partial);
+    if (partial) {
+        hipLaunchKernelGGL(gn_rigid_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, out44);
+        DFH_HIP_CHECK(hipFreeAsync(partial, s));
+    }
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }

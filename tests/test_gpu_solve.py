@@ -560,6 +560,17 @@ def test_rigid_gn_vs_oracle(golden):
     keep = val.numpy()
     _, co, _ = G.gn_step_rigid(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), verts[keep], norms[keep], corr[keep])
     assert abs(c2[0] - co) <= 1e-12 * co
+    # many workgroups: their sums are added in a fixed order (no atomics), so a solve repeats bit for bit
+    rng = np.random.default_rng(31)
+    V = rng.uniform(-1, 1, size=(300000, 3)); Nn = rng.normal(size=V.shape); Nn /= np.linalg.norm(Nn, axis=1, keepdims=True)
+    C = O.dqb_warp(x_true, V) + 1e-3 * rng.normal(size=V.shape)
+    runs = [solve.solve_rigid_gn(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), V, Nn, C, iters=4) for _ in range(3)]
+    for xr, cr in runs[1:]:
+        assert np.array_equal(xr, runs[0][0]) and list(cr) == list(runs[0][1])
+    xo = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+    for it in range(4):
+        xo, c, dx = G.gn_step_rigid(xo, V, Nn, C)
+    assert np.abs(runs[0][0] - xo).max() <= 1e-9
 
 
 def test_projective_association_vs_oracle():

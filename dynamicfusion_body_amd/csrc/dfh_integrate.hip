@@ -11,8 +11,10 @@
 //                    -ffp-contract=off): bit-identical to the fp64 CPU path.
 //   the FAST path -- for fp32 volumes: index -> (p0,p1,p2,l2) through one host-folded affine
 //                    map (one FMA per component and voxel), one v_rcp_f64 + one Newton step
-//                    (measured 2^-48.7 relative, profiles/ubench_r1.txt) instead of two IEEE
-//                    divisions, the pixel / frustum decisions in 2^-20-pixel fixed point on
+//                    (measured 2^-48.7 relative, profiles/ubench_r1.txt) per PACK of four voxels
+//                    -- the reciprocal of the product of their four depths, times the products
+//                    of the others: three more roundings -- instead of two IEEE divisions per
+//                    voxel, the pixel / frustum decisions in 2^-20-pixel fixed point on
 //                    the int32 ALU, and the sd > -tdist decision on float32 differences.
 //                    Error budget: < 2^-19 px for u,v; < 2.4e-7*max(|l2|,|z|) m for the
 //                    margin.  Whenever a voxel is closer than a guard band (8*2^-20 px;
@@ -187,6 +189,22 @@ __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const DepthT
     float l2f[VEC];
     unsigned pix[VEC];
     bool inside[VEC], amb[VEC];
+    double rinv[VEC];
+    if (VEC == 4) {
+        // the four reciprocals from ONE v_rcp_f64 (a quarter-rate instruction) of the product of the four depths: 1 / p2_j =
+        // (product of the others) / (product of all).  ~2^-48 relative like rcp_nr1 (three more roundings of 2^-53); the pack's
+        // depths are of one sign and away from zero, or the whole pack is re-evaluated exactly (pack_singular)
+        double d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = __builtin_fma(p.Az[2], (double)(j * ZS), base[2]);
+        const double d01 = d[0] * d[1], d23 = d[2] * d[3];
+        const double rall = rcp_nr1(d01 * d23);
+        const double r01 = rall * d23, r23 = rall * d01;               // 1 / (d0 d1), 1 / (d2 d3)
+        rinv[0] = r01 * d[1]; rinv[1] = r01 * d[0]; rinv[2 % VEC] = r23 * d[3 % VEC]; rinv[3 % VEC] = r23 * d[2 % VEC];
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) rinv[j] = rcp_nr1(__builtin_fma(p.Az[2], (double)(j * ZS), base[2]));
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const double jf = (double)(j * ZS);
@@ -195,7 +213,7 @@ __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const DepthT
         const double p2 = __builtin_fma(p.Az[2], jf, base[2]);
         l2v[j] = PINHOLE ? p2 : __builtin_fma(p.Az[NC - 1], jf, base[NC - 1]);
         l2f[j] = (float)l2v[j];
-        const double r = rcp_nr1(p2);
+        const double r = rinv[j];
         const int qu = cvt_i32_sat(p0 * r);              // trunc, saturating; NaN -> 0 (inside the band)
         const int qv = cvt_i32_sat(p1 * r);
         // distance to the nearest multiple of 0.5 px: pixel ties AND the integer frustum edges

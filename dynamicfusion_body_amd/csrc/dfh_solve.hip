@@ -2729,15 +2729,19 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
         DFH_HIP_CHECK(hipGetDevice(&dev));
         DFH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    int wpb = n_nodes <= 8 * 64 ? 8 : 16;             // fat workgroups: <= 64 partial sums per reduction where possible
-    if (const char *e = getenv("DFH_PCG_WPB")) { const int v = atoi(e); if (v == 4 || v == 8) wpb = v; }
+    // Workgroups of 8 waves (one row each) as long as they fit one per CU, of 16 beyond.  Measured at 2 048 rows (tools/kbench_pcg.py):
+    // 256 workgroups x 8 waves 55 us per 10-iteration solve (slope 4.3 us, prologue 14.5), 128 x 16 waves 90 us (6.4 / 27.3).
+    int wpb = (n_nodes + 7) / 8 <= n_cu ? 8 : 16;
+    if (const char *e = getenv("DFH_PCG_WPB")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) wpb = v; }
     const int nblk = (n_nodes + wpb - 1) / wpb;
     // Persistent path only when its grid barrier cannot starve: (1) the occupancy query says a workgroup of this size
-    // fits on a CU, (2) the grid takes at most half the CUs (a second stream's or process's solve fits beside it),
+    // fits on a CU, (2) the grid has at most one workgroup per CU (other kernels of this process may hold CUs for a while: they
+    // end, the waiting workgroups then start; what must NOT run beside it is a second persistent solve that also wants most of
+    // the chip -- two of them could wait for each other until the spin bound makes both leave and report DFH_E_TIMEOUT),
     // (3) the caller has not declared co-residency unsafe (dfh_pcg_set_mode(2): several processes time-sharing one GPU),
     // (4) the abort counter exists (it cannot be allocated while the stream is being captured).  Otherwise: two launches
     // per iteration, no spinning.
-    bool persistent = 2 * nblk <= n_cu && nblk <= kMaxPcgBlocks && dfh::g_pcg_mode != 2 && !getenv("DFH_PCG_MULTILAUNCH");
+    bool persistent = nblk <= n_cu && nblk <= kMaxPcgBlocks && dfh::g_pcg_mode != 2 && !getenv("DFH_PCG_MULTILAUNCH");
     unsigned long long *abort_count = nullptr;
     if (persistent) {
         static int occ512 = -1, occ1024 = -1;

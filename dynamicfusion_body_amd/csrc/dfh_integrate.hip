@@ -118,13 +118,27 @@ __device__ __forceinline__ bool exact_voxel(const IntegrateParams &p, const Dept
 }
 
 // Rare-path wrapper: the coordinates are laundered through empty asm so the compiler cannot
-// hoist the exact chain's loop-invariant arithmetic out of the (almost never taken) branch.
+// hoist the exact chain's loop-invariant arithmetic out of the (almost never taken) branch -- and the parameters come
+// through a laundered POINTER, so that their loads stay inside the branch too: read through the by-value kernel argument, the
+// exact chain's ~30 doubles (K, Kinv, lw, ...) were fetched into scalar registers at the top of the kernel, beside the fast
+// path's own 24-32, and the overflow was parked in vector lanes (25 v_writelane + the read-backs per wave, ~10 % of what a
+// wave issues).
 template <typename DepthT, bool PINHOLE>
-__device__ __forceinline__ bool exact_voxel_rare(const IntegrateParams &p, const DepthT *__restrict__ depth,
+__device__ __forceinline__ bool exact_voxel_rare(const IntegrateParams *pp, const DepthT *__restrict__ depth,
                                                  int x, int y, int z, double &sd_out) {
     asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-    return exact_voxel<DepthT, PINHOLE>(p, depth, x, y, z, sd_out);
+    asm volatile("" : "+s"(pp));
+    return exact_voxel<DepthT, PINHOLE>(*pp, depth, x, y, z, sd_out);
 }
+
+// The IntegrateParams a kernel received BY VALUE, as a pointer into its kernel-argument segment (byte_offset = what precedes it:
+// three pointers in every single-view kernel): for exact_voxel_rare.
+__device__ __forceinline__ const IntegrateParams *kernarg_params(int byte_offset) {
+    typedef const char __attribute__((address_space(4))) *KernArgBytes;
+    KernArgBytes ka = (KernArgBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    return (const IntegrateParams *)(ka + byte_offset);
+}
+constexpr int kParamsAfterThreePointers = 24;
 
 __device__ __forceinline__ double rcp_nr1(double d) {      // relative error <= 2^-48.7 (measured)
     const double r = __builtin_amdgcn_rcp(d);
@@ -166,8 +180,8 @@ struct NoHook {
 // the place to issue further independent loads (the brick sweep starts its T / w loads there, one memory round trip
 // instead of two); any_inside = some voxel of the pack projects into the image.
 template <typename DepthT, int VEC, bool PINHOLE, bool STRIDED, typename Hook = NoHook>
-__device__ __forceinline__ bool view_pack(const IntegrateParams &p, const DepthT *__restrict__ depth, int x, int y, int z0,
-                                          float (&ms)[VEC], bool (&upd)[VEC], Hook &&after_gathers = NoHook()) {
+__device__ __forceinline__ bool view_pack(const IntegrateParams &p, const IntegrateParams *p_rare, const DepthT *__restrict__ depth, int x,
+                                          int y, int z0, float (&ms)[VEC], bool (&upd)[VEC], Hook &&after_gathers = NoHook()) {
     constexpr int ZS = STRIDED ? 64 : 1;                 // z step between a lane's voxels
     constexpr int NC = PINHOLE ? 3 : 4;
     const unsigned ulim = (unsigned)(p.W - 1) << kFixShift;
@@ -256,7 +270,7 @@ __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const DepthT
         float m = p.ts_f;
         if (__builtin_expect(redo, 0)) {
             double sd;
-            ok = exact_voxel_rare<DepthT, PINHOLE>(p, depth, x, y, z0 + j * ZS, sd);
+            ok = exact_voxel_rare<DepthT, PINHOLE>(p_rare, depth, x, y, z0 + j * ZS, sd);
             m = (float)((sd < p.tdist ? sd : p.tdist) * p.inv_scale);
         } else if (ok & !freespace) {
             double cz = -(double)dval[j];
@@ -272,7 +286,7 @@ __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const DepthT
             if (!PINHOLE) {
                 const double margin = sd + p.tdist;
                 ok = margin > 0.0;
-                if (fabs(margin) < 1e-7) ok = exact_voxel_rare<DepthT, PINHOLE>(p, depth, x, y, z0 + j * ZS, cz);
+                if (fabs(margin) < 1e-7) ok = exact_voxel_rare<DepthT, PINHOLE>(p_rare, depth, x, y, z0 + j * ZS, cz);
             }
             m = (float)((sd < p.tdist ? sd : p.tdist) * p.inv_scale);
         }
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(256) void integrate_depth_kernel(float *__restrict_
     for (int xl = blockIdx.y * p.planes_per_block; xl < xl_end; ++xl) {
         float ms[VEC];              // min(tdist, sd) / scale
         bool upd[VEC];
-        if (!view_pack<DepthT, VEC, PINHOLE, STRIDED>(p, depth, p.x0 + xl, y, z0, ms, upd)) continue;
+        if (!view_pack<DepthT, VEC, PINHOLE, STRIDED>(p, kernarg_params(kParamsAfterThreePointers), depth, p.x0 + xl, y, z0, ms, upd)) continue;
         const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
         using P = Pack<float, VEC>;
         P t, w;
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(256) void integrate_depth_rows_early_kernel(float *
     using P = Pack<float, 4>;
     P t, w;
     bool loaded = false;
-    const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, depth, p.x0 + xl, y, z0, ms, upd, [&](bool any_inside) {
+    const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, kernarg_params(kParamsAfterThreePointers), depth, p.x0 + xl, y, z0, ms, upd, [&](bool any_inside) {
         if (any_inside) {
             t = *reinterpret_cast<const P *>(tsdf + off);
             w = *reinterpret_cast<const P *>(tsdf_w + off);
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(256) void integrate_depth_multi_kernel(float *__res
             const IntegrateParams &p = views[v];         // uniform address: scalar loads
             float ms[VEC];
             bool upd[VEC];
-            if (!view_pack<DepthT, VEC, PINHOLE, false>(p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd)) continue;
+            if (!view_pack<DepthT, VEC, PINHOLE, false>(p, &p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd)) continue;
             if (!loaded) {
                 t = *reinterpret_cast<const P *>(tsdf + off);
                 w = *reinterpret_cast<const P *>(tsdf_w + off);
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(256) void integrate_depth_brick_kernel(float *__res
     // T / w of a pack that projects into the image are requested together with its depth gathers: in the bricks that
     // survive the classification nearly every such pack is updated, so little is fetched in vain and the sweep pays one
     // memory round trip instead of two
-    const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, depth, p.x0 + xl, y, z0, ms, upd, [&](bool any_inside) {
+    const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, kernarg_params(kParamsAfterThreePointers), depth, p.x0 + xl, y, z0, ms, upd, [&](bool any_inside) {
         if (EARLY && any_inside && in_grid) {
             t = *reinterpret_cast<const P *>(tsdf + off);
             w = *reinterpret_cast<const P *>(tsdf_w + off);
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(256) void integrate_depth_multi_brick_kernel(float 
         const IntegrateParams &p = views[v];             // uniform address: scalar loads
         float ms[4];
         bool upd[4];
-        const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd);
+        const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, &p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd);
         if (!(any && in_grid)) continue;
         if (!loaded) {
             t = *reinterpret_cast<const P *>(tsdf + off);

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void gn_build_rigid_kernel(const double *__res
         acc[27] += 0.5 * r * r;
         acc[28] += 1.0;
     }
-    for (int e = 0; e < 29; ++e) {
+#pragma unroll
+    for (int e = 0; e < 29; ++e) {                 // (unrolled: acc[e] with a run-time e would move the 29 sums to scratch memory)
         red[threadIdx.x] = acc[e];
         __syncthreads();
         for (int st = 128; st > 0; st >>= 1) {

@@ -123,11 +123,14 @@ __device__ __forceinline__ bool exact_voxel(const IntegrateParams &p, const Dept
 // exact chain's ~30 doubles (K, Kinv, lw, ...) were fetched into scalar registers at the top of the kernel, beside the fast
 // path's own 24-32, and the overflow was parked in vector lanes (25 v_writelane + the read-backs per wave, ~10 % of what a
 // wave issues).
-template <typename DepthT, bool PINHOLE>
+// (LAZY = false, the multi-view kernels: their parameters are read from the workspace through scalar loads either way and fit
+// the scalar registers; with a second, laundered pointer to the same structures the compiler turned the FAST path's scalar
+// loads into vector loads -- 512^3 x 8 views 743 -> 1 169 us.)
+template <typename DepthT, bool PINHOLE, bool LAZY>
 __device__ __forceinline__ bool exact_voxel_rare(const IntegrateParams *pp, const DepthT *__restrict__ depth,
                                                  int x, int y, int z, double &sd_out) {
     asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-    asm volatile("" : "+s"(pp));
+    if (LAZY) asm volatile("" : "+s"(pp));
     return exact_voxel<DepthT, PINHOLE>(*pp, depth, x, y, z, sd_out);
 }
 
@@ -179,7 +182,7 @@ struct NoHook {
 // after_gathers(any_inside): called right after the depth gathers have been issued and before their values are used --
 // the place to issue further independent loads (the brick sweep starts its T / w loads there, one memory round trip
 // instead of two); any_inside = some voxel of the pack projects into the image.
-template <typename DepthT, int VEC, bool PINHOLE, bool STRIDED, typename Hook = NoHook>
+template <typename DepthT, int VEC, bool PINHOLE, bool STRIDED, bool LAZY = true, typename Hook = NoHook>
 __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const IntegrateParams *p_rare, const DepthT *__restrict__ depth, int x,
                                           int y, int z0, float (&ms)[VEC], bool (&upd)[VEC], Hook &&after_gathers = NoHook()) {
     constexpr int ZS = STRIDED ? 64 : 1;                 // z step between a lane's voxels
@@ -270,7 +273,7 @@ __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const Integr
         float m = p.ts_f;
         if (__builtin_expect(redo, 0)) {
             double sd;
-            ok = exact_voxel_rare<DepthT, PINHOLE>(p_rare, depth, x, y, z0 + j * ZS, sd);
+            ok = exact_voxel_rare<DepthT, PINHOLE, LAZY>(p_rare, depth, x, y, z0 + j * ZS, sd);
             m = (float)((sd < p.tdist ? sd : p.tdist) * p.inv_scale);
         } else if (ok & !freespace) {
             double cz = -(double)dval[j];
@@ -286,7 +289,7 @@ __device__ __forceinline__ bool view_pack(const IntegrateParams &p, const Integr
             if (!PINHOLE) {
                 const double margin = sd + p.tdist;
                 ok = margin > 0.0;
-                if (fabs(margin) < 1e-7) ok = exact_voxel_rare<DepthT, PINHOLE>(p_rare, depth, x, y, z0 + j * ZS, cz);
+                if (fabs(margin) < 1e-7) ok = exact_voxel_rare<DepthT, PINHOLE, LAZY>(p_rare, depth, x, y, z0 + j * ZS, cz);
             }
             m = (float)((sd < p.tdist ? sd : p.tdist) * p.inv_scale);
         }
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void integrate_depth_multi_kernel(float *__res
             const IntegrateParams &p = views[v];         // uniform address: scalar loads
             float ms[VEC];
             bool upd[VEC];
-            if (!view_pack<DepthT, VEC, PINHOLE, false>(p, &p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd)) continue;
+            if (!view_pack<DepthT, VEC, PINHOLE, false, false>(p, &p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd)) continue;
             if (!loaded) {
                 t = *reinterpret_cast<const P *>(tsdf + off);
                 w = *reinterpret_cast<const P *>(tsdf_w + off);
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(256) void integrate_depth_multi_brick_kernel(float 
         const IntegrateParams &p = views[v];             // uniform address: scalar loads
         float ms[4];
         bool upd[4];
-        const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, &p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd);
+        const bool any = view_pack<DepthT, 4, PINHOLE, false, false>(p, &p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd);
         if (!(any && in_grid)) continue;
         if (!loaded) {
             t = *reinterpret_cast<const P *>(tsdf + off);

@@ -178,6 +178,46 @@ def test_composed_frame_loop_tracks_without_drift():
     assert max(counts[20:]) < 1.15 * min(counts[20:])                     # steady band
 
 
+def test_mesh_started_inside_the_frame_equals_the_mesh_after_it():
+    """SlabFrame.step(on_updated=...) calls back once the TSDF update is queued: a mesh whose count pass is queued there on a
+    second stream (mesh.marching_cubes_begin) and finished after the frame equals, element for element, the mesh extracted from
+    the canonical volume afterwards -- the sample refresh that runs beside it only reads the volume."""
+    from dynamicfusion_body_amd import mesh
+    from dynamicfusion_body_amd.pipeline import SlabFrame
+    R, N = 96, 160
+    H, W, fx, cx, cy = scene.CAMERAS["C2"]
+    K = scene.intrinsics(fx, cx, cy)
+    scale, center, tdist = scene.grid_params(R)
+    node_pos, node_w = scene.fibonacci_nodes(N, R)
+    lws = [scene.view_extrinsic(a) for a in (0.0, 40.0, -40.0)]
+    sf = SlabFrame(K, scale, center, R, tdist / scale, node_pos, node_w, knn=4, pcg_iters=10, band=2.0, distributed=False)
+    for lw in lws:
+        sf.integrate(torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda(), lw)
+    sf.refresh_samples()
+    side = torch.cuda.Stream()
+    for f in range(3):
+        off = np.array([0.4, -0.25, 0.15]) * np.sin(0.5 * (f + 1)) * scale
+        ds = [torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0, sphere_offset=off)).cuda() for lw in lws]
+        pending, calls = [], []
+
+        def start():
+            calls.append(1)
+            with torch.cuda.stream(side):
+                side.wait_event(sf.updated)
+                pending.append(mesh.marching_cubes_begin(sf.T, 0.0))
+        torch.cuda.current_stream().wait_stream(side)             # the previous frame's mesh has read the canonical volume
+        sf.step(ds, lws, gn_iters=4, on_updated=start)
+        assert len(calls) == 1
+        with torch.cuda.stream(side):
+            got = pending[0].finish()
+        side.synchronize()
+        torch.cuda.synchronize()
+        ref = mesh.marching_cubes(sf.T, 0.0)
+        assert got[0].shape[0] > 1000
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+
+
 def test_frame_loop_variants_give_the_same_bits(monkeypatch):
     """SlabFrame.step overlaps the live-volume sweep (side stream) with the plan build and reads the plan's counts back through
     pinned memory behind an event; the plan's lists are built by counting + per-list sorts.  The sequential loop

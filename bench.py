@@ -177,6 +177,11 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
             "eager_ms_per_gn_iter": dt_eager / n_it * 1e3, "graph_ms_per_gn_iter": graph_ms, "host_issue_ms_per_gn_iter": t_issue / n_it * 1e3,
             "final_cost": cost, "valid_samples_rank0": cnt,
             "hbm_bytes_per_iter_algorithmic": alg, "hbm_GBps_algorithmic": alg / (dt / n_it) / 1e9,
+            "bound": "not HBM (SURVEY 8(d)): rows kernel = fp64 issue on the CUs + the matrix pipe (v_mfma_f64_16x16x4, 64 cycles each), "
+                     "gather = latency of the longest lists, PCG = one cross-XCD hand-off per iteration; counters (256^3 / 512 nodes, "
+                     "profiles/r2_gn_experiments.txt sections 2-4, 13): rows kernel VALU issue 33 % of resident wave cycles, waiting 53 %, "
+                     "MFMA pipe busy 3.57 M cycles per launch, LDS bank conflicts 14 % of LDS cycles; gather moves 46 MB for 22 MB of live "
+                     "sub-blocks; PCG iteration 3.0 us of which ~1.8 us hand-off",
             "workload": "%d^3 canonical volume, %d-node warp field, DQB warp + projective association + %d GN "
                         "iterations per solve (fp64), samples sharded by axis-0 slab" % (R, N, iters)}
 

@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--launch", default="auto", choices=("auto", "eager", "graph"),
                     help="how the timed K1 steps are issued: eager ctypes calls, one hipGraph replay, auto = the faster")
     ap.add_argument("--no-k1-512", action="store_true", help="skip the 512^3 K1 roofline leg (1 GPU only)")
+    ap.add_argument("--job-timeout", type=int, default=1500, help="--gpus N started by this script: seconds after which all ranks are killed")
     ap.add_argument("--leg-timeout", type=int, default=300, help="N > 1: seconds the secondary legs (gn, frame) may take before "
                                                                    "rank 0 prints the line without them and every rank leaves (0 = off)")
     ap.add_argument("--no-frame", action="store_true", help="skip the end-to-end per-frame leg")
@@ -299,24 +300,40 @@ def pmc_traffic(kernel_substr, res):
     return best
 
 
-def touched_bytes(torch, kernels, depth, K, Kinv, lw, scale, center, tdist, tsdf_res, res, x_range, H, W):
-    """Bytes one launch of integrate_depth_kernel really loads and stores for this view: the kernel reads and writes
-    T and w of a 16-byte pack (4 voxels along z) iff the view updates one of its voxels, 64 B per such pack, plus the
-    depth map once.  Counted exactly, outside any timed region: the view is integrated into a fresh volume pair and
-    the packs with a non-zero weight are counted (torch plumbing; the PMC `traffic` figure cross-checks it)."""
+def moved_bytes(torch, kernels, depth, K, Kinv, lw, scale, center, tdist, tsdf_res, res, x_range, H, W):
+    """Bytes one single-view launch really loads and stores for this view, by the sweep the library takes for this slab
+    (kernels.integrate_path):
+      rows            T and w of a 16-byte pack (4 voxels along z) are read and written iff the view updates one of its voxels:
+                      64 B per such pack;
+      columns         every pack of the slab is read (32 B), updated packs are written (32 B);
+      columns_culled  every pack of a brick that survives the classification is read (32 B: the mask array the sweep left in
+                      its workspace says which), updated packs are written (32 B);
+    plus the depth map once.  Counted exactly, outside any timed region: the view is integrated into a fresh volume pair and
+    the packs with a non-zero weight are counted (torch plumbing; the PMC `traffic` figure cross-checks it).
+    Returns (bytes, updated voxels, path)."""
     nx = x_range[1] - x_range[0]
     Tt = torch.full((nx, res[1], res[2]), float(tdist), dtype=torch.float32, device="cuda")
     Wt = torch.zeros_like(Tt)
-    kernels.integrate_depth(Tt, Wt, depth, K, Kinv, lw, scale, center, tdist, 100.0, tsdf_res=tsdf_res, res=res, x_range=x_range)
+    ws = kernels.integrate_workspace(1, H, W, res, x_range)
+    path = kernels.integrate_path(Tt, depth, res=res, x_range=x_range)
+    kernels.integrate_depth(Tt, Wt, depth, K, Kinv, lw, scale, center, tdist, 100.0, tsdf_res=tsdf_res, res=res, x_range=x_range, workspace=ws)
     upd = Wt > 0
     vox = int(upd.sum().item())
+    n_packs = nx * res[1] * (res[2] // 4) if res[2] % 4 == 0 else nx * res[1] * res[2]
     if res[2] % 4 == 0:
         packs = int(upd.view(-1, 4).any(dim=1).sum().item())
     else:
         packs = vox                                   # scalar kernel: one voxel per "pack" (16 B each)
+    per_pack = 32.0 if res[2] % 4 == 0 else 8.0       # T + w of one pack, one direction
+    if path == "columns":
+        loaded = n_packs
+    elif path == "columns_culled":
+        alive = int((kernels.brick_masks(ws, res, x_range) != 0).sum().item())
+        loaded = min(n_packs, alive * 64)             # (bricks that stick out of a ragged grid have fewer packs: upper bound)
+    else:
+        loaded = packs
     del Tt, Wt, upd
-    per_pack = 64.0 if res[2] % 4 == 0 else 16.0
-    return per_pack * packs + 4.0 * H * W, vox
+    return per_pack * (loaded + packs) + 4.0 * H * W, vox, path
 
 
 def time_launches(torch, fn, n, warm=2):
@@ -336,7 +353,7 @@ def k1_512_leg(torch, kernels, scene):
     """K1 at 512^3 with 1280x720 depth (BASELINE configs 4/5): the working set (1.07 GB) is far beyond the 256 MiB
     Infinity Cache.  Two views: the bench's 0-degree view (updates about half the voxels) and a view that updates every
     voxel (camera moved back so that the frustum contains the whole grid, a wall far behind it: all free space), for which
-    touched bytes = algorithmic bytes."""
+    moved bytes = algorithmic bytes."""
     R = 512
     H, W, fx, cx, cy = scene.CAMERAS["C5"]
     K = scene.intrinsics(fx, cx, cy)
@@ -351,14 +368,15 @@ def k1_512_leg(torch, kernels, scene):
     lw_full[2, 3] += 1.5                                    # camera 1.5 m further back: the whole cube is in view
     d_full = torch.full((H, W), -8.0, dtype=torch.float32, device="cuda")
     for name, lw, d in (("view_0deg", lw0, d0), ("view_all_voxels", lw_full, d_full)):
-        tb, vox = touched_bytes(torch, kernels, d, K, Kinv, lw, scale, center, tdist, R, (R, R, R), (0, R), H, W)
+        tb, vox, path = moved_bytes(torch, kernels, d, K, Kinv, lw, scale, center, tdist, R, (R, R, R), (0, R), H, W)
         ms = time_launches(torch, lambda: kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist, 100.0), 10)
         alg = 16.0 * R ** 3 + 4.0 * H * W
-        out[name] = {"kernel_ms": ms, "updated_fraction": vox / float(R ** 3), "touched_bytes": tb,
-                     "touched_GBps": tb / (ms * 1e-3) / 1e9, "frac_touched": tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        out[name] = {"kernel_ms": ms, "sweep": path, "updated_fraction": vox / float(R ** 3), "moved_bytes": tb,
+                     "moved_GBps": tb / (ms * 1e-3) / 1e9, "frac_moved": tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes": alg, "algorithmic_GBps": alg / (ms * 1e-3) / 1e9,
                      "frac_algorithmic": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mvox_per_s": R ** 3 / ms / 1e3}
-    out["workload"] = "512^3 grid, 1280x720 depth, one rigid fuseDepths sweep per launch, 1 GPU"
+    out["workload"] = ("512^3 grid, 1280x720 depth, one rigid fuseDepths call per launch (depth pyramid + brick classification + "
+                       "column sweep: kernel_ms is the whole call), 1 GPU")
     del T, Wt
     return out
 
@@ -369,7 +387,8 @@ def main():
     if args.gpus > 1 and not launch.under_launcher():
         # `python bench.py --gpus N`: start the N ranks ourselves.  This parent never touches the GPU (no HIP call, no
         # torch.cuda query) and never re-execs; it relays rank 0's JSON line and the worst exit code.
-        sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, json_only=True))
+        # (a finite limit: a rank stuck in a driver call that ignores SIGTERM must not make this command wait for ever)
+        sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, json_only=True, timeout=args.job_timeout))
     import torch
     import torch.distributed as dist
     from dynamicfusion_body_amd import kernels, scene
@@ -491,15 +510,20 @@ def main():
 
     value = vox_per_step * args.steps / dt / 1e6
     # ---- roofline of the dominant kernel (this rank's slab).  `achieved` counts the bytes the launch really moves
-    # (touched packs, see touched_bytes; cross-checked by the PMC `traffic`), not the 16 B/voxel of SURVEY section 8(d):
+    # (see moved_bytes; cross-checked by the PMC `traffic`), not the 16 B/voxel of SURVEY section 8(d):
     # that figure credits packs no view updates, which the kernel never loads, and is kept as `algorithmic_*`.
-    tb = [touched_bytes(torch, kernels, depths[v], K, Kinv, lws[v], scale, center, tdist, tsdf_res, res, x_range, H, W)
+    tb = [moved_bytes(torch, kernels, depths[v], K, Kinv, lws[v], scale, center, tdist, tsdf_res, res, x_range, H, W)
           for v in range(len(lws))]
     touched = sum(t[0] for t in tb) / len(tb)
+    sweep_path = tb[0][2]
     upd_frac = sum(t[1] for t in tb) / len(tb) / float(max(1, nx) * R * R)
     alg_bytes = 16.0 * nx * R * R + 4.0 * H * W               # per launch (one rank's slab), SURVEY section 8(d)
     achieved = touched / (kern_ms * 1e-3) / 1e9
     alg_gbps = alg_bytes / (kern_ms * 1e-3) / 1e9
+    k1_kernel = {"rows": "integrate_depth_kernel", "columns": "integrate_depth_column_kernel",
+                 "columns_culled": "integrate_depth_column_kernel", "exact": "integrate_depth_exact_kernel"}[sweep_path]
+    if sweep_path == "rows" and nx * R * R <= (1 << 23):
+        k1_kernel = "integrate_depth_rows_early_kernel"
     out = {
         "metric": "Mvoxels/s TSDF fusion + GN-iters/s warp solve, 256³ grid, 1/2/4/8 GPU",
         "value": value,
@@ -521,31 +545,36 @@ def main():
                    "graph_ms_per_step": None if dt_graph is None else dt_graph / args.steps * 1e3},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "integrate_depth_kernel", "kernel_ms": kern_ms,
-                     "achieved_is": "bytes the launch loads and stores (64 B per 4-voxel pack with an updated voxel + the "
-                                    "depth map), mean over the cycled views, / mean launch duration",
-                     "touched_bytes_per_launch": touched, "updated_voxel_fraction": upd_frac,
+                     "kernel": k1_kernel, "sweep": sweep_path, "kernel_ms": kern_ms,
+                     "achieved_is": "bytes the launch loads and stores (see moved_bytes: by the sweep taken, here '%s') + the "
+                                    "depth map, mean over the cycled views, / mean launch duration" % sweep_path,
+                     "moved_bytes_per_launch": touched, "updated_voxel_fraction": upd_frac,
                      "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_gbps,
                      "frac_algorithmic": alg_gbps / HBM_PEAK_GBS,
-                     "limiter": "VALU (fp64 projection) and L1 tag look-ups of the depth gathers, not HBM: "
-                                "profiles/r1d_k1_experiments.txt, DESIGN.md section 3"},
+                     "limiter": "the life of a wave (launch, projection, dependent depth gathers, store drain), not bytes or VALU: a 256^3 "
+                                "pair of volumes (134 MB) sits in the 256 MiB Infinity Cache; k1_512 below is the out-of-cache figure "
+                                "(profiles/r3_k1_experiments.txt, DESIGN.md section 3)"},
     }
 
-    # measured device-copy ceiling (float4 copy of 1 GiB, far beyond the 256 MiB Infinity Cache)
-    src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
-    dst = torch.empty_like(src)
-    dst.copy_(src)
-    torch.cuda.synchronize()
-    c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
-    c0.record()
-    for _ in range(5):
-        dst.copy_(src)
-    c1.record()
-    torch.cuda.synchronize()
-    ceil_gbs = 5 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-    del src, dst
-    out["roofline"]["copy_ceiling_GBps"] = ceil_gbs
-    out["roofline"]["frac_of_copy_ceiling"] = achieved / ceil_gbs
+    # measured ceilings of THIS access pattern, hand-written (tools/ubench/rmw_stream.hip, built by __graft_entry__.build): a float4
+    # copy and an in-place read-modify-write of two 512^3 float32 volumes (far beyond the 256 MiB Infinity Cache) as 1-KiB rows and
+    # as 4 x 2 x 32 bricks, default and non-temporal cache policy.  The sweep's ceiling is the best RMW figure.  Run as a child
+    # process on rank 0 only (its own 1 GiB of HBM).
+    if rank == 0:
+        try:
+            import subprocess
+            ub = os.path.join(ROOT, "tools", "ubench", "rmw_stream")
+            r = subprocess.run([ub, "512", "ceiling"], capture_output=True, text=True, timeout=120)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            ceil = json.loads(line)
+            ceil_gbs = max(ceil["rmw_rows_GBps"], ceil["rmw_rows_nt_GBps"], ceil["rmw_bricks_4x2x32_GBps"], ceil["rmw_bricks_4x2x32_nt_GBps"])
+            out["roofline"]["copy_ceiling_GBps"] = ceil_gbs
+            out["roofline"]["copy_ceiling_is"] = "best in-place read-modify-write of T and w at 512^3 (tools/ubench/rmw_stream.hip)"
+            out["roofline"]["ceilings_GBps"] = ceil
+            out["roofline"]["frac_of_copy_ceiling"] = achieved / ceil_gbs
+        except Exception as e:                                                # a missing tool must not lose the line
+            out["roofline"]["copy_ceiling_GBps"] = None
+            out["roofline"]["copy_ceiling_error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
     # secondary number: the same views fused in ONE sweep of the volume (dfh_integrate_depth_multi; bit-identical to the
     # consecutive sweeps timed above, compute-bound on the per-view projection -- never the headline `value`)
     try:
@@ -563,7 +592,7 @@ def main():
     except Exception as e:                                                   # a secondary figure must not lose the line
         out["multi_view_sweep"] = {"error": repr(e)}
     if world == 1:
-        tr = pmc_traffic("integrate_depth_kernel", R)
+        tr = pmc_traffic(k1_kernel, R)
         if tr is not None:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_source"] = "profiles/" + tr[1]
@@ -608,30 +637,50 @@ def main():
             out["k1_512"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     # The headline (K1) is measured; the secondary legs below run collectives.  If a rank fails inside one of them its peers would
-    # wait in a collective for ever, so every rank arms a watchdog: when it fires, rank 0 prints the line with what it has and all
-    # ranks leave.  (One rank: exceptions are simply caught.)
+    # wait in a collective for ever, so every rank runs a watchdog thread: it ends the rank when the legs' time limit passes OR when
+    # another rank has posted "failed" in the process group's store (looked at twice a second), rank 0 printing the line with
+    # what it has.  A run with a failed or timed-out leg still prints its line but EXITS NON-ZERO (3): a stalled collective must
+    # not look like a clean run to whoever launched it.  (One rank: exceptions are caught, the line is printed, exit code 3.)
     import threading
     emit_lock = threading.Lock()
+    EXIT_LEG_FAILED = 3
+    store = None
+    if distributed:
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
 
-    def emit_and_leave(timed_out=False):
+    def emit_and_leave(bad=False, why=None):
         with emit_lock:                                   # (the watchdog thread and the main thread must not both print)
-            if timed_out:
+            if bad:
                 for leg in ("gn", "frame"):
                     if leg not in out and not (args.no_gn or (leg == "frame" and args.no_frame)):
-                        out[leg] = {"error": "did not finish within %d s (a rank failed or a collective stalled)" % args.leg_timeout}
+                        out[leg] = {"error": why or "did not finish within %d s (a rank failed or a collective stalled)" % args.leg_timeout}
             if rank == 0:
                 print(json.dumps(out))
                 sys.stdout.flush()
-            if timed_out:
-                os._exit(0)
+            if bad:
+                sys.stderr.flush()
+                os._exit(EXIT_LEG_FAILED)                 # (not sys.exit: the main thread may sit inside a collective)
 
     # (a watchdog THREAD, not SIGALRM: a rank stuck inside a collective is inside a C call, where Python runs no signal handler --
-    # but torch releases the GIL there, so a timer thread does run)
-    watchdog = None
+    # but torch releases the GIL there, so a thread does run)
+    legs_done = threading.Event()
+
+    def watch():
+        deadline = time.time() + args.leg_timeout
+        while not legs_done.wait(0.5):
+            if time.time() > deadline:
+                emit_and_leave(bad=True)
+            try:
+                if store is not None and store.check(["bench_leg_failed"]):
+                    emit_and_leave(bad=True, why="another rank failed in this leg (see its stderr)")
+            except Exception:
+                pass
+
     if distributed and args.leg_timeout > 0:
-        watchdog = threading.Timer(args.leg_timeout, emit_and_leave, kwargs={"timed_out": True})
-        watchdog.daemon = True
-        watchdog.start()
+        threading.Thread(target=watch, daemon=True).start()
     failed = False
     if not args.no_gn:
         try:
@@ -646,16 +695,22 @@ def main():
                 out["frame"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
                 failed = True
     if distributed and failed:
-        # this rank's collectives no longer match its peers': do not enter another one; the watchdogs (theirs and ours) end the job
-        if watchdog is not None:
-            time.sleep(args.leg_timeout + 5)
-        emit_and_leave(timed_out=True)
+        # this rank's collectives no longer match its peers': do not enter another one.  Tell the peers (their watchdogs look at
+        # the store), give rank 0 a moment to print its line before a launcher that kills the job at the first non-zero exit
+        # sees ours, and leave.
+        try:
+            if store is not None:
+                store.set("bench_leg_failed", str(rank))
+        except Exception:
+            pass
+        if rank != 0:
+            time.sleep(3.0)
+        emit_and_leave(bad=True, why="not run: an earlier leg failed on this rank")
+    legs_done.set()
     if distributed:
         dist.barrier()
-        if watchdog is not None:
-            watchdog.cancel()
         dist.destroy_process_group()
-    emit_and_leave()
+    emit_and_leave(bad=failed)
 
 
 if __name__ == "__main__":

@@ -25,9 +25,12 @@ _SIGNATURES = {
     "dfh_version": (_int, []),
     "dfh_last_error": (ctypes.c_char_p, []),
     "dfh_stream_synchronize": (_int, [_vp]),
+    "dfh_set_option": (_int, [ctypes.c_char_p, ctypes.c_long]),
+    "dfh_get_option": (ctypes.c_long, [ctypes.c_char_p]),
     "dfh_integrate_workspace_bytes": (ctypes.c_size_t, [_int, _int, _int, _c_int_p, _int, _int]),
     "dfh_integrate_depth": (_int, [_vp, _vp, _int, _c_int_p, _int, _int, _int, _vp, _int, _int, _int,
                                    _c_double_p, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, ctypes.c_size_t, _vp]),
+    "dfh_integrate_depth_path": (_int, [_int, _c_int_p, _int, _int, _int, _int, _int]),
     "dfh_integrate_depth_ocl": (_int, [_vp, _vp, _c_int_p, _int, _int, _vp, _int, _int, ctypes.POINTER(ctypes.c_float),
                                        ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.c_float, _vp]),
     "dfh_integrate_multi_workspace_bytes": (ctypes.c_size_t, [_int]),
@@ -140,6 +143,26 @@ def check(rc, what):
         if rc == -4:
             raise DfhTimeout("%s: %s" % (what, msg))
         raise DfhError("%s failed (%d): %s" % (what, rc, msg))
+
+
+_options_touched = set()
+
+
+def set_option(name, value):
+    """A development switch of the library (include/dfusion_hip.h: dfh_set_option); value None = unset (-1)."""
+    check(load().dfh_set_option(name.encode(), -1 if value is None else int(value)), "dfh_set_option")
+    _options_touched.add(name)
+
+
+def reset_options():
+    """Every switch changed through set_option() back to unset (tests call this between cases)."""
+    for name in sorted(_options_touched):
+        check(load().dfh_set_option(name.encode(), -1), "dfh_set_option")
+    _options_touched.clear()
+
+
+def get_option(name):
+    return int(load().dfh_get_option(name.encode()))
 
 
 _darr_cache = {}

@@ -33,4 +33,27 @@ struct DQ { double q[8]; };
 
 constexpr int kWave = 64;             // CDNA wavefront
 
+// ---- development switches (dfh_set_option / DFH_OPTIONS, include/dfusion_hip.h) -----------
+// One table, filled once at the first call into the library; -1 = unset.  The call paths read this struct, never the
+// environment.  k1_*: depth -> TSDF sweep; k2/k3: volume -> volume fusion; gn_* / plan_* / pcg_*: the solve.
+#define DFH_OPTION_LIST(X)                                                                                                \
+    X(k1_strided) X(k1_late_loads) X(k1_planes_per_block) X(k1_force_scalar) X(k1_bricks_min) X(k1_no_bricks)            \
+    X(k1_bricks_nocull) X(k1_no_multi) X(k1_cull) X(k1_nzi) X(k1_prefetch) X(k1_nt)                  \
+    X(k2_exact) X(k2_no_strided) X(k3_no_cache) X(plan_radix) X(rigid_atomic) X(gn_reg_own_launch) X(gn_reg_own_gather) \
+    X(dbg_gather_part) X(pcg_wpb) X(pcg_multilaunch) X(pcg_spin_limit) X(gn_iter_own_clear)
+struct Options {
+#define DFH_X(n) long n;
+    DFH_OPTION_LIST(DFH_X)
+#undef DFH_X
+};
+const Options &opt();                 // dfh_core.hip
+
+// ---- what the library remembers per device (a process may drive several GPUs) ----------
+struct DeviceInfo {
+    int n_cu = 0;                     // 0 = not queried yet
+    int pcg_occ512 = -1, pcg_occ1024 = -1;   // workgroups of the persistent PCG kernels that fit one CU; -1 = not queried yet
+};
+DeviceInfo &device_info(int device);  // dfh_core.hip
+inline bool on(long v) { return v > 0; }
+
 }  // namespace dfh

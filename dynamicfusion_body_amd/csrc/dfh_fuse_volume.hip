@@ -610,14 +610,14 @@ extern "C" int dfh_fuse_volume_rigid(void *tsdf, void *tsdf_w, int vol_dtype, co
     const size_t esz = vol_dtype == DFH_F32 ? 4 : 8;
     const bool vec4 = (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) && ((uintptr_t)tsdf_w % (4 * esz) == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (vol_dtype == DFH_F32 && vec4 && !getenv("DFH_K2_EXACT")) {
+    if (vol_dtype == DFH_F32 && vec4 && !on(opt().k2_exact)) {
         RigidFastParams f;
         fold_rigid(lw_dq, f);
         p.zpacks = p.Z / 4;
         p.zp_shift = -1;
         for (int b = 0; b < 31; ++b) if (p.zpacks == (1 << b)) p.zp_shift = b;
         dim3 grid((unsigned)(((long)p.Y * p.zpacks + 255) / 256), (unsigned)p.nx), block(256);
-        const bool strided = p.zpacks % 64 == 0 && !getenv("DFH_NO_STRIDED");
+        const bool strided = p.zpacks % 64 == 0 && !on(opt().k2_no_strided);
 #define DFH_K2(LT, ST) hipLaunchKernelGGL((fuse_volume_rigid_fast_kernel<LT, ST>), grid, block, 0, s, (float *)tsdf, \
                                           (float *)tsdf_w, (const LT *)live, p, f)
         if (live_dtype == DFH_F32) { if (strided) DFH_K2(float, true); else DFH_K2(float, false); }
@@ -681,7 +681,7 @@ extern "C" int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, cons
     const size_t base = cand_bytes(res, x0, x1);
     const size_t cached1 = dfh_dqb_workspace_bytes_cached(res, x0, x1, knn, n_nodes, 1);
     const size_t cached2 = dfh_dqb_workspace_bytes_cached(res, x0, x1, knn, n_nodes, 2);
-    const bool has_idx = cached1 > base && workspace_bytes >= cached1 && !getenv("DFH_K3_NO_CACHE");
+    const bool has_idx = cached1 > base && workspace_bytes >= cached1 && !on(opt().k3_no_cache);
     const bool has_w = has_idx && workspace_bytes >= cached2;
     unsigned short *knn_cache = has_idx ? reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + base) : nullptr;
     double *w_cache = has_w ? reinterpret_cast<double *>(static_cast<char *>(workspace) + cached1) : nullptr;

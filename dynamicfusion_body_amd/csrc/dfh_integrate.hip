@@ -62,13 +62,11 @@ constexpr int kFixOne = 1 << kFixShift;
 constexpr int kFixHalf = 1 << (kFixShift - 1);
 constexpr int kFixBand = 8;                     // guard band around multiples of 0.5 px
 constexpr int kFastMaxDim = 2048;               // (dim-1) << 20 must fit in int32
-// brick = kBrX x kBrY x kBrZ voxels = one wave (64 lanes x 4 voxels); kBrZ / 4 z-packs per row, kBrX * kBrY rows
-#ifndef DFH_BRICK_Y
-#define DFH_BRICK_Y 4
-#endif
-constexpr int kBrX = 4, kBrY = DFH_BRICK_Y, kBrZ = 256 / (kBrX * kBrY);      // 4 x 4 x 16 (shipped) or 4 x 2 x 32
-constexpr int kBrZP = kBrZ / 4;                  // z-packs per row of a brick
-static_assert(kBrX * kBrY * kBrZP == 64, "a brick is one wave");
+// brick = kBrX x kBrY x kBrZ voxels = 4 x 2 x 32 = one wave instruction's worth (64 lanes x 4 voxels along z); eight z-packs =
+// 128 bytes per row: every cache line of T and w is touched by ONE instruction (4 x 4 x 16, round 2's shape, culls a little
+// finer on oblique views but its 64-byte segments cost 15-40 % in the sweep: profiles/r3_k1_experiments.txt)
+constexpr int kBrX = 4, kBrY = 2, kBrZ = 256 / (kBrX * kBrY);
+constexpr int kMaxColumnBricks = 16;            // bricks per wave of the column walk (their masks sit in the first lanes)
 constexpr int kPyrLevels = 5;                   // pyramid levels 1..5 (cells of 2..32 pixels)
 constexpr int kCullMargin = 1 << 10;            // 2^-10 px: corner projections are good to 2^-19 px, the reference's to 1e-12 px
 constexpr long kEarlyRowsMaxVoxels = 1L << 23;  // slabs up to half of 256^3 take the early-load row sweep (integrate_depth_rows_early_kernel);
@@ -441,53 +439,67 @@ __global__ __launch_bounds__(256) void integrate_depth_multi_kernel(float *__res
 // Brick mapping with conservative culling.
 // The row mapping above gives every wave a 1 x 1 x 256 run of voxels: such a run crosses the frustum planes and the
 // occlusion boundary almost always, so the ~50 % of the voxels a view cannot update still pay the whole projection and
-// gather.  Here a wave owns a compact 4 x 4 x 16 brick (lane = z-pack + 4 y + 16 x; a quarter-wave touches four 64-byte
-// row segments, the four waves of a workgroup sit behind one another in z, so every 256-byte stretch of a row is
-// consumed by one workgroup).  Voxel centres of a brick span a box; an affine map followed by the perspective divide
-// keeps the image of a box in front of the camera inside the bounding rectangle of its eight projected corners.  So:
+// gather.  Here a wave works on compact bricks of 4 x BY x (64 / BY) voxels (BY = 4: 4 x 4 x 16, lane = z-pack + 4 y + 16 x,
+// a quarter-wave touches four 64-byte row segments; BY = 2: 4 x 2 x 32, 128-byte segments).  Voxel centres of a brick span a
+// box; an affine map followed by the perspective divide keeps the image of a box in front of the camera inside the bounding
+// rectangle of its eight projected corners.  So:
 //   * all corners in front of the camera and the rectangle entirely outside [0, W-1) x [0, H-1) (with a 2^-10 px
-//     margin, the corners being good to 2^-19 px): no voxel is visible -> the wave skips the view;
+//     margin, the corners being good to 2^-19 px): no voxel is visible -> the brick is skipped for that view;
 //   * (pinhole) z_max = the largest valid depth over the pixels the rectangle can round to, from a max-pyramid of the
 //     depth map, and z_max + tdist (+ margin) <= the smallest corner depth: every voxel has sd <= -tdist or no depth at
 //     all -> nothing is updated -> skip.
 // Skipping is only ever done when NO voxel of the brick would be updated, so the result is bit-identical to the row
 // kernels (tests compare every voxel).  Bricks that survive run view_pack exactly as before.
+//
+// Round 3: a wave no longer owns ONE brick but walks a COLUMN of them along z (tools/ubench/rmw_stream.hip is the
+// measurement behind this).  A wave's slot is held from launch until its last store has been acknowledged, and nothing
+// but its own instructions can fill that time: with one brick per wave the life of a wave was
+//   launch + index arithmetic + mask load | projection | gathers + T/w in flight | decisions + average | store drain
+// = three exposed memory latencies around ~0.5 us of arithmetic, 8 waves per SIMD could not cover them (VALU 43 % busy,
+// waves waiting 75 % of their life) and the sweep ran at 0.57 of HBM peak where a bare read-modify-write of the same
+// bytes reaches 0.72 (0.80 with non-temporal accesses on whole 128-byte lines).  Walking a column, the wave has the NEXT
+// brick's T / w loads in flight while it projects the current one, and the stores of the previous brick drain meanwhile:
+// the launch, the index arithmetic and the mask load are paid once per column, the grid is three-dimensional (no
+// divisions: the first version spent ~600 scalar instructions per wave on 64-bit divisions of a linear workgroup index).
 struct BrickGeom {
-    int nzg;           // workgroups along z (64 voxels each)
+    int nbz;           // bricks along z
     int nyb;           // bricks along y
     int nxb;           // bricks along x (slab)
-    int order;         // launch order of the workgroups (tuning): 0 = z fastest, 1 = y fastest, 2 = one contiguous x range per XCD
+    int nzi;           // bricks per wave: the four waves of workgroup (by, c, bx) take the bricks bz = 4 (c nzi + i) + wave, i < nzi
+    int nzc;           // workgroups along z = ceil(nbz / (4 nzi))
 };
 
-// true when `p`'s view provably updates no voxel of the brick whose first voxel is (x0, y0, z0) (global indices)
-template <bool PINHOLE>
-__device__ __forceinline__ bool brick_culled(const IntegrateParams &p, int x0, int y0, int z0) {
+// The projected bounding rectangle of a brick (2^-20 px fixed point, possibly saturated), its smallest camera depth and
+// whether every corner lies in front of the camera.
+struct BrickBounds {
+    int umin, umax, vmin, vmax;
+    double l2min;
+    bool front;
+};
+
+// corner `c` (bit 0: +x, bit 1: +y, bit 2: +z end) of the brick whose first voxel is (x0, y0, z0)
+template <bool PINHOLE, int BY>
+__device__ __forceinline__ void brick_corner(const IntegrateParams &p, int x0, int y0, int z0, int c, int &qu, int &qv, double &l2, bool &front) {
     constexpr int NC = PINHOLE ? 3 : 4;
-    double base[NC];
-    {
-        const double xf = (double)x0, yf = (double)y0, zf = (double)z0;
+    constexpr int BZ = 256 / (kBrX * BY);
+    const double xf = (double)(x0 + ((c & 1) ? kBrX - 1 : 0)), yf = (double)(y0 + ((c & 2) ? BY - 1 : 0)), zf = (double)(z0 + ((c & 4) ? BZ - 1 : 0));
+    double q[NC];
 #pragma unroll
-        for (int r = 0; r < NC; ++r) base[r] = __builtin_fma(p.Az[r], zf, __builtin_fma(p.Ax[r], xf, __builtin_fma(p.Ay[r], yf, p.Ac[r])));
-    }
-    int umin = 0x7fffffff, umax = (int)0x80000000, vmin = 0x7fffffff, vmax = (int)0x80000000;
-    double l2min = __builtin_huge_val();
-    bool front = true;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {                        // the affine map is linear in the corner offsets
-        double q[NC];
-#pragma unroll
-        for (int r = 0; r < NC; ++r)
-            q[r] = base[r] + (((c & 1) ? (double)(kBrX - 1) * p.Ax[r] : 0.0) + ((c & 2) ? (double)(kBrY - 1) * p.Ay[r] : 0.0) +
-                              ((c & 4) ? (double)(kBrZ - 1) * p.Az[r] : 0.0));
-        front = front && q[2] > 1e-6;
-        const double rr = rcp_nr1(q[2]);
-        const int qu = cvt_i32_sat(q[0] * rr), qv = cvt_i32_sat(q[1] * rr);
-        umin = min(umin, qu); umax = max(umax, qu); vmin = min(vmin, qv); vmax = max(vmax, qv);
-        l2min = fmin(l2min, q[NC - 1]);
-    }
-    if (!front) return false;                            // a corner at or behind the camera plane: no claim
+    for (int r = 0; r < NC; ++r) q[r] = __builtin_fma(p.Az[r], zf, __builtin_fma(p.Ax[r], xf, __builtin_fma(p.Ay[r], yf, p.Ac[r])));
+    front = q[2] > 1e-6;
+    const double rr = rcp_nr1(q[2]);
+    qu = cvt_i32_sat(q[0] * rr);
+    qv = cvt_i32_sat(q[1] * rr);
+    l2 = q[NC - 1];
+}
+
+// true when a view with these bounds provably updates no voxel of the brick
+template <bool PINHOLE>
+__device__ __forceinline__ bool bounds_culled(const IntegrateParams &p, BrickBounds b) {
+    if (!b.front) return false;                          // a corner at or behind the camera plane: no claim
+    int umin = b.umin, umax = b.umax, vmin = b.vmin, vmax = b.vmax;
     const int ulim = (p.W - 1) << kFixShift, vlim = (p.H - 1) << kFixShift;
-    // (the corner sums above differ from view_pack's FMA chain by ~1e-13 relative: far inside the 2^-10 px margin)
+    // (the corners are view_pack's own FMA chain at the corner voxels: ~2^-19 px, far inside the 2^-10 px margin)
     if (umax < -kCullMargin || umin > ulim + kCullMargin || vmax < -kCullMargin || vmin > vlim + kCullMargin) return true;
     if (!PINHOLE || p.pyr == nullptr) return false;
     // pixels the voxels can round to: [floor(umin), ceil(umax)] x [floor(vmin), ceil(vmax)], clipped to the image
@@ -500,147 +512,209 @@ __device__ __forceinline__ bool brick_culled(const IntegrateParams &p, int x0, i
     if (px1 < px0 || py1 < py0) return false;            // (cannot happen after the rectangle test: no claim)
     int L = 1;
     while (L <= kPyrLevels && (((px1 >> L) - (px0 >> L)) > 1 || ((py1 >> L) - (py0 >> L)) > 1)) ++L;
-    if (L > kPyrLevels) return false;                    // footprint wider than two 32-pixel cells: no claim
+    if (L > kPyrLevels) {                                // wider than two 32-pixel cells (long bricks seen side-on): up to 4 x 4 of them
+        L = kPyrLevels;
+        if (((px1 >> L) - (px0 >> L)) > 3 || ((py1 >> L) - (py0 >> L)) > 3) return false;      // no claim
+    }
     const float *lv = p.pyr + p.pyr_off[L];
     const int wl = p.pyr_w[L];
     const int cx0 = px0 >> L, cx1 = px1 >> L, cy0 = py0 >> L, cy1 = py1 >> L;
-    const float zmax = fmaxf(fmaxf(lv[cy0 * wl + cx0], lv[cy0 * wl + cx1]), fmaxf(lv[cy1 * wl + cx0], lv[cy1 * wl + cx1]));
+    float zmax = 0.0f;                                   // (pyramid values are >= 0)
+    for (int cy = cy0; cy <= cy1; ++cy)
+        for (int cx = cx0; cx <= cx1; ++cx) zmax = fmaxf(zmax, lv[cy * wl + cx]);
     // sd = z - l2 <= zmax - l2min for every voxel with a valid pixel; the margin covers the float32 rounding of l2min
-    const float l2f = (float)l2min;
+    const float l2f = (float)b.l2min;
     return zmax + p.tdist_f + fmaf(fabsf(l2f), 4e-7f, 1e-5f) <= l2f;
 }
 
+// one thread, one brick: the eight corners in turn
+template <bool PINHOLE, int BY>
+__device__ __forceinline__ bool brick_culled(const IntegrateParams &p, int x0, int y0, int z0) {
+    BrickBounds b{0x7fffffff, (int)0x80000000, 0x7fffffff, (int)0x80000000, __builtin_huge_val(), true};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int qu, qv;
+        double l2;
+        bool fr;
+        brick_corner<PINHOLE, BY>(p, x0, y0, z0, c, qu, qv, l2, fr);
+        b.front = b.front && fr;
+        b.umin = min(b.umin, qu); b.umax = max(b.umax, qu); b.vmin = min(b.vmin, qv); b.vmax = max(b.vmax, qv);
+        b.l2min = fmin(b.l2min, l2);
+    }
+    return bounds_culled<PINHOLE>(p, b);
+}
+
 // Classification pass: one THREAD per brick, bit v of mask[brick] = view v may update a voxel of the brick.  Bricks are
-// numbered ((bx * nyb + by) * nzg + bzg) * 4 + wave, i.e. the four bricks of one sweep workgroup are consecutive.
-template <bool PINHOLE, bool BYVAL>
+// numbered (bx * nyb + by) * nbz + bz: the bricks of one column are consecutive.
+template <bool PINHOLE, bool BYVAL, int BY>
 __global__ __launch_bounds__(256) void brick_classify_kernel(const IntegrateParams *__restrict__ views, const IntegrateParams p1,
                                                               int n_views, const BrickGeom g, int n_bricks,
                                                               unsigned short *__restrict__ mask) {
+    constexpr int BZ = 256 / (kBrX * BY);
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= n_bricks) return;
-    const int wv = b & 3;
-    int t = b >> 2;
-    const int bzg = t % g.nzg; t /= g.nzg;
+    const int bz = b % g.nbz;
+    const int t = b / g.nbz;
     const int by = t % g.nyb;
     const int bx = t / g.nyb;
-    const int z0 = 4 * kBrZ * bzg + kBrZ * wv;
     unsigned m = 0;
-    if (z0 < p1.Z) {
-        for (int v = 0; v < n_views; ++v) {
-            const IntegrateParams &p = BYVAL ? p1 : views[v];
-            if (!(p.cull && brick_culled<PINHOLE>(p, p.x0 + kBrX * bx, kBrY * by, z0))) m |= 1u << v;
-        }
+    for (int v = 0; v < n_views; ++v) {
+        const IntegrateParams &p = BYVAL ? p1 : views[v];
+        if (!(p.cull && brick_culled<PINHOLE, BY>(p, p.x0 + kBrX * bx, BY * by, BZ * bz))) m |= 1u << v;
     }
     mask[b] = (unsigned short)m;
 }
 
-__device__ __forceinline__ void brick_coords(const IntegrateParams &p, const BrickGeom g, int &xl, int &y, int &z0, int &brick) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int bzg, by, bx;
-    const long lin = (long)blockIdx.y * gridDim.x + blockIdx.x;
-    if (g.order == 0) {                                   // z fastest, then y, then x
-        bzg = (int)(lin % g.nzg); by = (int)((lin / g.nzg) % g.nyb); bx = (int)(lin / ((long)g.nzg * g.nyb));
-    } else if (g.order == 1) {                            // y fastest, then z, then x
-        by = (int)(lin % g.nyb); bzg = (int)((lin / g.nyb) % g.nzg); bx = (int)(lin / ((long)g.nzg * g.nyb));
-    } else if (g.order == 3) {                            // x fastest, then y, then z
-        bx = (int)(lin % g.nxb); by = (int)((lin / g.nxb) % g.nyb); bzg = (int)(lin / ((long)g.nxb * g.nyb));
-    } else if (g.order == 4) {                            // y fastest with a diagonal z
-        by = (int)(lin % g.nyb); bzg = (int)((lin / g.nyb + by) % g.nzg); bx = (int)(lin / ((long)g.nzg * g.nyb));
-    } else if (g.order == 5) {                            // y fastest, then x, then z
-        by = (int)(lin % g.nyb); bx = (int)((lin / g.nyb) % g.nxb); bzg = (int)(lin / ((long)g.nxb * g.nyb));
-    } else {
-        // workgroups are dealt round-robin to the 8 XCDs: give XCD k the k-th eighth of the (x, y, z) ordered bricks
-        const long total = (long)gridDim.x * gridDim.y;
-        const long per = (total + 7) / 8;
-        const long logical = (lin & 7) * per + (lin >> 3);      // (total % 8 == 0, checked on the host)
-        bzg = (int)(logical % g.nzg); by = (int)((logical / g.nzg) % g.nyb); bx = (int)(logical / ((long)g.nzg * g.nyb));
-    }
-    brick = (((bx * g.nyb + by) * g.nzg) + bzg) * 4 + wv;
-    xl = kBrX * bx + lane / (kBrY * kBrZP);               // slab-local plane
-    y = kBrY * by + (lane / kBrZP) % kBrY;
-    z0 = 4 * kBrZ * bzg + kBrZ * wv + 4 * (lane % kBrZP);
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static_assert(sizeof(f32x4) == sizeof(Pack<float, 4>), "a pack is one 16-byte access");
+
+// NT: non-temporal accesses (global_load / global_store ... nt).  Measured (tools/ubench/rmw_stream.hip, 512^3): an in-place
+// read-modify-write of T and w runs at 5.7 TB/s with the default policy and at 6.4 TB/s non-temporal -- IF every 128-byte
+// line is touched by one instruction (rows, 4 x 2 x 32 bricks); with 64-byte segments (4 x 4 x 16) the second toucher of a
+// line finds it gone and non-temporal is slower (5.0 TB/s).
+template <bool NT>
+__device__ __forceinline__ Pack<float, 4> ld_pack(const float *a) {
+    const f32x4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a)) : *reinterpret_cast<const f32x4 *>(a);
+    Pack<float, 4> r;
+    r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
+    return r;
 }
+template <bool NT>
+__device__ __forceinline__ void st_pack(float *a, const Pack<float, 4> &r) {
+    f32x4 v;
+    v.x = r.v[0]; v.y = r.v[1]; v.z = r.v[2]; v.w = r.v[3];
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(a));
+    else *reinterpret_cast<f32x4 *>(a) = v;
+}
+
+// The column walk shared by the single- and the multi-view sweep: this wave's bricks as a bit set (bit i = brick
+// bz0 + 4 i takes part), the lane's voxel coordinates, its row offset.
+template <int BY>
+struct ColumnLane {
+    static constexpr int BZ = 256 / (kBrX * BY), BZP = BZ / 4;
+    int xl, y, zl, bz0;
+    bool in_xy;
+    size_t row;
+    unsigned mv;       // lane i: the 16-bit view mask of brick bz0 + 4 i (0 beyond the column)
+
+    // returns the set of bricks to visit: those with a non-zero mask, or (`all`) every brick of the wave inside the grid
+    __device__ __forceinline__ unsigned long long init(const BrickGeom &g, int nx, int Y, int Z, const unsigned short *__restrict__ mask,
+                                                       unsigned full_mask, bool all) {
+        const int lane = threadIdx.x & 63;
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int by = blockIdx.x, c = blockIdx.y, bx = blockIdx.z;
+        xl = kBrX * bx + lane / (BY * BZP);
+        y = BY * by + (lane / BZP) % BY;
+        zl = 4 * (lane % BZP);
+        bz0 = 4 * c * g.nzi + wv;
+        in_xy = xl < nx && y < Y;
+        row = ((size_t)xl * Y + y) * Z;
+        const int bz = bz0 + 4 * lane;
+        const bool mine = lane < g.nzi && bz < g.nbz;
+        mv = 0;
+        if (mine) mv = mask ? (unsigned)mask[(size_t)(bx * g.nyb + by) * g.nbz + bz] : full_mask;
+        return __ballot(all ? mine : mv != 0);
+    }
+
+    __device__ __forceinline__ int z_of(int i) const { return BZ * (bz0 + 4 * i) + zl; }
+};
 
 // One view.  mask == NULL: every brick is swept (no classification pass ran).
-template <typename DepthT, bool PINHOLE, bool EARLY>
-__global__ __launch_bounds__(256) void integrate_depth_brick_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
-                                                                     const DepthT *__restrict__ depth, const IntegrateParams p,
-                                                                     const BrickGeom g, const unsigned short *__restrict__ mask) {
-    int xl, y, z0, brick;
-    brick_coords(p, g, xl, y, z0, brick);
-    if (mask && __builtin_amdgcn_readfirstlane((int)mask[__builtin_amdgcn_readfirstlane(brick)]) == 0) return;   // (wave-uniform)
-    const bool in_grid = xl < p.nx && y < p.Y && z0 < p.Z;
-    float ms[4];
-    bool upd[4];
-    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z0;
+// PREFETCH: T / w of the wave's NEXT brick are requested right after the depth gathers of the current one (they are in
+// flight through its decisions, its stores and the next projection); otherwise a brick's T / w are requested when the walk
+// reaches it, ahead of its projection.
+#ifdef DFH_K1_WAVES                    // experiment builds: force the register budget of DFH_K1_WAVES waves per SIMD
+#define DFH_K1_OCC __attribute__((amdgpu_waves_per_eu(DFH_K1_WAVES, DFH_K1_WAVES)))
+#else
+#define DFH_K1_OCC
+#endif
+template <typename DepthT, bool PINHOLE, int BY, bool PREFETCH, bool NT>
+__global__ __launch_bounds__(256) DFH_K1_OCC void integrate_depth_column_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                      const DepthT *__restrict__ depth, const IntegrateParams p,
+                                                                      const BrickGeom g, const unsigned short *__restrict__ mask) {
+    ColumnLane<BY> c;
+    unsigned long long alive = c.init(g, p.nx, p.Y, p.Z, mask, 1u, false);
+    if (alive == 0) return;
     using P = Pack<float, 4>;
+    const IntegrateParams *p_rare = kernarg_params(kParamsAfterThreePointers);
+    int i = __builtin_ctzll(alive);
+    alive &= alive - 1;
+    int z0 = c.z_of(i);
+    bool in_grid = c.in_xy && z0 < p.Z;
     P t, w;
-    bool loaded = false;
-    // T / w of a pack that projects into the image are requested together with its depth gathers: in the bricks that
-    // survive the classification nearly every such pack is updated, so little is fetched in vain and the sweep pays one
-    // memory round trip instead of two
-    const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, kernarg_params(kParamsAfterThreePointers), depth, p.x0 + xl, y, z0, ms, upd, [&](bool any_inside) {
-        if (EARLY && any_inside && in_grid) {
-            t = *reinterpret_cast<const P *>(tsdf + off);
-            w = *reinterpret_cast<const P *>(tsdf_w + off);
-            loaded = true;
+    if (PREFETCH && in_grid) { t = ld_pack<NT>(tsdf + c.row + z0); w = ld_pack<NT>(tsdf_w + c.row + z0); }
+    for (;;) {
+        if (!PREFETCH && in_grid) { t = ld_pack<NT>(tsdf + c.row + z0); w = ld_pack<NT>(tsdf_w + c.row + z0); }
+        const bool more = alive != 0;
+        int zn = 0;
+        bool in_grid_n = false;
+        P tn, wn;
+        if (more) {
+            zn = c.z_of(__builtin_ctzll(alive));
+            in_grid_n = c.in_xy && zn < p.Z;
         }
-    });
-    if (!(any && in_grid)) return;
-    if (!loaded) {                                        // (late variant; early: cannot happen, any implies any_inside)
-        t = *reinterpret_cast<const P *>(tsdf + off);
-        w = *reinterpret_cast<const P *>(tsdf_w + off);
-    }
-    apply_pack<4>(t, w, ms, upd, p.wmax_f);
-    *reinterpret_cast<P *>(tsdf + off) = t;
-    *reinterpret_cast<P *>(tsdf_w + off) = w;
-}
-
-// FRESH: the volume is taken to be (fresh_t, 0) everywhere -- a live volume that starts from np.zeros + tdist / np.zeros
-// (core/fusion_dm.py:152-153) -- so nothing is loaded and EVERY pack is written: the fill and the sweep in one pass over the
-// volume (one write of it instead of a write, a read of the updated part and another write).
-template <typename DepthT, bool PINHOLE, bool FRESH>
-__global__ __launch_bounds__(256) void integrate_depth_multi_brick_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
-                                                                           const IntegrateParams *__restrict__ views, const ViewPtrs vp,
-                                                                           const BrickGeom g, const unsigned short *__restrict__ mask,
-                                                                           const float fresh_t) {
-    int xl, y, z0, brick;
-    brick_coords(views[0], g, xl, y, z0, brick);
-    unsigned m = mask ? (unsigned)__builtin_amdgcn_readfirstlane((int)mask[__builtin_amdgcn_readfirstlane(brick)]) : (1u << vp.n) - 1u;
-    const bool in_grid = xl < views[0].nx && y < views[0].Y && z0 < views[0].Z;
-    using P = Pack<float, 4>;
-    const size_t off = ((size_t)xl * views[0].Y + y) * views[0].Z + z0;
-    P t, w;
-    if (FRESH) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { t.v[j] = fresh_t; w.v[j] = 0.0f; }
-    }
-    if (m == 0) {
-        if (FRESH && in_grid) {
-            *reinterpret_cast<P *>(tsdf + off) = t;
-            *reinterpret_cast<P *>(tsdf_w + off) = w;
-        }
-        return;
-    }
-    bool loaded = FRESH;
-    while (m) {                                           // views in ascending order: the order of consecutive sweeps
-        const int v = __builtin_ctz(m);
-        m &= m - 1;
-        const IntegrateParams &p = views[v];             // uniform address: scalar loads
         float ms[4];
         bool upd[4];
-        const bool any = view_pack<DepthT, 4, PINHOLE, false, false>(p, &p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + xl, y, z0, ms, upd);
-        if (!(any && in_grid)) continue;
-        if (!loaded) {
-            t = *reinterpret_cast<const P *>(tsdf + off);
-            w = *reinterpret_cast<const P *>(tsdf_w + off);
-            loaded = true;
+        const bool any = view_pack<DepthT, 4, PINHOLE, false>(p, p_rare, depth, p.x0 + c.xl, c.y, z0, ms, upd, [&](bool) {
+            if (PREFETCH && in_grid_n) { tn = ld_pack<NT>(tsdf + c.row + zn); wn = ld_pack<NT>(tsdf_w + c.row + zn); }
+        });
+        if (any && in_grid) {
+            apply_pack<4>(t, w, ms, upd, p.wmax_f);
+            st_pack<NT>(tsdf + c.row + z0, t);
+            st_pack<NT>(tsdf_w + c.row + z0, w);
         }
-        apply_pack<4>(t, w, ms, upd, p.wmax_f);
+        if (!more) break;
+        alive &= alive - 1;
+        z0 = zn;
+        in_grid = in_grid_n;
+        if (PREFETCH) { t = tn; w = wn; }
     }
-    if (loaded && in_grid) {
-        *reinterpret_cast<P *>(tsdf + off) = t;
-        *reinterpret_cast<P *>(tsdf_w + off) = w;
+}
+
+// Several views in one sweep, column walk.  FRESH: the volume is taken to be (fresh_t, 0) everywhere -- a live volume that
+// starts from np.zeros + tdist / np.zeros (core/fusion_dm.py:152-153) -- so nothing is loaded and EVERY pack is written:
+// the fill and the sweep in one pass over the volume (one write of it instead of a write, a read of the updated part and
+// another write).  Otherwise T / w of a surviving brick are requested before its first view's projection and written if a
+// view updated the pack.
+template <typename DepthT, bool PINHOLE, int BY, bool FRESH, bool NT>
+__global__ __launch_bounds__(256) void integrate_depth_multi_column_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                            const IntegrateParams *__restrict__ views, const ViewPtrs vp,
+                                                                            const BrickGeom g, const unsigned short *__restrict__ mask,
+                                                                            const float fresh_t) {
+    ColumnLane<BY> c;
+    const int nx = views[0].nx, Y = views[0].Y, Z = views[0].Z;
+    unsigned long long alive = c.init(g, nx, Y, Z, mask, (1u << vp.n) - 1u, FRESH);
+    using P = Pack<float, 4>;
+    while (alive) {
+        const int i = __builtin_ctzll(alive);
+        alive &= alive - 1;
+        unsigned m = (unsigned)__builtin_amdgcn_readlane((int)c.mv, i);
+        const int z0 = c.z_of(i);
+        const bool in_grid = c.in_xy && z0 < Z;
+        P t, w;
+        if (FRESH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t.v[j] = fresh_t; w.v[j] = 0.0f; }
+        } else if (in_grid) {
+            t = ld_pack<NT>(tsdf + c.row + z0);
+            w = ld_pack<NT>(tsdf_w + c.row + z0);
+        }
+        bool touched = FRESH;
+        while (m) {                                       // views in ascending order: the order of consecutive sweeps
+            const int v = __builtin_ctz(m);
+            m &= m - 1;
+            const IntegrateParams &p = views[v];         // uniform address: scalar loads
+            float ms[4];
+            bool upd[4];
+            const bool any = view_pack<DepthT, 4, PINHOLE, false, false>(p, &p, static_cast<const DepthT *>(vp.depth[v]), p.x0 + c.xl, c.y, z0, ms, upd);
+            if (!(any && in_grid)) continue;
+            apply_pack<4>(t, w, ms, upd, p.wmax_f);
+            touched = true;
+        }
+        if (touched && in_grid) {
+            st_pack<NT>(tsdf + c.row + z0, t);
+            st_pack<NT>(tsdf_w + c.row + z0, w);
+        }
     }
 }
 
@@ -822,7 +896,7 @@ static int launch_integrate(void *tsdf, void *tsdf_w, const void *depth, Integra
     dim3 block(256);
     if constexpr (FAST) {
         // strided lanes need whole 256-voxel runs per wave: 64 packs of one row
-        const bool strided = VEC == 4 && p.zpacks % 64 == 0 && getenv("DFH_STRIDED");   // opt-in: measured no faster
+        const bool strided = VEC == 4 && p.zpacks % 64 == 0 && on(opt().k1_strided);   // opt-in: measured no faster
         if (strided) {
             if constexpr (VEC == 4) {
                 if (pinhole) {
@@ -833,7 +907,7 @@ static int launch_integrate(void *tsdf, void *tsdf_w, const void *depth, Integra
                                        (float *)tsdf, (float *)tsdf_w, (const DepthT *)depth, p);
                 }
             }
-        } else if (VEC == 4 && p.planes_per_block == 1 && (long)p.nx * p.Y * p.Z <= kEarlyRowsMaxVoxels && !getenv("DFH_K1_LATE_LOADS")) {
+        } else if (VEC == 4 && p.planes_per_block == 1 && (long)p.nx * p.Y * p.Z <= kEarlyRowsMaxVoxels && !on(opt().k1_late_loads)) {
             if (pinhole)
                 hipLaunchKernelGGL((integrate_depth_rows_early_kernel<DepthT, true>), grid, block, 0, stream, (float *)tsdf, (float *)tsdf_w,
                                    (const DepthT *)depth, p);
@@ -908,8 +982,7 @@ static bool fill_params(IntegrateParams &p, const int res[3], int tsdf_res, int 
         if (chunks < 1) chunks = 1;
         if (chunks > p.nx) chunks = p.nx;
         p.planes_per_block = (int)((p.nx + chunks - 1) / chunks);
-        const char *env = getenv("DFH_PLANES_PER_BLOCK");       // tuning knob for kbench sweeps
-        if (env && atoi(env) > 0) p.planes_per_block = atoi(env);
+        if (opt().k1_planes_per_block > 0) p.planes_per_block = (int)opt().k1_planes_per_block;       // tuning knob for kbench sweeps
     }
     return K[1] == 0.0 && K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0 && K[8] == 1.0 && Kinv[6] == 0.0 && Kinv[7] == 0.0 &&
            Kinv[8] == 1.0;
@@ -937,22 +1010,60 @@ static int launch_pyramids(const void *const *depth, int n_views, int H, int W, 
     return DFH_OK;
 }
 
-static BrickGeom brick_geom(int Y, int Z, int nx, dim3 &grid, int &n_bricks) {
+// Column walk geometry for a slab of nx planes.  nzi (bricks per wave): as long a walk as leaves >= ~4 workgroups per
+// workgroup slot of the chip (256 CUs x 8), at most kMaxColumnBricks; option k1_nzi overrides.
+static BrickGeom brick_geom(int by_shape, int Y, int Z, int nx, dim3 &grid, int &n_bricks) {
     BrickGeom g;
-    g.nzg = (Z + 4 * kBrZ - 1) / (4 * kBrZ);
-    g.nyb = (Y + kBrY - 1) / kBrY;
-    const int nxb = (nx + kBrX - 1) / kBrX;
-    g.nxb = nxb;
-    // launch order of the workgroups: measured at 512^3 (profiles/r2_k1_experiments.txt) y-fastest beats z-fastest by 3-10 %
-    // (which HBM channels the workgroups in flight hit together), an XCD-contiguous order loses 20 %
-    g.order = getenv("DFH_K1_ORDER") ? atoi(getenv("DFH_K1_ORDER")) : 1;
-    if (g.order == 2 && ((long)g.nzg * g.nyb * nxb) % 8 != 0) g.order = 0;     // the XCD split needs whole eighths
-    grid = dim3((unsigned)(g.nzg * g.nyb), (unsigned)nxb);
-    n_bricks = g.nzg * g.nyb * nxb * 4;
+    const int bz_len = 256 / (kBrX * by_shape);
+    g.nbz = (Z + bz_len - 1) / bz_len;
+    g.nyb = (Y + by_shape - 1) / by_shape;
+    g.nxb = (nx + kBrX - 1) / kBrX;
+    const int per_col = (g.nbz + 3) / 4;                   // bricks per wave if one workgroup took the whole column
+    int nzi = per_col < kMaxColumnBricks ? per_col : kMaxColumnBricks;
+    while (nzi > 1 && (long)g.nyb * g.nxb * ((per_col + nzi - 1) / nzi) < 8192) nzi = (nzi + 1) / 2;
+    if (opt().k1_nzi > 0) nzi = (int)(opt().k1_nzi < kMaxColumnBricks ? opt().k1_nzi : kMaxColumnBricks);
+    g.nzi = nzi;
+    g.nzc = (per_col + nzi - 1) / nzi;
+    grid = dim3((unsigned)g.nyb, (unsigned)g.nzc, (unsigned)g.nxb);
+    n_bricks = g.nbz * g.nyb * g.nxb;
     return g;
 }
 
+// Non-temporal T / w accesses (the bricks' 128-byte segments make every line one instruction's): only when the slab (T and w, 8 B per voxel) does not fit
+// the 256 MiB Infinity Cache -- at 256^3 (134 MB, cache resident from sweep to sweep) they cost 15 %, at 512^3 they gain 6-9 %
+// (profiles/r3_k1_experiments.txt).  Option k1_nt = 0 / 1 forces them off / on.
+static bool use_nt(size_t slab_voxels) {
+    if (opt().k1_nt >= 0) return opt().k1_nt != 0;
+    return slab_voxels * 8 > ((size_t)256 << 20);
+}
+
 static size_t pyr_bytes(int n_views, int H, int W) { return (size_t)n_views * pyramid_floats(H, W, nullptr, nullptr, nullptr) * sizeof(float); }
+
+}  // namespace dfh
+
+namespace dfh {
+
+// Which sweep a single-view call takes (dfh_integrate_depth_path reports it; bench.py counts the bytes of that sweep).
+//   rows: slabs up to half of 256^3 (kEarlyRowsMaxVoxels; with early loads) and everything the fast path cannot take;
+//   columns: the 4 x 2 x 32 brick column walk over every brick -- slabs that fit the 256 MiB Infinity Cache (256^3: 134 MB) are
+//     swept whole in less time than the two culling launches (pyramid ~5 us, classification ~8 us) save: 36-40 us unculled, 40
+//     culled, 42-46 rows;
+//   columns, culled: larger slabs (512^3: 240-250 us against 330 unculled, 410-425 rows).
+// Options k1_no_bricks, k1_bricks_min (in 256-voxel bricks), k1_cull = 0 / 1, k1_bricks_nocull override.  (Classification
+// inside the sweep's waves -- eight lanes per brick -- was built and measured slower than the pass at both sizes: its pyramid
+// look-up is a memory round trip at the start of every wave, profiles/r3_k1_experiments.txt.)
+static int single_view_path(int vol_dtype, const int res[3], int x0, int x1, bool fast_ok, bool vec4, bool have_ws) {
+    if (vol_dtype != DFH_F32 || !fast_ok) return DFH_K1_PATH_EXACT;
+    const long slab_voxels = (long)(x1 - x0) * res[1] * res[2];
+    const long bricks_min = opt().k1_bricks_min >= 0 ? opt().k1_bricks_min : kEarlyRowsMaxVoxels / 256 + 1;
+    const long slab_bricks = (long)((res[1] + 3) / 4) * ((res[2] + 15) / 16) * ((x1 - x0 + kBrX - 1) / kBrX);
+    if (vec4 && !on(opt().k1_no_bricks) && slab_bricks >= bricks_min) {
+        const bool want_cull = !on(opt().k1_bricks_nocull) && (opt().k1_cull >= 0 ? opt().k1_cull != 0 : (size_t)slab_voxels * 8 > ((size_t)256 << 20));
+        if (!want_cull) return DFH_K1_PATH_COLUMNS;
+        if (have_ws) return DFH_K1_PATH_COLUMNS_CULLED;
+    }
+    return DFH_K1_PATH_ROWS;
+}
 
 }  // namespace dfh
 
@@ -960,8 +1071,16 @@ extern "C" size_t dfh_integrate_workspace_bytes(int n_views, int H, int W, const
     if (n_views <= 0 || H < 2 || W < 2 || !res || res[1] <= 0 || res[2] <= 0 || x1 < x0) return 0;
     dim3 grid;
     int n_bricks = 0;
-    dfh::brick_geom(res[1], res[2], x1 - x0, grid, n_bricks);
+    dfh::brick_geom(dfh::kBrY, res[1], res[2], x1 - x0, grid, n_bricks);
     return dfh::params_bytes(n_views) + dfh::pyr_bytes(n_views, H, W) + ((size_t)n_bricks * sizeof(unsigned short) + 15) / 16 * 16;
+}
+
+extern "C" int dfh_integrate_depth_path(int vol_dtype, const int res[3], int x0, int x1, int H, int W, int have_workspace) {
+    using namespace dfh;
+    DFH_REQUIRE(res && res[0] > 0 && res[1] > 0 && res[2] > 0 && 0 <= x0 && x0 <= x1 && x1 <= res[0], "dfh_integrate_depth_path: bad grid or slab");
+    const bool fast_ok = H <= kFastMaxDim && W <= kFastMaxDim;
+    const bool vec4 = res[2] % 4 == 0 && !on(opt().k1_force_scalar);
+    return single_view_path(vol_dtype, res, x0, x1, fast_ok, vec4, have_workspace != 0);
 }
 
 extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3],
@@ -983,44 +1102,44 @@ extern "C" int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, cons
     IntegrateParams p;
     const size_t esz = vol_dtype == DFH_F32 ? 4 : 8;
     const bool vec4 = (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) && ((uintptr_t)tsdf_w % (4 * esz) == 0) &&
-                      !getenv("DFH_FORCE_SCALAR");
+                      !on(opt().k1_force_scalar);
     const bool pinhole = fill_params(p, res, tsdf_res, x0, x1, H, W, K, Kinv, lw, scale, center, tdist, wmax, vec4);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // fixed-point pixel coordinates need (dim-1) << 20 to fit in int32
     const bool fast_ok = H <= kFastMaxDim && W <= kFastMaxDim && scale > 0.0 && tdist > 0.0;
 
-    // brick sweep + culling: float32 volumes on the fast path, with a workspace for the depth pyramid and the brick masks
-    // For ONE view the brick sweep costs two small launches more (pyramid, classification) and pays off on large slabs only:
-    // 512^3 337-350 us against 360-394 us for the row sweep (a view that updates nothing: 73 against 233 us), 256^3 48-51
-    // against 43.5 us (profiles/r2_k1_experiments.txt).  Smaller slabs keep the row sweep; DFH_K1_BRICKS_MIN overrides.
     const bool have_ws = workspace && workspace_bytes >= dfh_integrate_workspace_bytes(1, H, W, res, x0, x1);
-    const long bricks_min = getenv("DFH_K1_BRICKS_MIN") ? atol(getenv("DFH_K1_BRICKS_MIN")) : 131072;
-    const long slab_bricks = (long)((res[1] + kBrY - 1) / kBrY) * ((res[2] + 4 * kBrZ - 1) / (4 * kBrZ)) * ((x1 - x0 + kBrX - 1) / kBrX) * 4;
-    const bool bricks = vol_dtype == DFH_F32 && fast_ok && vec4 && !getenv("DFH_K1_NO_BRICKS") && slab_bricks >= bricks_min &&
-                        (have_ws || getenv("DFH_K1_BRICKS_NOCULL"));
-    if (bricks) {
-        const bool cull = have_ws && !getenv("DFH_K1_BRICKS_NOCULL");
+    const int path = single_view_path(vol_dtype, res, x0, x1, fast_ok, vec4, have_ws);
+    if (path == DFH_K1_PATH_COLUMNS || path == DFH_K1_PATH_COLUMNS_CULLED) {
+        const bool cull = path == DFH_K1_PATH_COLUMNS_CULLED;
         dim3 grid;
         int n_bricks = 0;
-        const BrickGeom g = brick_geom(p.Y, p.Z, p.nx, grid, n_bricks);
+        const BrickGeom g = brick_geom(kBrY, p.Y, p.Z, p.nx, grid, n_bricks);
         unsigned short *mask = nullptr;
         if (cull) {
             p.cull = 1;
             attach_pyramid(p, workspace, 1, 0, H, W);
-            mask = reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + params_bytes(1) + pyr_bytes(1, H, W));
             const void *dptr[1] = {depth};
             const int rc = depth_dtype == DFH_F32 ? launch_pyramids<float>(dptr, 1, H, W, &p, s) : launch_pyramids<double>(dptr, 1, H, W, &p, s);
             if (rc != DFH_OK) return rc;
+            mask = reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + params_bytes(1) + pyr_bytes(1, H, W));
             const dim3 cgrid((unsigned)((n_bricks + 255) / 256));
-            if (pinhole) hipLaunchKernelGGL((brick_classify_kernel<true, true>), cgrid, dim3(256), 0, s, nullptr, p, 1, g, n_bricks, mask);
-            else hipLaunchKernelGGL((brick_classify_kernel<false, true>), cgrid, dim3(256), 0, s, nullptr, p, 1, g, n_bricks, mask);
+#define DFH_CLASSIFY(PH, BY) hipLaunchKernelGGL((brick_classify_kernel<PH, true, BY>), cgrid, dim3(256), 0, s, nullptr, p, 1, g, n_bricks, mask)
+            if (pinhole) DFH_CLASSIFY(true, kBrY); else DFH_CLASSIFY(false, kBrY);
+#undef DFH_CLASSIFY
         }
-        const bool early = !getenv("DFH_K1_LATE_LOADS");
-#define DFH_BRICK(DT, PH) do { if (early) hipLaunchKernelGGL((integrate_depth_brick_kernel<DT, PH, true>), grid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const DT *)depth, p, g, mask); \
-                               else hipLaunchKernelGGL((integrate_depth_brick_kernel<DT, PH, false>), grid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const DT *)depth, p, g, mask); } while (0)
-        if (depth_dtype == DFH_F32) { if (pinhole) DFH_BRICK(float, true); else DFH_BRICK(float, false); }
-        else { if (pinhole) DFH_BRICK(double, true); else DFH_BRICK(double, false); }
-#undef DFH_BRICK
+        // T / w of the wave's next brick requested one brick ahead: culled sweeps of large slabs gain 3 % on views that update
+        // everything (373 against 384 us at 512^3), cache-resident slabs lose 5-10 % (80 against 70 VGPRs); k1_prefetch forces
+        const bool prefetch = opt().k1_prefetch >= 0 ? opt().k1_prefetch != 0 : cull;
+        const bool nt = use_nt((size_t)p.nx * p.Y * p.Z);
+#define DFH_COL(DT, PH, BY, PF, NT) hipLaunchKernelGGL((integrate_depth_column_kernel<DT, PH, BY, PF, NT>), grid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const DT *)depth, p, g, mask)
+#define DFH_COL_PF(DT, PH, BY, NT) do { if (prefetch) DFH_COL(DT, PH, BY, true, NT); else DFH_COL(DT, PH, BY, false, NT); } while (0)
+#define DFH_COL_SHAPE(DT, PH) do { if (nt) DFH_COL_PF(DT, PH, kBrY, true); else DFH_COL_PF(DT, PH, kBrY, false); } while (0)
+        if (depth_dtype == DFH_F32) { if (pinhole) DFH_COL_SHAPE(float, true); else DFH_COL_SHAPE(float, false); }
+        else { if (pinhole) DFH_COL_SHAPE(double, true); else DFH_COL_SHAPE(double, false); }
+#undef DFH_COL_SHAPE
+#undef DFH_COL_PF
+#undef DFH_COL
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }
@@ -1076,9 +1195,9 @@ static int integrate_multi_impl(void *tsdf, void *tsdf_w, int vol_dtype, const i
     DFH_REQUIRE(depth_dtype == DFH_F32 || depth_dtype == DFH_F64, "dfh_integrate_depth_multi: bad depth_dtype %d", depth_dtype);
     const size_t esz = vol_dtype == DFH_F32 ? 4 : 8;
     const bool vec4 = res[0] > 0 && res[1] > 0 && res[2] > 0 && (res[2] % 4 == 0) && ((uintptr_t)tsdf % (4 * esz) == 0) &&
-                      ((uintptr_t)tsdf_w % (4 * esz) == 0) && !getenv("DFH_FORCE_SCALAR");
+                      ((uintptr_t)tsdf_w % (4 * esz) == 0) && !on(opt().k1_force_scalar);
     const bool fast_ok = vol_dtype == DFH_F32 && H <= kFastMaxDim && W <= kFastMaxDim && scale > 0.0 && tdist > 0.0 &&
-                         workspace && workspace_bytes >= dfh_integrate_multi_workspace_bytes(n_views) && !getenv("DFH_K1_NO_MULTI");
+                         workspace && workspace_bytes >= dfh_integrate_multi_workspace_bytes(n_views) && !on(opt().k1_no_multi);
     if (!fast_ok || n_views == 1 || x1 <= x0) {
         // one sweep per view: the same results (every argument is checked there)
         if (fresh) {
@@ -1100,8 +1219,9 @@ static int integrate_multi_impl(void *tsdf, void *tsdf_w, int vol_dtype, const i
     ViewPtrs vp;
     bool pinhole = true;
     const bool have_pyr = workspace_bytes >= dfh_integrate_workspace_bytes(n_views, H, W, res, x0, x1);
-    const bool bricks = vec4 && !getenv("DFH_K1_NO_BRICKS") && (have_pyr || getenv("DFH_K1_BRICKS_NOCULL"));
-    const bool cull = bricks && have_pyr && !getenv("DFH_K1_BRICKS_NOCULL");
+    const bool nocull = on(opt().k1_bricks_nocull);
+    const bool bricks = vec4 && !on(opt().k1_no_bricks) && (have_pyr || nocull);
+    const bool cull = bricks && have_pyr && !nocull;
     for (int v = 0; v < n_views; ++v) {
         pinhole = fill_params(hp[v], res, tsdf_res, x0, x1, H, W, K, Kinv, lw + 12 * v, scale, center, tdist, wmax, vec4) && pinhole;
         vp.depth[v] = depth[v];
@@ -1123,22 +1243,26 @@ static int integrate_multi_impl(void *tsdf, void *tsdf_w, int vol_dtype, const i
     if (bricks) {
         dim3 bgrid;
         int n_bricks = 0;
-        const BrickGeom g = brick_geom(p.Y, p.Z, p.nx, bgrid, n_bricks);
+        const BrickGeom g = brick_geom(kBrY, p.Y, p.Z, p.nx, bgrid, n_bricks);
         unsigned short *mask = nullptr;
         if (cull) {
             mask = reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + params_bytes(n_views) + pyr_bytes(n_views, H, W));
             const int rc = depth_dtype == DFH_F32 ? launch_pyramids<float>(depth, n_views, H, W, hp, s) : launch_pyramids<double>(depth, n_views, H, W, hp, s);
             if (rc != DFH_OK) return rc;
             const dim3 cgrid((unsigned)((n_bricks + 255) / 256));
-            if (pinhole) hipLaunchKernelGGL((brick_classify_kernel<true, false>), cgrid, dim3(256), 0, s, dv, p, n_views, g, n_bricks, mask);
-            else hipLaunchKernelGGL((brick_classify_kernel<false, false>), cgrid, dim3(256), 0, s, dv, p, n_views, g, n_bricks, mask);
+#define DFH_CLASSIFY(PH, BY) hipLaunchKernelGGL((brick_classify_kernel<PH, false, BY>), cgrid, dim3(256), 0, s, dv, p, n_views, g, n_bricks, mask)
+            if (pinhole) DFH_CLASSIFY(true, kBrY); else DFH_CLASSIFY(false, kBrY);
+#undef DFH_CLASSIFY
         }
-#define DFH_MBRICK(DT, PH, FR) hipLaunchKernelGGL((integrate_depth_multi_brick_kernel<DT, PH, FR>), bgrid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, dv, vp, g, mask, (float)fresh_value)
-#define DFH_MBRICK2(DT, PH) do { if (fresh) DFH_MBRICK(DT, PH, true); else DFH_MBRICK(DT, PH, false); } while (0)
-        if (depth_dtype == DFH_F32) { if (pinhole) DFH_MBRICK2(float, true); else DFH_MBRICK2(float, false); }
-        else { if (pinhole) DFH_MBRICK2(double, true); else DFH_MBRICK2(double, false); }
-#undef DFH_MBRICK2
-#undef DFH_MBRICK
+        const bool nt = use_nt((size_t)p.nx * p.Y * p.Z);
+#define DFH_MCOL(DT, PH, BY, FR, NT) hipLaunchKernelGGL((integrate_depth_multi_column_kernel<DT, PH, BY, FR, NT>), bgrid, dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, dv, vp, g, mask, (float)fresh_value)
+#define DFH_MCOL_FR(DT, PH, BY, NT) do { if (fresh) DFH_MCOL(DT, PH, BY, true, NT); else DFH_MCOL(DT, PH, BY, false, NT); } while (0)
+#define DFH_MCOL_SHAPE(DT, PH) do { if (nt) DFH_MCOL_FR(DT, PH, kBrY, true); else DFH_MCOL_FR(DT, PH, kBrY, false); } while (0)
+        if (depth_dtype == DFH_F32) { if (pinhole) DFH_MCOL_SHAPE(float, true); else DFH_MCOL_SHAPE(float, false); }
+        else { if (pinhole) DFH_MCOL_SHAPE(double, true); else DFH_MCOL_SHAPE(double, false); }
+#undef DFH_MCOL_SHAPE
+#undef DFH_MCOL_FR
+#undef DFH_MCOL
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }

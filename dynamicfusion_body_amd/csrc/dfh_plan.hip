@@ -416,7 +416,7 @@ int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const
     const int n_tiles = (n_samples + kPlanTile - 1) / kPlanTile;
     DFH_HIP_CHECK(hipMemsetAsync(unc_ws, 0, sizeof(int), s));
     hipLaunchKernelGGL(plan_runid_kernel, dim3(n_tiles), dim3(256), 0, s, nbr, n_samples, knn, tile_off, run_id, row_first);
-    if (getenv("DFH_PLAN_RADIX")) {              // the lists through two stable device radix sorts (round 2, first half): kept for A/B
+    if (on(opt().plan_radix)) {              // the lists through two stable device radix sorts (round 2, first half): kept for A/B
         hipLaunchKernelGGL(plan_zero2_kernel, dim3((unsigned)((n_blocks + n_nodes + 2 + 255) / 256)), dim3(256), 0, s, blk_ptr, n_blocks + 1,
                            node_ptr, n_nodes + 1);
         hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, row_first, n_rows, knn, row_ptr, col,

@@ -2269,7 +2269,7 @@ int dfh_gn_build_rigid(const double *verts, const double *normals, const double 
     // per-workgroup sums in stream-ordered scratch, added in a fixed order by a second launch: the same bits every run.
     // (No scratch -- allocation refused, e.g. inside a stream capture without pool support: atomics, last bits may vary.)
     double *partial = nullptr;
-    if (getenv("DFH_RIGID_ATOMIC") || hipMallocAsync(reinterpret_cast<void **>(&partial), sizeof(double) * 29 * (size_t)blocks, s) != hipSuccess) {
+    if (on(opt().rigid_atomic) || hipMallocAsync(reinterpret_cast<void **>(&partial), sizeof(double) * 29 * (size_t)blocks, s) != hipSuccess) {
         (void)hipGetLastError();
         partial = nullptr;
     }
@@ -2458,7 +2458,7 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = (n_samples + kTile - 1) / kTile;
     // planned build: the regulariser's pair rows ride along in the data-row launch (they only write partial_reg)
-    const bool reg_in_data_launch = planned_reg && node_nbr && rw != 0.0 && n_samples > 0 && !getenv("DFH_GN_REG_OWN_LAUNCH");
+    const bool reg_in_data_launch = planned_reg && node_nbr && rw != 0.0 && n_samples > 0 && !on(opt().gn_reg_own_launch);
     double *tile_cost = planned && partial ? partial + (size_t)n_rows * gn_row_stride(knn) : nullptr;   // 2 doubles per tile, behind the rows; then one live flag per row
     if (planned) {
         // every block / rhs entry / cost is written by the gather, and every row of `partial` by the tile pass (rows
@@ -2508,10 +2508,10 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
 #undef DFH_BUILD
         DFH_HIP_CHECK(hipGetLastError());
     }
-    const int dbg_part = getenv("DFH_DBG_GATHER_PART") ? atoi(getenv("DFH_DBG_GATHER_PART")) : 0;
+    const int dbg_part = opt().dbg_gather_part > 0 ? (int)opt().dbg_gather_part : 0;
     // the regulariser's lists ride along in the data rows' gather when its rows were built in the data-row launch
     RegLists rl = {};
-    const bool reg_in_gather = reg_in_data_launch && !getenv("DFH_GN_REG_OWN_GATHER");
+    const bool reg_in_gather = reg_in_data_launch && !on(opt().gn_reg_own_gather);
     if (reg_in_gather) {
         rl.partial = partial_reg; rl.blk_ptr = rblk_ptr; rl.blk_ent = rblk_ent; rl.node_ptr = rnode_ptr; rl.node_ent = rnode_ent;
         rl.n_rows = n_nodes * knn;
@@ -2724,16 +2724,15 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
     PcgParams p{n_nodes, lm_abs, lm_rel};
     dim3 grid((n_nodes + 255) / 256), block(256);
     // One persistent launch when every row can have its own co-resident wave (N <= 16 waves x #CUs / 2)
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        DFH_HIP_CHECK(hipGetDevice(&dev));
-        DFH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int dev = 0;
+    DFH_HIP_CHECK(hipGetDevice(&dev));
+    DeviceInfo &di = device_info(dev);              // per DEVICE: a process may drive several
+    if (di.n_cu == 0) DFH_HIP_CHECK(hipDeviceGetAttribute(&di.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int n_cu = di.n_cu;
     // Workgroups of 8 waves (one row each) as long as they fit one per CU, of 16 beyond.  Measured at 2 048 rows (tools/kbench_pcg.py):
     // 256 workgroups x 8 waves 55 us per 10-iteration solve (slope 4.3 us, prologue 14.5), 128 x 16 waves 90 us (6.4 / 27.3).
     int wpb = (n_nodes + 7) / 8 <= n_cu ? 8 : 16;
-    if (const char *e = getenv("DFH_PCG_WPB")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) wpb = v; }
+    { const long v = opt().pcg_wpb; if (v == 4 || v == 8 || v == 16) wpb = (int)v; }
     const int nblk = (n_nodes + wpb - 1) / wpb;
     // Persistent path only when its grid barrier cannot starve: (1) the occupancy query says a workgroup of this size
     // fits on a CU, (2) the grid has at most one workgroup per CU (other kernels of this process may hold CUs for a while: they
@@ -2742,11 +2741,10 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
     // (3) the caller has not declared co-residency unsafe (dfh_pcg_set_mode(2): several processes time-sharing one GPU),
     // (4) the abort counter exists (it cannot be allocated while the stream is being captured).  Otherwise: two launches
     // per iteration, no spinning.
-    bool persistent = nblk <= n_cu && nblk <= kMaxPcgBlocks && dfh::g_pcg_mode != 2 && !getenv("DFH_PCG_MULTILAUNCH");
+    bool persistent = nblk <= n_cu && nblk <= kMaxPcgBlocks && dfh::g_pcg_mode != 2 && !on(opt().pcg_multilaunch);
     unsigned long long *abort_count = nullptr;
     if (persistent) {
-        static int occ512 = -1, occ1024 = -1;
-        int &occ = wpb <= 8 ? occ512 : occ1024;
+        int &occ = wpb <= 8 ? di.pcg_occ512 : di.pcg_occ1024;
         if (occ < 0) {
             int nb = 0;
             const hipError_t e = wpb <= 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcg_cg1_kernel<512>, 64 * 8, 0)
@@ -2756,8 +2754,6 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
         persistent = occ >= 1;
     }
     if (persistent) {
-        int dev = 0;
-        DFH_HIP_CHECK(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && g_abort_count[dev]) {
             abort_count = g_abort_count[dev];
         } else {
@@ -2773,8 +2769,6 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
     }
     unsigned *abort_host = nullptr;
     if (persistent) {
-        int dev = 0;
-        DFH_HIP_CHECK(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && g_abort_host[dev] &&
             hipHostGetDevicePointer(reinterpret_cast<void **>(&abort_host), g_abort_host[dev], 0) != hipSuccess) {
             (void)hipGetLastError();
@@ -2782,7 +2776,7 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
         }
         if (!precleared) DFH_HIP_CHECK(hipMemsetAsync(scal, 0, sizeof(double) * (n_scal + 12 * N6), s));
         unsigned spin_limit = kSpinLimit;
-        if (const char *e = getenv("DFH_PCG_SPIN_LIMIT")) spin_limit = (unsigned)strtoul(e, nullptr, 10);
+        if (opt().pcg_spin_limit >= 0) spin_limit = (unsigned)opt().pcg_spin_limit;
         unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
         double *part = scal + 3 * ((size_t)iters + 2);                                    // (2 per iteration + 1) reductions x nblk slots
         if (wpb <= 8)
@@ -2877,7 +2871,7 @@ int dfh_gn_iteration(const double *sample_pos, const double *sample_nrm, const i
     rc = gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
                        n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
                        blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream, &aa,
-                       getenv("DFH_GN_ITER_OWN_CLEAR") ? nullptr : zbegin, zcount, &zeroed);
+                       on(opt().gn_iter_own_clear) ? nullptr : zbegin, zcount, &zeroed);
     if (rc != DFH_OK) return rc;
     return pcg_solve_impl(row_ptr, col, vals, rhs, n_nodes, pcg_iters, lm_abs, lm_rel, x_out, pcg_workspace, pcg_workspace_bytes, node_dq,
                           step, stream, zeroed);

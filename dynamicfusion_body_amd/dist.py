@@ -111,13 +111,45 @@ def halo_planes(local, n_planes):
     return lo, hi
 
 
+def collective_device(device=None):
+    """The device small host-side values travel on: RCCL ("nccl") moves GPU tensors only, gloo moves CPU ones (and GPU
+    ones through a host copy).  `device` overrides (tests rehearse the GPU plumbing over gloo)."""
+    if device is not None:
+        return torch.device(device)
+    return torch.device("cuda" if (dist.get_backend() == "nccl" and torch.cuda.is_available()) else "cpu")
+
+
+def gather_rows(rows, device=None):
+    """Concatenation over ranks, in rank order, of per-rank (n_r, C) float64 numpy arrays (n_r differs from rank to rank):
+    every rank gets the same (sum n_r, C) array.  Sizes, padded buffers and outputs all live on ONE device chosen once
+    (`collective_device`), so the same code runs over RCCL and over gloo."""
+    import numpy as np
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    if rows.ndim != 2:
+        raise ValueError("gather_rows expects a 2-D array, got shape %s" % (rows.shape,))
+    _, ws = world()
+    if ws == 1:
+        return rows
+    dev = collective_device(device)
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s_) for s_ in sizes]
+    m = max(1, max(sizes))
+    buf = torch.zeros((m, rows.shape[1]), dtype=torch.float64, device=dev)
+    if rows.shape[0]:
+        buf[:rows.shape[0]] = torch.from_numpy(rows).to(dev)
+    parts = [torch.empty_like(buf) for _ in range(ws)]
+    dist.all_gather(parts, buf)
+    return np.concatenate([p_[:n_].cpu().numpy() for p_, n_ in zip(parts, sizes)])
+
+
 def all_ranks(flag):
     """True iff `flag` is true on every rank (one tiny all-reduce; ranks must take collective decisions alike)."""
     _, ws = world()
     if ws == 1:
         return bool(flag)
-    dev = "cuda" if (dist.get_backend() == "nccl" and torch.cuda.is_available()) else "cpu"
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=collective_device())
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(int(t[0]))
 
@@ -135,7 +167,6 @@ def max_over_ranks(values):
     _, ws = world()
     if ws == 1:
         return list(values)
-    dev = "cuda" if (dist.get_backend() == "nccl" and torch.cuda.is_available()) else "cpu"
-    t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    t = torch.tensor(list(values), dtype=torch.float64, device=collective_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t]

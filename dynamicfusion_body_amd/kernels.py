@@ -48,6 +48,37 @@ def integrate_workspace(n_views, H, W, res, x_range=None, device=None):
     return ws
 
 
+K1_PATHS = {0: "exact", 1: "rows", 2: "columns", 3: "columns_culled"}       # include/dfusion_hip.h: DFH_K1_PATH_*
+BRICK = (4, 2, 32)                                                            # voxels of a brick of the column sweep (csrc/dfh_integrate.hip)
+
+
+def integrate_path(T, depth, res=None, x_range=None, workspace=True):
+    """Name of the sweep integrate_depth takes for this slab and depth map (dfh_integrate_depth_path; no launch)."""
+    lib = _lib.load()
+    if res is None:
+        res = tuple(T.shape)
+    if x_range is None:
+        x_range = (0, res[0])
+    H, W = depth.shape
+    code = lib.dfh_integrate_depth_path(dtype_code(T), _lib.iarr(res), int(x_range[0]), int(x_range[1]), int(H), int(W), 1 if workspace else 0)
+    if code < 0:
+        _lib.check(code, "dfh_integrate_depth_path")
+    return K1_PATHS[code]
+
+
+def brick_masks(workspace, res, x_range=None):
+    """The per-brick 16-bit view masks the last culled sweep through `workspace` left behind (bit v = view v may update a voxel
+    of the brick), as a (bricks_x, bricks_y, bricks_z) int16 view: the LAST region of the workspace (include/dfusion_hip.h:
+    dfh_integrate_workspace_bytes).  Measurement code counts surviving bricks with it."""
+    if x_range is None:
+        x_range = (0, res[0])
+    nb = (-(-(int(x_range[1]) - int(x_range[0])) // BRICK[0]), -(-int(res[1]) // BRICK[1]), -(-int(res[2]) // BRICK[2]))
+    n = nb[0] * nb[1] * nb[2]
+    raw = workspace.view(torch.int16)
+    tail = (2 * n + 15) // 16 * 8                       # the mask region is padded to whole 16-byte units
+    return raw[raw.numel() - tail:raw.numel() - tail + n].view(nb)
+
+
 def integrate_depth(T, Wt, depth, K, Kinv, lw, scale, center, tdist, wmax=100.0, tsdf_res=None,
                     res=None, x_range=None, workspace=None):
     """K1 = FusionDM.fuseDepths (reference core/fusion_dm.py:180-217) on device tensors.

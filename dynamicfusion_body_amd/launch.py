@@ -19,18 +19,22 @@ def under_launcher():
 
 
 def free_port():
+    """A port that was free a moment ago (the socket is closed before the ranks bind it: a small race that a second
+    job on the same host could win; the rendezvous then fails loudly and the caller retries)."""
     s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     return port
 
 
-def spawn_ranks(argv, n_ranks, timeout=None, extra_env=None, json_only=False):
+def spawn_ranks(argv, n_ranks, timeout=None, extra_env=None, json_only=False, grace=10.0):
     """Run `python argv...` as n_ranks processes (rank r gets RANK = LOCAL_RANK = r) and wait for all of them.
     Rank 0's stdout is passed through (that is where the one JSON line goes); the other ranks' stdout is dropped,
-    every rank's stderr is passed through.  Returns the largest exit code.  If one rank fails the others are
-    terminated (they would otherwise wait in a collective for ever).  json_only: of rank 0's stdout only lines that
+    every rank's stderr is passed through.  Returns the largest exit code.  If one rank fails the others get `grace`
+    seconds to leave by themselves, are then terminated and, another `grace` later, killed (they would otherwise wait in
+    a collective for ever); after `timeout` seconds everything still running is killed and reaped (124).  json_only: of rank 0's stdout only lines that
     start with "{" go to stdout, the rest (e.g. gloo's connection banner) to stderr -- one clean JSON line for a parser."""
     if n_ranks < 1:
         raise ValueError("n_ranks must be >= 1")
@@ -64,6 +68,16 @@ def spawn_ranks(argv, n_ranks, timeout=None, extra_env=None, json_only=False):
     t0 = time.time()
     rc = 0
     alive = list(procs)
+    first_failure = None                                  # when the first rank left with a non-zero code
+    terminated = None                                     # when the survivors were sent SIGTERM
+
+    def reap(ps, how):
+        for q in ps:
+            try:
+                how(q)
+            except OSError:
+                pass
+
     while alive:
         for p in list(alive):
             code = p.poll()
@@ -71,11 +85,25 @@ def spawn_ranks(argv, n_ranks, timeout=None, extra_env=None, json_only=False):
                 alive.remove(p)
                 if code != 0:
                     rc = max(rc, code if code > 0 else 1)
-                    for q in alive:                           # exact PIDs we started, nothing by pattern
-                        q.terminate()
-        if timeout is not None and time.time() - t0 > timeout:
-            for q in alive:
-                q.kill()
+                    if first_failure is None:
+                        first_failure = time.time()
+        now = time.time()
+        # after a failure the other ranks get `grace` seconds to notice and leave on their own (bench.py's ranks learn it from
+        # the store and rank 0 still prints its line), then SIGTERM, then -- a rank stuck in a driver call ignores that -- SIGKILL;
+        # only the exact processes started here are touched
+        if first_failure is not None and alive:
+            if terminated is None and now - first_failure > grace:
+                reap(alive, lambda q: q.terminate())
+                terminated = now
+            elif terminated is not None and now - terminated > grace:
+                reap(alive, lambda q: q.kill())
+        if timeout is not None and now - t0 > timeout:
+            reap(alive, lambda q: q.kill())
+            for q in alive:                               # no zombies
+                try:
+                    q.wait(timeout=10)
+                except Exception:
+                    pass
             return 124
         time.sleep(0.05)
     if relay is not None:

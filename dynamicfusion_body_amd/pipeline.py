@@ -183,20 +183,8 @@ class SlabFrame:
         pts = sv.spos if sv.S > 0 else torch.zeros((0, 3), dtype=torch.float64, device="cuda")
         gather = None
         if self.ws > 1:
-            import torch.distributed as dist
-
-            def gather(uns):
-                n = torch.tensor([uns.shape[0]], dtype=torch.int64)
-                sizes = [torch.zeros_like(n) for _ in range(self.ws)]
-                dist.all_gather(sizes, n if dist.get_backend() != "nccl" else n.cuda())
-                m = max(1, int(max(int(s_) for s_ in sizes)))
-                buf = torch.zeros((m, 3), dtype=torch.float64)
-                buf[:uns.shape[0]] = torch.from_numpy(uns.reshape(-1, 3))
-                if dist.get_backend() == "nccl":
-                    buf = buf.cuda()
-                parts = [torch.zeros_like(buf) for _ in range(self.ws)]
-                dist.all_gather(parts, buf)
-                return np.concatenate([p_[:int(n_)].cpu().numpy() for p_, n_ in zip(parts, sizes)])
+            def gather(uns):                             # (ragged all-gather on one device: dist.gather_rows)
+                return self.D.gather_rows(np.asarray(uns, dtype=np.float64).reshape(-1, 3))
         # the samples are stored sorted by node tuple; the greedy subsampling depends on the order of its input, so it is
         # fed in a canonical order (by position) that does not depend on the slab partition
         def canon(uns):

@@ -51,6 +51,15 @@ const char *dfh_last_error(void);
 /* Blocks until `stream` has drained (hipStreamSynchronize). */
 int dfh_stream_synchronize(void *stream);
 
+/* Development switches of the library (A/B experiments, tests that force a fall-back path).  They are NOT read from the
+ * environment on the call paths: the table is filled once, at the first call into the library, from the single environment
+ * variable DFH_OPTIONS="name=value,name=value" and is changed afterwards only through dfh_set_option().  Names are listed in
+ * tools/README.md (e.g. "k1_no_bricks", "pcg_multilaunch", "pcg_spin_limit"); a value of -1 means "unset / library default".
+ * dfh_set_option returns DFH_E_BADARG for an unknown name; dfh_get_option returns the current value (LONG_MIN if unknown).
+ * No reference counterpart (the reference has no tuning switches). */
+int dfh_set_option(const char *name, long value);
+long dfh_get_option(const char *name);
+
 /* A1  FusionDM.fuseDepths(dm, lw, tsdf, tsdf_w, scale, center, wmax)  core/fusion_dm.py:180-217
  * (CPU-path semantics; the OpenCL variant :600-737 is NOT what is reproduced).
  * For every voxel i=(x,y,z), x in [x0,x1):
@@ -74,6 +83,16 @@ int dfh_integrate_depth(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3
                         const double K[9], const double Kinv[9], const double lw[12],
                         double scale, const double center[3], double tdist, double wmax,
                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* Which sweep dfh_integrate_depth takes for float32 volumes of this slab and depth-map size (no launch): one of
+ * DFH_K1_PATH_*.  All of them produce the same volumes bit for bit; they differ in the bytes they move (measurement code
+ * counts those of the path taken).  have_workspace: a workspace of dfh_integrate_workspace_bytes(1, ...) bytes will be passed.
+ * No reference counterpart. */
+#define DFH_K1_PATH_EXACT 0          /* every voxel through the reference's fp64 chain (fp64 volumes, oversized depth maps) */
+#define DFH_K1_PATH_ROWS 1           /* one 1-KiB z run per wave; T, w loaded and stored for updated 16-byte packs only */
+#define DFH_K1_PATH_COLUMNS 2        /* 4 x 2 x 32 bricks, a wave walks a column of them; T, w of every pack loaded, updated packs stored */
+#define DFH_K1_PATH_COLUMNS_CULLED 3 /* the same behind a depth pyramid + brick classification: bricks no voxel of which can be updated are skipped */
+int dfh_integrate_depth_path(int vol_dtype, const int res[3], int x0, int x1, int H, int W, int have_workspace);
 
 /* The same for n_views depth maps in ONE sweep of the volume: what the reference's loops over fuseDepths do
  * (core/fusion_dm.py:152-154 initial fusion, :166-170 compute_live_tsdf), with every voxel's T and w read once, updated

@@ -22,3 +22,12 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _library_switches_do_not_leak():
+    """Development switches of the library (dfh_set_option) set by a test are unset again after it."""
+    yield
+    from dynamicfusion_body_amd import _lib
+    if _lib._options_touched:
+        _lib.reset_options()

@@ -75,6 +75,15 @@ def _worker(rank, ws, port, out):
             assert (lo is None) == (pa == 0) and (hi is None) == (pb == planes)
             assert lo is None or torch.equal(lo, vol[pa - 1])
             assert hi is None or torch.equal(hi, vol[pb])
+        # ragged rows (the unsupported surface points of update_graph): rank-ordered concatenation, empty contributions
+        import numpy as np
+        mine = [np.arange(15, dtype=np.float64).reshape(5, 3), np.zeros((0, 3))][rank]
+        allr = D.gather_rows(mine)
+        assert allr.shape == (5, 3) and np.array_equal(allr, np.arange(15, dtype=np.float64).reshape(5, 3))
+        mine = np.full((2 + 3 * rank, 3), float(rank))
+        allr = D.gather_rows(mine, device="cpu")                   # (the device choice is one argument: "cuda" under RCCL)
+        assert allr.shape == (7, 3) and (allr[:2] == 0).all() and (allr[2:] == 1).all()
+        assert D.collective_device().type == "cpu"                 # gloo
         try:
             D.allgather_planes(torch.zeros(1, 3, 2), 10)
             raise AssertionError("wrong slab size not rejected")

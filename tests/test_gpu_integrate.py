@@ -12,22 +12,23 @@ import pytest
 import torch
 
 from oracle import oracle_np as O
-from dynamicfusion_body_amd import FusionDM, kernels, scene
+from dynamicfusion_body_amd import FusionDM, _lib, kernels, scene
 
 pytestmark = pytest.mark.gpu
 
 F32_EPS = float(np.finfo(np.float32).eps)
 
 
-@pytest.fixture(autouse=True, params=["bricks", "rows"])
-def k1_path(request, monkeypatch):
-    """Every test of this file runs on both sweeps of float32 volumes: the default 4 x 4 x 16 brick sweep with conservative
-    culling (workspace with the depth pyramid) and the row sweep that projects every voxel (DFH_K1_NO_BRICKS)."""
+@pytest.fixture(autouse=True, params=["bricks", "bricks_nocull", "rows"])
+def k1_path(request):
+    """Every test of this file runs on the sweeps of float32 volumes: the 4 x 2 x 32 brick column walk with conservative
+    culling (depth pyramid + classification pass), the same walk over every brick (what mid-size slabs take), and the row sweep
+    that projects every voxel (option k1_no_bricks)."""
     if request.param == "rows":
-        monkeypatch.setenv("DFH_K1_NO_BRICKS", "1")
+        _lib.set_option("k1_no_bricks", 1)
     else:
-        monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
-        monkeypatch.setenv("DFH_K1_BRICKS_MIN", "0")          # (single views take the brick sweep on large slabs only)
+        _lib.set_option("k1_bricks_min", 0)          # (single views take the brick sweep on large slabs only)
+        _lib.set_option("k1_cull", 1 if request.param == "bricks" else 0)
     return request.param
 
 
@@ -212,7 +213,7 @@ def test_multi_view_sweep_many_views_and_errors():
 def test_fresh_live_volume_equals_fill_then_sweep(monkeypatch):
     """dfh_integrate_depth_multi_fresh (the fill of a live volume folded into the multi-view sweep, core/fusion_dm.py:152-153 +
     :166-170) against T.fill_(value); W.zero_(); dfh_integrate_depth_multi -- every voxel, bit for bit: brick sweep (every brick is
-    written, culled or not), a slab with global plane indices, the plain sweep (DFH_K1_NO_BRICKS), one view, no view, more
+    written, culled or not), a slab with global plane indices, the plain sweep (option k1_no_bricks), one view, no view, more
     than 16 views, a ragged grid and a float64 volume; the volumes start as garbage."""
     rng = np.random.default_rng(21)
     K = scene.intrinsics(150.3, 79.7, 59.6)
@@ -230,9 +231,9 @@ def test_fresh_live_volume_equals_fill_then_sweep(monkeypatch):
         grid = (R, res[1], res[2]) if x_range else res
         kw = dict(wmax=7.0, tsdf_res=R, res=grid, x_range=x_range or (0, res[0]))
         if no_bricks:
-            monkeypatch.setenv("DFH_K1_NO_BRICKS", "1")
+            _lib.set_option("k1_no_bricks", 1)
         else:
-            monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
+            _lib.set_option("k1_no_bricks", None)
         fill = tdist / scale
         Ta = torch.full(res, fill, dtype=dtype, device="cuda"); Wa = torch.zeros_like(Ta)
         kernels.integrate_depth_views(Ta, Wa, dms, K, Kinv, lws, scale, center, tdist, **kw)
@@ -241,7 +242,7 @@ def test_fresh_live_volume_equals_fill_then_sweep(monkeypatch):
         assert torch.equal(Ta, Tb) and torch.equal(Wa, Wb), (res, x_range, dtype, n_views, no_bricks)
         if n_views:
             assert int((Wa > 0).sum()) > 0 and int((Wa == 0).sum()) > 0
-    monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
+    _lib.set_option("k1_no_bricks", None)
 
 
 def test_slab_sweeps_equal_full_sweep():
@@ -429,10 +430,11 @@ def test_brick_culling_never_changes_a_voxel(k1_path, monkeypatch):
         outs = {}
         for path in ("bricks", "rows"):
             if path == "rows":
-                monkeypatch.setenv("DFH_K1_NO_BRICKS", "1")
+                _lib.set_option("k1_no_bricks", 1)
             else:
-                monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
-                monkeypatch.setenv("DFH_K1_BRICKS_MIN", "0")
+                _lib.set_option("k1_no_bricks", None)
+                _lib.set_option("k1_bricks_min", 0)
+                _lib.set_option("k1_cull", 1)
             T = torch.full(res, tdist / scale, dtype=torch.float32, device="cuda"); Wt = torch.zeros_like(T)
             Tm, Wm = T.clone(), Wt.clone()
             Tsl, Wsl = T.clone(), Wt.clone()
@@ -450,7 +452,7 @@ def test_brick_culling_never_changes_a_voxel(k1_path, monkeypatch):
         assert torch.equal(outs["bricks"][0], outs["rows"][0]) and torch.equal(outs["bricks"][1], outs["rows"][1])
         assert outs["bricks"][2] == outs["rows"][2]
         assert 0 < int((outs["rows"][1] > 0).sum()) < outs["rows"][1].numel()
-    monkeypatch.delenv("DFH_K1_NO_BRICKS", raising=False)
+    _lib.set_option("k1_no_bricks", None)
 
 
 def test_ocl_mode_matches_the_float32_restatement(k1_path):

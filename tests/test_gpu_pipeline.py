@@ -243,6 +243,8 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
         for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX", "DFH_GN_NO_FUSED_ITER"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setattr(HostScalar, "enabled", "NO_HOST_SCALARS" not in env)
+        from dynamicfusion_body_amd import _lib
+        _lib.set_option("plan_radix", 1 if "DFH_PLAN_RADIX" in env else None)        # (a switch of the library; the others are Python's)
         for k in env:
             if k.startswith("DFH_"):
                 monkeypatch.setenv(k, "1")

@@ -13,7 +13,7 @@ import torch
 
 from oracle import gn_np as G
 from oracle import oracle_np as O
-from dynamicfusion_body_amd import scene, solve
+from dynamicfusion_body_amd import _lib, scene, solve
 
 pytestmark = pytest.mark.gpu
 
@@ -178,14 +178,14 @@ def test_pcg_paths_agree_and_are_deterministic(golden, monkeypatch):
     runs = []
     for mode in ("persistent", "persistent", "multilaunch"):
         if mode == "multilaunch":
-            monkeypatch.setenv("DFH_PCG_MULTILAUNCH", "1")
+            _lib.set_option("pcg_multilaunch", 1)
         else:
-            monkeypatch.delenv("DFH_PCG_MULTILAUNCH", raising=False)
+            _lib.set_option("pcg_multilaunch", None)
         sv = make_solver(npos, ndq, nw, nbr, vidx, verts, norms, corr, nbr.shape[1], pcg_iters=12)
         sv.build(lw, rw)
         sv.solve_linear(0.5, 1e-3)
         runs.append((sv.dx.cpu().numpy().copy(), sv.vals.cpu().numpy().copy()))
-    monkeypatch.delenv("DFH_PCG_MULTILAUNCH", raising=False)
+    _lib.set_option("pcg_multilaunch", None)
     # the build uses fp64 atomics, so compare each solve against its own matrix only through the solution scale
     assert np.isfinite(runs[0][0]).all()
     assert np.abs(runs[0][0] - runs[2][0]).max() <= 1e-9 * np.abs(runs[2][0]).max()
@@ -200,13 +200,13 @@ def test_pcg_paths_agree_and_are_deterministic(golden, monkeypatch):
     sv.solve_linear(0.5, 1e-3)
     assert torch.equal(x1, sv.dx)
     # ... and through the two-launch path, five times (its dot products were atomic sums once: last bits differed run to run)
-    monkeypatch.setenv("DFH_PCG_MULTILAUNCH", "1")
+    _lib.set_option("pcg_multilaunch", 1)
     xs = []
     for _ in range(5):
         sv.vals.copy_(v0)
         sv.solve_linear(0.5, 1e-3)
         xs.append(sv.dx.clone())
-    monkeypatch.delenv("DFH_PCG_MULTILAUNCH", raising=False)
+    _lib.set_option("pcg_multilaunch", None)
     assert all(torch.equal(xs[0], x) for x in xs[1:])
     assert float((xs[0] - x1).abs().max()) <= 1e-9 * float(x1.abs().max())
 
@@ -221,9 +221,9 @@ def test_pcg_rows_wider_than_the_register_cache(multilaunch, monkeypatch):
     from dynamicfusion_body_amd.device import current_stream_ptr
     lib = _lib.load()
     if multilaunch:
-        monkeypatch.setenv("DFH_PCG_MULTILAUNCH", "1")
+        _lib.set_option("pcg_multilaunch", 1)
     else:
-        monkeypatch.delenv("DFH_PCG_MULTILAUNCH", raising=False)
+        _lib.set_option("pcg_multilaunch", None)
     rng = np.random.default_rng(11)
     N = 48
     adj = np.eye(N, dtype=bool)
@@ -281,7 +281,7 @@ def test_persistent_pcg_timeout_is_reported(golden, monkeypatch):
     """A grid barrier of the persistent PCG that does not complete within its spin bound makes every workgroup leave
     (x = NaN, node_dq untouched) -- and the host must hear about it: the next synchronising call raises DfhTimeout,
     the process then takes the multi-launch path, and the next solve is sound.  The time-out is forced with a spin
-    bound of 0 polls (DFH_PCG_SPIN_LIMIT), which no 2-workgroup barrier meets."""
+    bound of 0 polls (option pcg_spin_limit), which no 2-workgroup barrier meets."""
     from dynamicfusion_body_amd import _lib
     g, verts, norms, corr, nbr, vidx, npos, ndq, nw, lw, rw = load(golden)
     lib = _lib.load()
@@ -293,9 +293,9 @@ def test_persistent_pcg_timeout_is_reported(golden, monkeypatch):
         sv.check_status()                                                # nothing pending
         v0 = sv.vals.clone()
         dq0 = sv.node_dq.clone()
-        monkeypatch.setenv("DFH_PCG_SPIN_LIMIT", "0")
+        _lib.set_option("pcg_spin_limit", 0)
         sv.step(lw, rw, 0.5, 1e-3)                                       # build + PCG + twist update in one go
-        monkeypatch.delenv("DFH_PCG_SPIN_LIMIT")
+        _lib.set_option("pcg_spin_limit", None)
         with pytest.raises(_lib.DfhTimeout):
             sv.cost()
         assert torch.isnan(sv.dx).all() and torch.equal(sv.node_dq, dq0)  # no update was applied
@@ -305,9 +305,9 @@ def test_persistent_pcg_timeout_is_reported(golden, monkeypatch):
         # timed-out solve is still in flight or none has happened, raising once it has completed
         lib.dfh_pcg_set_mode(0)
         sv.vals.copy_(v0)
-        monkeypatch.setenv("DFH_PCG_SPIN_LIMIT", "0")
+        _lib.set_option("pcg_spin_limit", 0)
         sv.step(lw, rw, 0.5, 1e-3)
-        monkeypatch.delenv("DFH_PCG_SPIN_LIMIT")
+        _lib.set_option("pcg_spin_limit", None)
         torch.cuda.synchronize()
         with pytest.raises(_lib.DfhTimeout):
             sv.check_status(completed_only=True)
@@ -376,11 +376,11 @@ def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, mon
     sv.build(lw, rw)
     assert torch.equal(s1, sv.system)
     # the regulariser's rows / lists ride along in the data rows' launches; in launches of their own: the same bits
-    for switch in ("DFH_GN_REG_OWN_GATHER", "DFH_GN_REG_OWN_LAUNCH"):
-        monkeypatch.setenv(switch, "1")
+    for switch in ("gn_reg_own_gather", "gn_reg_own_launch"):
+        _lib.set_option(switch, 1)
         sv.build(lw, rw)
         assert torch.equal(s1, sv.system), switch
-        monkeypatch.delenv(switch)
+        _lib.set_option(switch, None)
     sv.build(lw, 0.0)                                   # without the regulariser rows
     s0 = sv.system.clone()
     monkeypatch.setenv("DFH_GN_ATOMIC", "1")

@@ -9,6 +9,8 @@
 #include "dfh_dq.h"
 
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 namespace dfh {
 
@@ -498,6 +500,486 @@ __global__ __launch_bounds__(256) void fuse_volume_dqb_kernel(VolT *__restrict__
     tsdf_w[off] = (VolT)(nw < p.wmax ? nw : p.wmax);                                                // :190
 }
 
+// ------------------------------------------------------------------------------------------
+// K3 fast path: float32 volumes, knn = 4 (round 3).
+// The exact kernel above spends ~350 fp64 operations per voxel on the reference's chain (8-norm with sqrt and a division, two
+// dual-quaternion sandwich products, the sampler, an IEEE division in the update) and -- with stored neighbourhoods -- reads
+// 48 B of cache per voxel (four 16-bit node indices, four fp64 blend weights, the fp64 integration weight): 3.7-4.0 x the
+// algorithmic bytes.  For float32 volumes only the DECISIONS have to be the reference's (which voxels are updated: bit-exact);
+// the values carry a float32 rounding anyway (bar: 2 n eps32 (1 + |T|)).  So:
+//   * dq_blend is invariant to a common scale of the weights: the cache keeps THREE weights normalised to sum 1 (fp64; the
+//     fourth is 1 - their sum) and the integration weight as float32: 28 B per voxel + the indices = 36 B instead of 48.
+//     (32-bit fixed-point weights -- 24 B in all -- were considered and rejected: their 2^-33 quantisation moves the warped
+//     point by ~1e-8 voxel, and x1 is rounded to float32 inside dqb_warp (core/util.py:69): the rounding decision of 0.1-5 %
+//     of the voxels would no longer provably be the reference's.)
+//   * the sandwich product is its closed form x' = (M(b) p + t(b)) / |b|_8^2 (M = r P r*, t = 2 vec(d r*)) with one
+//     corrected reciprocal; the second warp (m_lw, fixed) is an affine map folded on the host, as in K2;
+//   * decisions are guarded and fall back to the exact chain (weights recomputed from the node positions): the float32
+//     re-rounding of x1 within 1e-11 relative of a rounding tie (this path's x1 is good to ~1e-13); the sample position
+//     within 1e-9 of a face of the live volume or of a cell boundary (the reference's sampler is DIS-continuous across y / z
+//     cells: its y fraction blends along z); s within 1e-9 of -tdist; |b|_8 == 0 or weights that do not normalise.
+// Every mode (search, search + store, stored) runs THIS arithmetic on the same normalised weights: bit-identical results.
+struct DqbNorm {
+    double w0, w1, w2;          // w_j / sum, j = 0..2 (the fourth is 1 - (w0 + w1 + w2))
+    float wi;                   // mean node distance; negative = "exact chain only" (the weights do not normalise)
+};
+
+__device__ __forceinline__ DqbNorm dqb_normalise(const double (&wg)[4], double wi) {
+    DqbNorm e;
+    const double sum = (wg[0] + wg[1]) + (wg[2] + wg[3]);
+    e.wi = (float)wi;
+    if (!(sum > 1e-280) || !(sum < __builtin_huge_val())) {          // all-zero blend (core/fusion.py:544-549), overflow, NaN
+        e.w0 = e.w1 = e.w2 = 0.0;
+        e.wi = -1.0f;
+        return e;
+    }
+    const double inv = 1.0 / sum;
+    e.w0 = wg[0] * inv; e.w1 = wg[1] * inv; e.w2 = wg[2] * inv;
+    return e;
+}
+
+// is `v` within 1e-11 |v| of a float32 rounding tie (vf = (float)v)?
+__device__ __forceinline__ bool near_f32_tie(double v, float vf) {
+    const double d = fabs(v - (double)vf);                                   // exact
+    const float hulp = __uint_as_float((__float_as_uint(vf) & 0x7f800000u) - (24u << 23));   // half an ulp of vf (normal range)
+    // (below 2^-10 the float32 grid is no coarser than 1e4 times this path's own error: those few voxels go the exact way)
+    return !(fabs(d - (double)hulp) > 1e-11 * fabs(v)) || !(fabs(v) > 0x1p-10);
+}
+
+// the reference's chain for one voxel from scratch (weights from the node positions), written to float32 volumes
+template <typename LiveT>
+__device__ __forceinline__ void dqb_exact_voxel(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const LiveT *__restrict__ live,
+                                                const double *__restrict__ node_pos, const double *__restrict__ node_dq,
+                                                const double *__restrict__ node_w, const int (&bi)[4], const DqbParams &p,
+                                                double px, double py, double pz, size_t off) {
+    double bd[4], wg[4], wi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gi = bi[j];
+        const double dx = px - node_pos[3 * gi], dy = py - node_pos[3 * gi + 1], dz = pz - node_pos[3 * gi + 2];
+        bd[j] = (dx * dx + dy * dy) + dz * dz;
+    }
+    dqb_weights<4>(node_w, bd, bi, 4, wg, wi);
+    const D3 q = dqb_blend_warp<4>(node_dq, wg, bi, 4, p.lw.q, px, py, pz);
+    double s;
+    if (!interpolate_exact(live, p.LX, p.LY, p.LZ, q.x, q.y, q.z, s)) return;
+    if (!(s > -1.0 * p.tdist)) return;
+    double wt = (double)tsdf_w[off];
+    if (wt == 0.0) wt = wi;
+    const double m = s < p.tdist ? s : p.tdist;
+    tsdf[off] = (float)(((double)tsdf[off] * wt + m * wi) / (wi + wt));
+    const double nw = wi + wt;
+    tsdf_w[off] = (float)(nw < p.wmax ? nw : p.wmax);
+}
+
+#ifndef DFH_K3_STUB                  // experiment builds (tools/build_variant.sh ... -DDFH_K3_STUB=bits): parts of the steady-state kernel
+#define DFH_K3_STUB 0                // left out to see what it is bound by: 1 live gathers, 2 stores, 4 weight loads, 8 DQ rows, 16 index loads
+#endif
+
+// where the blend reads a node's eight DQ components from: global memory (a 64-byte row per node) or an LDS copy of the table
+struct DqGlobal {
+    const double *__restrict__ q;
+    __device__ __forceinline__ const double *row(int n) const { return q + 8 * (size_t)n; }
+};
+constexpr int kDqLdsStride = 10;            // doubles per node in LDS: 80-byte rows spread the 16-byte reads of different nodes over the banks
+struct DqLds {
+    const double *q;                        // (the caller indexes its __shared__ array directly: the address space survives inlining)
+    __device__ __forceinline__ const double *row(int n) const { return q + kDqLdsStride * n; }
+};
+
+// The fast path in three steps (the steady-state kernel calls them itself, with deferred exact re-evaluation; dqb_fast_voxel
+// runs them back to back with the exact chain inline).  Same operations in the same order either way: the same bits.
+struct DqbWarped {
+    double qx, qy, qz;          // sample position in the live volume
+    bool ok;                    // inside the live volume
+    bool redo;                  // a decision is too close to call: this voxel goes through the exact chain
+};
+
+// blend -> x1 (closed form) -> float32 re-rounding -> m_lw (affine) -> inside / cell-boundary tests
+template <typename DqSrc>
+__device__ __forceinline__ DqbWarped dqb_stage_warp(const DqSrc dqs, const int (&bi)[4], const DqbNorm e, const DqbParams &p,
+                                                    const RigidFastParams &f, double px, double py, double pz) {
+    DqbWarped o;
+    bool redo = !(e.wi >= 0.0f);
+    double wq[4];
+    wq[0] = e.w0; wq[1] = e.w1; wq[2] = e.w2;
+    wq[3] = 1.0 - ((wq[0] + wq[1]) + wq[2]);
+    double b[8];
+    if (DFH_K3_STUB & 8) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c] = (c == 0 ? 1.0 : 1e-3 * c) * wq[c & 3] + 1e-4 * bi[c & 3];
+    } else {
+        const double *d0 = dqs.row(bi[0]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c] = wq[0] * d0[c];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const double *dj = dqs.row(bi[j]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b[c] = __builtin_fma(wq[j], dj[c], b[c]);
+        }
+    }
+    const double n2 = __builtin_fma(b[0], b[0], __builtin_fma(b[1], b[1], __builtin_fma(b[2], b[2], b[3] * b[3]))) +
+                      __builtin_fma(b[4], b[4], __builtin_fma(b[5], b[5], __builtin_fma(b[6], b[6], b[7] * b[7])));
+    redo = redo | !(n2 > 1e-200);
+    double inv = __builtin_amdgcn_rcp(n2);
+    inv = __builtin_fma(inv, __builtin_fma(-n2, inv, 1.0), inv);
+    inv = __builtin_fma(inv, __builtin_fma(-n2, inv, 1.0), inv);
+    // x1 = (r P r* + 2 vec(d r*)) / |b|^2
+    const double w = b[0], x = b[1], y = b[2], z = b[3], d0 = b[4], d1 = b[5], d2 = b[6], d3 = b[7];
+    const double ww = w * w, xx = x * x, yy = y * y, zz = z * z;
+    const double xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    const double m00 = (ww + xx) - (yy + zz), m11 = (ww + yy) - (xx + zz), m22 = (ww + zz) - (xx + yy);
+    const double t0 = __builtin_fma(d3, y, __builtin_fma(-d2, z, __builtin_fma(d1, w, -d0 * x)));
+    const double t1 = __builtin_fma(-d3, x, __builtin_fma(d2, w, __builtin_fma(d1, z, -d0 * y)));
+    const double t2 = __builtin_fma(d3, w, __builtin_fma(d2, x, __builtin_fma(-d1, y, -d0 * z)));
+    const double u0 = __builtin_fma(m00, px, 2.0 * __builtin_fma(xy - wz, py, __builtin_fma(xz + wy, pz, t0)));
+    const double u1 = __builtin_fma(m11, py, 2.0 * __builtin_fma(xy + wz, px, __builtin_fma(yz - wx, pz, t1)));
+    const double u2 = __builtin_fma(m22, pz, 2.0 * __builtin_fma(xz - wy, px, __builtin_fma(yz + wx, py, t2)));
+    const double x1d = u0 * inv, y1d = u1 * inv, z1d = u2 * inv;
+    // the float32 re-rounding of x1 inside the second dqb_warp (core/util.py:69)
+    const float x1f = (float)x1d, y1f = (float)y1d, z1f = (float)z1d;
+    redo = redo | near_f32_tie(x1d, x1f) | near_f32_tie(y1d, y1f) | near_f32_tie(z1d, z1f);
+    const double ax = (double)x1f, ay = (double)y1f, az = (double)z1f;
+    o.qx = __builtin_fma(f.M[2], az, __builtin_fma(f.M[1], ay, __builtin_fma(f.M[0], ax, f.t[0])));
+    o.qy = __builtin_fma(f.M[5], az, __builtin_fma(f.M[4], ay, __builtin_fma(f.M[3], ax, f.t[1])));
+    o.qz = __builtin_fma(f.M[8], az, __builtin_fma(f.M[7], ay, __builtin_fma(f.M[6], ax, f.t[2])));
+    const double hx = (double)(p.LX - 1), hy = (double)(p.LY - 1), hz = (double)(p.LZ - 1);
+    const double lo = fmin(fmin(o.qx, o.qy), o.qz);
+    const double hi = fmin(fmin(hx - o.qx, hy - o.qy), hz - o.qz);
+    o.ok = (lo >= 0.0) & (hi >= 0.0);
+    // (NaN-safe: every comparison is written so that a NaN lands in `redo`)
+    redo = redo | !(fmin(fabs(lo), fabs(hi)) > 1e-9);
+    if (o.ok) {
+        // cell boundaries: the sampler's y / z fractions blend along the other axis, so it jumps where a coordinate crosses an integer
+        const double fx = o.qx - floor(o.qx), fy = o.qy - floor(o.qy), fz = o.qz - floor(o.qz);
+        redo = redo | !(fmin(fmin(fmin(fx, fy), fz), fmin(fmin(1.0 - fx, 1.0 - fy), 1.0 - fz)) > 1e-9);
+    }
+    o.redo = redo;
+    return o;
+}
+
+// the eight corner samples of sample_fast (requested here, used in dqb_stage_finish); voxel 0 when the position is outside
+template <typename LiveT>
+__device__ __forceinline__ void dqb_stage_gather(const LiveT *__restrict__ live, const DqbParams &p, const DqbWarped &wp, LiveT (&c)[8]) {
+    if (DFH_K3_STUB & 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = (LiveT)(0.25 * i + wp.qz * 1e-3);
+        return;
+    }
+    const double qx = wp.ok ? wp.qx : 0.0, qy = wp.ok ? wp.qy : 0.0, qz = wp.ok ? wp.qz : 0.0;
+    const int x0 = (int)floor(qx), y0 = (int)floor(qy), z0 = (int)floor(qz);
+    const int x1 = (int)ceil(qx), y1 = (int)ceil(qy), z1 = (int)ceil(qz);
+    const size_t sx = (size_t)p.LY * p.LZ, sy = (size_t)p.LZ;
+    c[0] = live[x0 * sx + y0 * sy + z0]; c[1] = live[x1 * sx + y0 * sy + z0];       // c000, c100 of sample_fast
+    c[2] = live[x0 * sx + y1 * sy + z0]; c[3] = live[x1 * sx + y1 * sy + z0];       // c001, c101  (y1)
+    c[4] = live[x0 * sx + y0 * sy + z1]; c[5] = live[x1 * sx + y0 * sy + z1];       // c010, c110  (z1)
+    c[6] = live[x0 * sx + y1 * sy + z1]; c[7] = live[x1 * sx + y1 * sy + z1];       // c011, c111
+}
+
+// `redo` voxels of the steady-state kernel are not re-evaluated in place -- the exact chain inlined into that kernel costs it
+// 40 VGPRs, i.e. half its waves -- but appended to a list (their linear voxel offsets) that dqb_redo_kernel works off right
+// behind it.  {count, blocks done} live in front of the list; the redo kernel's last block clears them for the next call.
+struct DqbRedoList {
+    unsigned *count;            // [0] entries, [1] blocks of the redo kernel that have finished
+    unsigned *offs;             // capacity: one entry per voxel of the slab (cannot overflow)
+};
+
+// sample (sample_fast's lerps), the s > -tdist decision, the running average; a `redo` voxel goes through the exact chain here
+// (DEFER = false) or onto the redo list
+template <typename LiveT, bool DEFER = false>
+__device__ __forceinline__ void dqb_stage_finish(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const LiveT *__restrict__ live,
+                                                 const double *__restrict__ node_pos, const double *__restrict__ node_dq,
+                                                 const double *__restrict__ node_w, const int (&bi)[4], float wi_f, const DqbParams &p,
+                                                 const DqbWarped &wp, const LiveT (&c)[8], double px, double py, double pz, size_t off,
+                                                 float t_old, float w_old, const DqbRedoList redo_list = DqbRedoList{nullptr, nullptr}) {
+    bool redo = wp.redo;
+    bool ok = wp.ok;
+    double sv = 0.0;
+    if (ok) {
+        const double xd = wp.qx - floor(wp.qx), yd = wp.qy - floor(wp.qy), zd = wp.qz - floor(wp.qz);
+        const double c000 = (double)c[0], c100 = (double)c[1], c001 = (double)c[2], c101 = (double)c[3];
+        const double c010 = (double)c[4], c110 = (double)c[5], c011 = (double)c[6], c111 = (double)c[7];
+        const double c00 = __builtin_fma(xd, c100 - c000, c000), c01 = __builtin_fma(xd, c101 - c001, c001);
+        const double c10 = __builtin_fma(xd, c110 - c010, c010), c11 = __builtin_fma(xd, c111 - c011, c011);
+        const double c0 = __builtin_fma(yd, c10 - c00, c00);          // y fraction blends the z1 samples (util.py:135)
+        const double c1 = __builtin_fma(yd, c11 - c01, c01);
+        sv = __builtin_fma(zd, c1 - c0, c0);                          // z fraction blends the y1 samples (util.py:137)
+        const double margin = sv + p.tdist;
+        ok = margin > 0.0;
+        redo = redo | !(fabs(margin) > 1e-9 * (1.0 + fabs(sv)));
+    }
+    if (DEFER) {
+        // one atomic per WAVE (an identity warp field puts every sample on a lattice point, i.e. every voxel on this list:
+        // 64 x fewer atomics on the one counter); all lanes of the wave reach this point together
+        const unsigned long long m = __ballot(redo);
+        if (m != 0ull) {
+            const int lane = (int)(threadIdx.x & 63);
+            unsigned base = 0;
+            if (lane == __builtin_ctzll(m)) base = atomicAdd(redo_list.count, (unsigned)__builtin_popcountll(m));
+            base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+            if (redo) redo_list.offs[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned)off;
+        }
+        if (redo) return;
+    }
+    if (__builtin_expect(redo, 0)) {
+        if (DEFER) {
+            return;
+        } else {
+            asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));              // keep the exact chain's arithmetic inside its branch
+            dqb_exact_voxel(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, p, px, py, pz, off);
+        }
+        return;
+    }
+    if (!ok) return;
+    const double wi = (double)wi_f;
+    double wt = (double)w_old;
+    if (wt == 0.0) wt = wi;                                                                         // fusion.py:186-187
+    const double m = fmin(sv, p.tdist);
+    const double den = wi + wt;
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+    if ((DFH_K3_STUB & 2) && den != 12345.678) return;
+    tsdf[off] = (float)(__builtin_fma((double)t_old, wt, m * wi) * r);                              // :189
+    tsdf_w[off] = (float)fmin(den, p.wmax);                                                         // :190
+}
+
+template <typename LiveT, typename DqSrc>
+__device__ __forceinline__ void dqb_fast_voxel(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const LiveT *__restrict__ live,
+                                               const double *__restrict__ node_pos, const double *__restrict__ node_dq, const DqSrc dqs,
+                                               const double *__restrict__ node_w, const int (&bi)[4], const DqbNorm e,
+                                               const DqbParams &p, const RigidFastParams &f, double px, double py, double pz, size_t off,
+                                               float t_old, float w_old) {
+    const DqbWarped wp = dqb_stage_warp(dqs, bi, e, p, f, px, py, pz);
+    LiveT c[8];
+    dqb_stage_gather(live, p, wp, c);
+    dqb_stage_finish(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, e.wi, p, wp, c, px, py, pz, off, t_old, w_old);
+}
+
+// MODE as in fuse_volume_dqb_kernel; the cache of modes 1 / 3 holds, behind the indices, three planes of normalised weights
+// (fp64, z-contiguous like the exact path's) and one float32 plane of integration weights.
+template <typename LiveT, int MODE>
+__global__ __launch_bounds__(256) void fuse_volume_dqb_fast_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                    const LiveT *__restrict__ live,
+                                                                    const double *__restrict__ node_pos,
+                                                                    const double *__restrict__ node_dq,
+                                                                    const double *__restrict__ node_w,
+                                                                    const int *__restrict__ cand,
+                                                                    unsigned short *__restrict__ knn_cache,
+                                                                    double *__restrict__ w_cache, const DqbParams p,
+                                                                    const RigidFastParams f) {
+    const size_t nvox = (size_t)p.nx * p.Y * p.Z;
+    float *__restrict__ wi_cache = reinterpret_cast<float *>(w_cache + 3 * nvox);
+    const long brick = blockIdx.x;
+    int xl, y, z;
+    bool inb;
+    if (MODE >= 2) {
+        const size_t lin = (size_t)blockIdx.x * 256 + threadIdx.x;
+        inb = lin < nvox;
+        z = (int)(lin % (size_t)p.Z);
+        y = (int)((lin / (size_t)p.Z) % (size_t)p.Y);
+        xl = (int)(lin / ((size_t)p.Z * p.Y));
+    } else {
+        const int bz = (int)(brick % p.nbz);
+        const int by = (int)((brick / p.nbz) % p.nby);
+        const int bx = (int)(brick / ((long)p.nbz * p.nby));
+        const int lz = threadIdx.x & (kBZ - 1);
+        const int ly = (threadIdx.x >> 4) & (kBY - 1);
+        const int lx = threadIdx.x >> 6;
+        xl = bx * kBX + lx; y = by * kBY + ly; z = bz * kBZ + lz;
+        inb = (xl < p.nx) && (y < p.Y) && (z < p.Z);
+    }
+    const double px = (double)(p.x0 + xl), py = (double)y, pz = (double)z;
+    const size_t off = ((size_t)xl * p.Y + y) * p.Z + z;
+    int bi[4];
+    DqbNorm e;
+    if (MODE >= 2) {
+        if (!inb) return;
+        const uint2 v = *reinterpret_cast<const uint2 *>(knn_cache + off * 4);
+        bi[0] = min((int)(v.x & 0xffffu), p.N - 1); bi[1] = min((int)(v.x >> 16), p.N - 1);          // a stale or foreign workspace must not fault
+        bi[2] = min((int)(v.y & 0xffffu), p.N - 1); bi[3] = min((int)(v.y >> 16), p.N - 1);
+    } else {
+        double bd[4];
+        block_knn<4>(node_pos, cand + brick * (kCap + 1), p.N, px, py, pz, inb, bd, bi);
+        if (!inb) return;
+        if (MODE == 1) {
+            uint2 v;
+            v.x = (unsigned)bi[0] | ((unsigned)bi[1] << 16);
+            v.y = (unsigned)bi[2] | ((unsigned)bi[3] << 16);
+            *reinterpret_cast<uint2 *>(knn_cache + off * 4) = v;
+        }
+        double wg[4], wi;
+        dqb_weights<4>(node_w, bd, bi, 4, wg, wi);
+        e = dqb_normalise(wg, wi);
+        if (MODE == 1 && w_cache) {
+            w_cache[off] = e.w0; w_cache[nvox + off] = e.w1; w_cache[2 * nvox + off] = e.w2;
+            wi_cache[off] = e.wi;
+        }
+    }
+    if (MODE == 3) {
+        e.w0 = w_cache[off]; e.w1 = w_cache[nvox + off]; e.w2 = w_cache[2 * nvox + off];
+        e.wi = wi_cache[off];
+    } else if (MODE == 2) {
+        double bd[4], wg[4], wi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gi = bi[j];
+            const double dx = px - node_pos[3 * gi], dy = py - node_pos[3 * gi + 1], dz = pz - node_pos[3 * gi + 2];
+            bd[j] = (dx * dx + dy * dy) + dz * dz;
+        }
+        dqb_weights<4>(node_w, bd, bi, 4, wg, wi);
+        e = dqb_normalise(wg, wi);
+    }
+    dqb_fast_voxel(tsdf, tsdf_w, live, node_pos, node_dq, DqGlobal{node_dq}, node_w, bi, e, p, f, px, py, pz, off, tsdf[off], tsdf_w[off]);
+}
+
+// Stored neighbourhoods, steady state (Z a multiple of 64, the node table fits the LDS): persistent workgroups that keep the
+// whole node_dq table in LDS and walk 64-voxel runs of z rows.  What the one-run-per-wave kernel above is bound by
+// (profiles/r3_k3_experiments.txt): not arithmetic and not cache bytes -- the fp64 chain and the fast path took the same
+// 330 us -- but a chain of dependent memory round trips per run at 4-7 waves per SIMD: per-voxel inputs 0.77 us, the four
+// nodes' DQ rows (16 gathers of 16 B per lane: 256 B per voxel through a 64 B/clk L1, the texture addresser 93 % busy),
+// the eight live-volume samples 2.3 us, the store drain 1.0 us (in-kernel stamps of every phase, -DDFH_K3_TRACE builds of
+// round 3).  Here the DQ rows come from LDS (16 ds_read on a path of their own), the coordinates are wave-uniform scalar
+// arithmetic (the kernel above divides a 64-bit linear index per lane), and undecidable voxels go onto a list instead of through
+// an inlined exact chain (63 instead of 102 VGPRs): 340 -> 248 us at 256^3 / 512 nodes.  (A software pipeline over three runs
+// -- inputs of run i+2 and live samples of run i+1 in flight while run i is finished -- was built and measured slower, 267 us:
+// with the memory operations stubbed out the kernel still takes 172 us; it is bound by its ~220 fp64 instructions per run.)
+struct DqbRunInputs {
+    uint2 idx;
+    double w0, w1, w2;
+    float wi, t, w;
+};
+
+template <typename LiveT, int TPB>
+__global__ __launch_bounds__(TPB) void fuse_volume_dqb_lds_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
+                                                                   const LiveT *__restrict__ live,
+                                                                   const double *__restrict__ node_pos,
+                                                                   const double *__restrict__ node_dq,
+                                                                   const double *__restrict__ node_w,
+                                                                   const unsigned short *__restrict__ knn_cache,
+                                                                   const double *__restrict__ w_cache, const DqbParams p,
+                                                                   const RigidFastParams f, int n_runs, const DqbRedoList redo_list) {
+    extern __shared__ double sdq[];                                           // N rows of kDqLdsStride doubles
+    for (int i = threadIdx.x; i < p.N * 8; i += TPB) sdq[(i >> 3) * kDqLdsStride + (i & 7)] = node_dq[i];
+    __syncthreads();
+    const size_t nvox = (size_t)p.nx * p.Y * p.Z;
+    const float *__restrict__ wi_cache = reinterpret_cast<const float *>(w_cache + 3 * nvox);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)));
+    const int n_waves = (int)gridDim.x * (TPB / 64);
+    const int runs_per_row = p.Z >> 6;
+    auto fetch = [&](int r, DqbRunInputs &in) {
+        const size_t off = (size_t)r * 64 + lane;
+        if (DFH_K3_STUB & 16) in.idx = make_uint2((unsigned)(r & 255) | 0x10000u * ((r + 7) & 255), (unsigned)((r + 3) & 255) | 0x10000u * ((r + 11) & 255));
+        else in.idx = *reinterpret_cast<const uint2 *>(knn_cache + off * 4);
+        if (DFH_K3_STUB & 4) { in.w0 = 0.4 + 1e-9 * lane; in.w1 = 0.3; in.w2 = 0.2; in.wi = 30.0f; }
+        else {
+            in.w0 = w_cache[off]; in.w1 = w_cache[nvox + off]; in.w2 = w_cache[2 * nvox + off];
+            in.wi = wi_cache[off];
+        }
+        in.t = tsdf[off]; in.w = tsdf_w[off];
+    };
+    auto coords = [&](int r, double &px, double &py, double &pz) {
+        const int row = r / runs_per_row;                                      // (wave-uniform arithmetic)
+        const int xl = row / p.Y;
+        px = (double)(p.x0 + xl); py = (double)(row - xl * p.Y); pz = (double)((r - row * runs_per_row) * 64 + lane);
+    };
+    auto nodes_of = [&](uint2 idx, int (&bi)[4]) {
+        bi[0] = min((int)(idx.x & 0xffffu), p.N - 1); bi[1] = min((int)(idx.x >> 16), p.N - 1);   // a stale or foreign workspace must not fault
+        bi[2] = min((int)(idx.y & 0xffffu), p.N - 1); bi[3] = min((int)(idx.y >> 16), p.N - 1);
+    };
+    if (wave >= n_runs) return;
+    for (int r = wave; r < n_runs; r += n_waves) {                            // consecutive waves take consecutive runs
+        DqbRunInputs in;
+        fetch(r, in);
+        double px, py, pz;
+        coords(r, px, py, pz);
+        int bi[4];
+        nodes_of(in.idx, bi);
+        DqbNorm e;
+        e.w0 = in.w0; e.w1 = in.w1; e.w2 = in.w2; e.wi = in.wi;
+        const DqbWarped wp = dqb_stage_warp(DqLds{sdq}, bi, e, p, f, px, py, pz);
+        LiveT c[8];
+        dqb_stage_gather(live, p, wp, c);
+        dqb_stage_finish<LiveT, true>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, e.wi, p, wp, c, px, py, pz, (size_t)r * 64 + lane,
+                                      in.t, in.w, redo_list);
+    }
+}
+
+// The voxels the steady-state kernel could not decide (a float32 rounding tie of x1, a sample on a cell or volume boundary, s
+// at -tdist: ~1e-4 of them), through the reference's chain.  Fixed grid; the last block to finish clears the list's header.
+template <typename LiveT>
+__global__ __launch_bounds__(256) void dqb_redo_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const LiveT *__restrict__ live,
+                                                        const double *__restrict__ node_pos, const double *__restrict__ node_dq,
+                                                        const double *__restrict__ node_w, const unsigned short *__restrict__ knn_cache,
+                                                        const DqbParams p, const DqbRedoList redo_list) {
+    const unsigned n = redo_list.count[0];
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const size_t off = redo_list.offs[i];
+        const int z = (int)(off % (size_t)p.Z);
+        const int y = (int)((off / (size_t)p.Z) % (size_t)p.Y);
+        const int xl = (int)(off / ((size_t)p.Z * p.Y));
+        const uint2 v = *reinterpret_cast<const uint2 *>(knn_cache + off * 4);
+        int bi[4];
+        bi[0] = min((int)(v.x & 0xffffu), p.N - 1); bi[1] = min((int)(v.x >> 16), p.N - 1);
+        bi[2] = min((int)(v.y & 0xffffu), p.N - 1); bi[3] = min((int)(v.y >> 16), p.N - 1);
+        dqb_exact_voxel(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, p, (double)(p.x0 + xl), (double)y, (double)z, off);
+    }
+    __syncthreads();                                                          // (this block's reads of count[0] are done)
+    if (threadIdx.x == 0 && atomicAdd(redo_list.count + 1, 1u) == gridDim.x - 1) {
+        redo_list.count[0] = 0u;
+        redo_list.count[1] = 0u;
+    }
+}
+
+template <typename LiveT>
+static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const double *node_pos, const double *node_dq,
+                           const double *node_w, int *cand, unsigned short *knn_cache, double *w_cache, int mode, const DqbParams &p,
+                           hipStream_t s) {
+    RigidFastParams f;
+    fold_rigid(p.lw.q, f);
+    // the redo list of the steady-state kernel sits in the cache's spare room: the fast path uses 28 of the 40 B per voxel of
+    // a level-2 workspace (three fp64 planes, one float32 plane), the list one unsigned per voxel behind them + 16 B of header
+    DqbRedoList redo_list{nullptr, nullptr};
+    if (w_cache) {
+        const size_t nv = (size_t)p.nx * p.Y * p.Z;
+        unsigned *base = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(w_cache) + nv * 28);
+        redo_list.count = base;
+        redo_list.offs = base + 4;
+        if (mode == 1) DFH_HIP_CHECK(hipMemsetAsync(base, 0, 16, s));        // (rebuild: the header starts clean)
+    }
+    const long nbricks = (long)p.nbx * p.nby * p.nbz;
+    const long nblocks = mode >= 2 ? ((long)p.nx * p.Y * p.Z + 255) / 256 : nbricks;
+#define DFH_K3F(MODE) hipLaunchKernelGGL((fuse_volume_dqb_fast_kernel<LiveT, MODE>), dim3((unsigned)nblocks), dim3(256), 0, s, (float *)tsdf, \
+                                         (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, p, f)
+    const long n_runs = (long)p.nx * p.Y * (p.Z / 64);
+    const size_t lds = (size_t)p.N * kDqLdsStride * sizeof(double);
+    if (mode == 3 && p.Z % 64 == 0 && n_runs < (1L << 25) && lds <= 64 * 1024 && !on(opt().k3_no_lds)) {
+        // persistent grid: as many 256-thread workgroups as fit the chip with this much LDS (160 KB per CU), at most 8 per CU
+        int dev = 0;
+        DFH_HIP_CHECK(hipGetDevice(&dev));
+        DeviceInfo &di = device_info(dev);
+        if (di.n_cu == 0) DFH_HIP_CHECK(hipDeviceGetAttribute(&di.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        // workgroups of 1024 threads: sixteen waves share one copy of the table (measured 248 us against 263 for 512 / 256)
+        const int tpb = opt().k3_tpb == 256 || opt().k3_tpb == 512 ? (int)opt().k3_tpb : 1024;
+        long per_cu = (long)(160 * 1024 / (lds + 512));
+        const long max_per_cu = 2048 / tpb;
+        if (per_cu > max_per_cu) per_cu = max_per_cu;
+        if (opt().k3_wg_per_cu > 0) per_cu = opt().k3_wg_per_cu;
+        long wgs = per_cu * di.n_cu;
+        const int wpb = tpb / 64;
+        if (wgs * wpb > n_runs) wgs = (n_runs + wpb - 1) / wpb;
+#define DFH_K3L(TPB) hipLaunchKernelGGL((fuse_volume_dqb_lds_kernel<LiveT, TPB>), dim3((unsigned)wgs), dim3(TPB), lds, s, (float *)tsdf, (float *)tsdf_w, \
+                                        (const LiveT *)live, node_pos, node_dq, node_w, knn_cache, w_cache, p, f, (int)n_runs, redo_list)
+        if (tpb == 256) DFH_K3L(256); else if (tpb == 512) DFH_K3L(512); else DFH_K3L(1024);
+#undef DFH_K3L
+    } else if (mode == 0) DFH_K3F(0); else if (mode == 1) DFH_K3F(1); else if (mode == 2) DFH_K3F(2); else DFH_K3F(3);
+#undef DFH_K3F
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
 template <typename VolT, typename LiveT>
 static int launch_dqb(void *tsdf, void *tsdf_w, const void *live, const double *node_pos, const double *node_dq,
                       const double *node_w, int *cand, unsigned short *knn_cache, double *w_cache, int mode, const DqbParams &p,
@@ -685,10 +1167,30 @@ extern "C" int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, cons
     const bool has_w = has_idx && workspace_bytes >= cached2;
     unsigned short *knn_cache = has_idx ? reinterpret_cast<unsigned short *>(static_cast<char *>(workspace) + base) : nullptr;
     double *w_cache = has_w ? reinterpret_cast<double *>(static_cast<char *>(workspace) + cached1) : nullptr;
-    const int mode = !has_idx ? 0 : (rebuild_candidates ? 1 : (has_w ? 3 : 2));
+    int mode = !has_idx ? 0 : (rebuild_candidates ? 1 : (has_w ? 3 : 2));
+    // float32 volumes with knn = 4 take the fast path; its cache (28 B per voxel) lives where the exact path keeps its fp64
+    // weights, so a workspace remembers which of the two wrote it: stored weights of the other kind are not used (the stored
+    // indices serve both; the weights are then recomputed, mode 2)
+    const bool fast = vol_dtype == DFH_F32 && knn == 4 && !on(opt().k3_exact);
+    if (has_w) {
+        static std::mutex mu;
+        static std::unordered_map<const void *, int> format;           // workspace -> 1 (fast entries) / 2 (fp64 weights)
+        std::lock_guard<std::mutex> lock(mu);
+        if (mode == 1) {
+            if (format.size() > 4096) format.clear();
+            format[workspace] = fast ? 1 : 2;
+        } else if (mode == 3) {
+            const auto it = format.find(workspace);
+            if (it == format.end() || it->second != (fast ? 1 : 2)) mode = 2;
+        }
+    }
     if (rebuild_candidates) {
         hipLaunchKernelGGL(dqb_candidates_kernel, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, s, node_pos, cand, p);
         DFH_HIP_CHECK(hipGetLastError());
+    }
+    if (fast) {
+        if (live_dtype == DFH_F32) return launch_dqb_fast<float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
+        return launch_dqb_fast<double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
     }
     if (vol_dtype == DFH_F32) {
         if (live_dtype == DFH_F32) return launch_dqb<float, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);

@@ -255,12 +255,12 @@ class Fusion:
             self._normals = np.asarray(self._normals)[keep]
             self._faces = None
             if len(self._vertices) > 0 and getattr(self, '_radius', None) is not None:
-                from scipy.spatial import cKDTree
-                vt = cKDTree(np.asarray(self._vertices, dtype=np.float64))
+                # every node re-anchored on its nearest remaining vertex (dfh_nearest_points)
+                npos = np.array([np.asarray(nd[1], dtype=np.float64) for nd in self._nodes])
+                vidx = _graph.nearest_points(npos, np.asarray(self._vertices, dtype=np.float64)).cpu().numpy()
                 for i in range(len(self._nodes)):
                     nd = self._nodes[i]
-                    _, vidx = vt.query(np.asarray(nd[1], dtype=np.float64))
-                    self._nodes[i] = (int(vidx), nd[1], nd[2], 2 * self._radius)
+                    self._nodes[i] = (int(vidx[i]), nd[1], nd[2], 2 * self._radius)
 
     def solve(self, correspondences=None, method='cnn', precompute_lw=True, tukey_data_weight=0.2,
               huber_regularization_weight=0.001, regularization_weight=1, iterations=10, pcg_iters=30, huber_delta=1.0):
@@ -410,47 +410,37 @@ class Fusion:
         self._radius = self._subsample_rate * np.average(e)                      # :92
         self.construct_graph()
 
-    def construct_graph(self, host=False):
+    def construct_graph(self):
         """Reference core/fusion.py:101-123 (needs `_vertices` and `_radius`).  The vertex -> node table is computed on the
-        device (dfh_sample_knn); host=True runs the numpy / KDTree twin instead (CPU-side tests of the definition)."""
+        device (dfh_sample_knn); `_kdtree` is a graph.NodeIndex (device look-ups) in place of the reference's KD-tree."""
         if self._vertices is None or getattr(self, '_radius', None) is None:
             raise ValueError('construct_graph needs _vertices and _radius')
-        if host:
-            self._nodes, self._kdtree, self._neighbor_look_up = _graph.construct_graph(self._vertices, self._radius, self._knn)
-            return
-        from scipy.spatial import KDTree
         vidx, pos, dq, w, lookup = _graph.construct_graph_device(self._vertices, self._radius, self._knn)
         self._nodes = [(vidx[i], pos[i], dq[i].copy(), w[i]) for i in range(len(pos))]
-        self._kdtree = KDTree(pos)                                               # (N nodes: host look-ups of single points)
+        self._kdtree = _graph.NodeIndex(pos)
         self._neighbor_look_up = lookup.cpu().numpy().astype(np.int64)
 
     def _dq_blend_kdtree(self, pos):
         d, loc = self._kdtree.query(pos, k=self._knn)                       # core/fusion.py:529
         return self.dq_blend(pos, [self._nodes[i][2] for i in np.atleast_1d(loc)], np.atleast_1d(loc))
 
-    def update_graph(self, refresh_surface=True, host=False):
+    def update_graph(self, refresh_surface=True):
         """Reference core/fusion.py:201-239: refresh the surface, re-anchor the nodes, insert nodes
         for unsupported vertices, rebuild the lookup, drop the live-frame data, write the warp field.
-        The O(vertices x nodes) steps run on the device (graph.update_graph_device); host=True runs the numpy / KDTree
-        twin instead (CPU-side tests of the definition against the reference's outputs)."""
+        The O(vertices x nodes) steps run on the device (graph.update_graph_device)."""
         if refresh_surface:
             self.marching_cubes()
-        if host:
-            self._nodes, self._kdtree, self._neighbor_look_up, n_new = _graph.update_graph(
-                self._nodes, self._kdtree, self._vertices, self._radius, self._knn, self._dq_blend_kdtree)
-        else:
-            from scipy.spatial import KDTree
-            pos, dq, w, _ = self.node_arrays()
-            vidx, P2, Q2, W2, lookup, n_new = _graph.update_graph_device(pos, dq, w, np.asarray(self._vertices, dtype=np.float64),
-                                                                        self._radius, self._knn)
-            vidx, P2, Q2 = vidx.cpu().numpy(), P2.cpu().numpy(), Q2.cpu().numpy()
-            old = self._nodes
-            N = len(old)
-            # old nodes keep their position / DQ objects (:208-212); new ones carry the blend (:222)
-            self._nodes = [(vidx[i], old[i][1], old[i][2], 2 * self._radius) for i in range(N)] + \
-                          [(vidx[i], P2[i], Q2[i], 2 * self._radius) for i in range(N, len(P2))]
-            self._kdtree = KDTree(P2)
-            self._neighbor_look_up = lookup.cpu().numpy().astype(np.int64)
+        pos, dq, w, _ = self.node_arrays()
+        vidx, P2, Q2, W2, lookup, n_new = _graph.update_graph_device(pos, dq, w, np.asarray(self._vertices, dtype=np.float64),
+                                                                    self._radius, self._knn)
+        vidx, P2, Q2 = vidx.cpu().numpy(), P2.cpu().numpy(), Q2.cpu().numpy()
+        old = self._nodes
+        N = len(old)
+        # old nodes keep their position / DQ objects (:208-212); new ones carry the blend (:222)
+        self._nodes = [(vidx[i], old[i][1], old[i][2], 2 * self._radius) for i in range(N)] + \
+                      [(vidx[i], P2[i], Q2[i], 2 * self._radius) for i in range(N, len(P2))]
+        self._kdtree = _graph.NodeIndex(P2)
+        self._neighbor_look_up = lookup.cpu().numpy().astype(np.int64)
         self._curr_tsdf = None
         self._correspondences = []
         self._workspace_key = None

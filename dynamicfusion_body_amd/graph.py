@@ -5,10 +5,10 @@ Device path (`construct_graph_device`, `update_graph_device`; what Fusion and pi
 O(vertices x nodes) step is a HIP kernel behind the C ABI -- anchor vertices (dfh_nearest_points), the vertex -> node
 table (dfh_sample_knn), the unsupported-vertex test (dfh_graph_unsupported), the new nodes' DQs (dfh_dq_blend_points).
 Only the greedy radius subsampling stays on the host: it is sequential by definition and runs on the unsupported set only.
-Host twins (`construct_graph`, `update_graph`: numpy + scipy.KDTree, statement for statement the reference's loops) are
-kept for CPU-side tests of the definition against golden g8."""
+The reference's own loops (numpy + a KD-tree, statement for statement) live in oracle/graph_np.py as the checker of this
+path; nothing here builds a KD-tree: the `_kdtree` attribute the reference's callers touch is a `NodeIndex`, whose
+query() runs on the device."""
 import numpy as np
-from scipy.spatial import KDTree
 
 NEW_NODE_DQ = np.array([1, 0.00, 0.00, 0.00, 0.00, 0.01, 0.01, 0.00], dtype=np.float32)     # core/fusion.py:115
 
@@ -30,41 +30,6 @@ def uniform_sample(arr, radius):
         keep = ~(np.sqrt(np.sum(d * d, axis=1)) < radius)
         candidates, locations = candidates[keep], locations[keep]
     return np.array(result), np.array(result_idx)
-
-
-def construct_graph(vertices, radius, knn):
-    """Reference core/fusion.py:101-123.  Returns (nodes, kdtree, neighbor_look_up): nodes is the
-    list of 4-tuples (vertex index, position, DQ, weight = 2*radius)."""
-    nodes_v, nodes_idx = uniform_sample(vertices, radius)
-    nodes = [(nodes_idx[i], nodes_v[i], NEW_NODE_DQ.copy(), 2 * radius) for i in range(len(nodes_v))]
-    kdtree = KDTree(nodes_v)
-    lookup = [kdtree.query(v, k=knn)[1] for v in vertices]
-    return nodes, kdtree, lookup
-
-
-def update_graph(nodes, kdtree, vertices, radius, knn, dq_blend):
-    """Reference core/fusion.py:203-233 after the marching-cubes refresh: re-anchor every node on
-    its nearest vertex, find the vertices no node supports (min over their knn nodes of
-    |node - v| / w >= 1), subsample them into new nodes whose DQ is the blend of the OLD graph at
-    that point (`dq_blend(pos)`, :222), rebuild the KD-tree and the vertex -> node table.
-    Returns (nodes, kdtree, neighbor_look_up, number of inserted nodes)."""
-    vert_kdtree = KDTree(vertices)
-    nodes = list(nodes)
-    for i in range(len(nodes)):
-        pos, se3 = nodes[i][1], nodes[i][2]
-        _, vidx = vert_kdtree.query(pos)
-        nodes[i] = (vidx, pos, se3, 2 * radius)
-    unsupported = []
-    for vert in vertices:
-        _, kdidx = kdtree.query(vert, k=knn)
-        if min([np.linalg.norm(nodes[idx][1] - vert) / nodes[idx][3] for idx in np.atleast_1d(kdidx)]) >= 1:
-            unsupported.append(vert)
-    new_v, new_idx = uniform_sample(unsupported, radius)
-    for i in range(len(new_v)):
-        nodes.append((new_idx[i], new_v[i], dq_blend(new_v[i]), 2 * radius))
-    kdtree = KDTree(np.array([n[1] for n in nodes]))
-    lookup = [kdtree.query(v, k=knn)[1] for v in vertices]
-    return nodes, kdtree, lookup, len(new_v)
 
 
 # ------------------------------------------------------------------------------------------------- device path
@@ -120,6 +85,33 @@ def dq_blend_points(points, nbr, node_dq, node_pos, node_w):
     _lib.check(lib.dfh_dq_blend_points(X.data_ptr(), X.shape[0], nb.data_ptr(), nb.shape[1], Q.data_ptr(), P.data_ptr(), Wn.data_ptr(),
                                        P.shape[0], out.data_ptr(), current_stream_ptr()), "dfh_dq_blend_points")
     return out
+
+
+class NodeIndex:
+    """What the reference keeps in `_kdtree` (a scipy KDTree over the node positions, core/fusion.py:120,232) as far as its
+    callers use it: `.data` and `.query(x, k)` -> (distances, indices), nearest first, ties to the lower index -- answered
+    by dfh_sample_knn on the device (a brute-force scan: the graph has a few thousand nodes at most)."""
+
+    def __init__(self, points):
+        self.data = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+        self.n = len(self.data)
+
+    def query(self, x, k=1):
+        from .solve import sample_knn
+        x = np.asarray(x, dtype=np.float64)
+        single = x.ndim == 1
+        X = np.ascontiguousarray(x.reshape(-1, 3))
+        kk = min(int(k), self.n)
+        nbr, _ = sample_knn(X, self.data, np.ones(self.n), kk)
+        idx = nbr.cpu().numpy().astype(np.int64)
+        d = np.linalg.norm(self.data[idx] - X[:, None, :], axis=2)
+        if kk < int(k):                                   # scipy pads missing neighbours with (inf, n)
+            pad = int(k) - kk
+            idx = np.concatenate([idx, np.full((len(X), pad), self.n, dtype=np.int64)], axis=1)
+            d = np.concatenate([d, np.full((len(X), pad), np.inf)], axis=1)
+        if int(k) == 1:
+            d, idx = d[:, 0], idx[:, 0]
+        return (d[0], idx[0]) if single else (d, idx)
 
 
 def construct_graph_device(vertices, radius, knn):

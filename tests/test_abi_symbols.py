@@ -39,10 +39,31 @@ def test_library_has_gfx950_code_object(lib_path):
 
 
 def test_no_oracle_in_product():
-    """The product path must never import the oracle (it is the checker)."""
+    """The product path must never import the oracle (it is the checker), must not bring a CPU nearest-neighbour structure
+    of its own (scipy's KD-trees: the reference's host-side search, restated only in oracle/graph_np.py), and the library's
+    call paths must not read the environment (one getenv: DFH_OPTIONS, at the first call)."""
+    import re
     pkg = os.path.dirname(os.path.abspath(_lib.__file__))
     for root, _, files in os.walk(pkg):
         for f in files:
             if f.endswith(".py"):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert not re.search(r"import\s+c?KDTree|scipy\.spatial", txt), f
+    n_getenv = 0
+    csrc = os.path.join(pkg, "csrc")
+    for f in os.listdir(csrc):
+        n_getenv += len(re.findall(r"\bgetenv\s*\(", open(os.path.join(csrc, f)).read()))
+    assert n_getenv <= 2, n_getenv
+
+
+def test_options_round_trip():
+    """dfh_set_option / dfh_get_option: known names round-trip, unknown names are refused (no GPU needed)."""
+    import pytest
+    _lib.set_option("k1_no_bricks", 1)
+    assert _lib.get_option("k1_no_bricks") == 1
+    _lib.set_option("k1_no_bricks", None)
+    assert _lib.get_option("k1_no_bricks") == -1
+    with pytest.raises(ValueError):
+        _lib.set_option("no_such_switch", 1)
+    assert _lib.get_option("no_such_switch") < -(2 ** 62)

@@ -7,7 +7,8 @@ import pickle
 import numpy as np
 import pytest
 
-from dynamicfusion_body_amd import Fusion, graph, io
+from dynamicfusion_body_amd import graph, io
+from oracle import graph_np
 
 
 def test_uniform_sample_and_construct_graph(golden):
@@ -16,7 +17,7 @@ def test_uniform_sample_and_construct_graph(golden):
     assert np.array_equal(i, g["us_i"]) and np.array_equal(v, g["us_v"])
     e_v, e_i = graph.uniform_sample([], 1.0)
     assert e_v.size == 0 and e_i.size == 0
-    nodes, kd, lookup = graph.construct_graph(g["verts"], float(g["radius"]), int(g["knn"]))
+    nodes, kd, lookup = graph_np.construct_graph(g["verts"], float(g["radius"]), int(g["knn"]))
     assert np.array_equal(np.array([n[0] for n in nodes]), g["cg_idx"])
     assert np.array_equal(np.array([n[1] for n in nodes]), g["cg_pos"])
     assert np.array_equal(np.array([n[2] for n in nodes]), g["cg_dq"]) and nodes[0][2].dtype == np.float32
@@ -25,21 +26,27 @@ def test_uniform_sample_and_construct_graph(golden):
 
 
 def test_update_graph_matches_reference(golden):
+    """The oracle's restatement of update_graph (oracle/graph_np.py) against the reference's own outputs (g8); the device
+    path is checked against the same golden in tests/test_gpu_graph.py."""
+    from oracle import oracle_np as O
     g = golden("g8_graph_io")
     k = int(g["knn"])
-    fu = Fusion(np.zeros((4, 4, 4)), 1.0, knn=k, write_warpfield=False)
-    fu._vertices, fu._radius = g["verts"], float(g["radius"])
-    fu.construct_graph(host=True)
-    fu._nodes = [(n[0], n[1], g["ug_dq_in"][i], n[3]) for i, n in enumerate(fu._nodes)]
-    fu._vertices = g["verts2"]
-    n_new = fu.update_graph(refresh_surface=False, host=True)
+    radius = float(g["radius"])
+    nodes, kd, lookup = graph_np.construct_graph(g["verts"], radius, k)
+    nodes = [(n[0], n[1], g["ug_dq_in"][i], n[3]) for i, n in enumerate(nodes)]
+
+    def dq_blend(pos):                                                        # Fusion.dq_blend over the OLD tree (core/fusion.py:527-551)
+        _, loc = kd.query(pos, k=k)
+        loc = np.atleast_1d(loc)
+        return O.dq_blend(pos, np.array([nodes[i][2] for i in loc], dtype=np.float64), np.array([nodes[i][1] for i in loc]),
+                          np.array([nodes[i][3] for i in loc]))
+    nodes2, kd2, lookup2, n_new = graph_np.update_graph(nodes, kd, g["verts2"], radius, k, dq_blend)
     assert n_new == len(g["ug_idx"]) - len(g["cg_idx"]) and n_new > 0
-    assert np.array_equal(np.array([n[0] for n in fu._nodes]), g["ug_idx"])
-    assert np.array_equal(np.array([n[1] for n in fu._nodes]), g["ug_pos"])
-    assert np.abs(np.array([np.asarray(n[2], dtype=np.float64) for n in fu._nodes]) - g["ug_dq"]).max() <= 1e-14
-    assert np.array_equal(np.array([n[3] for n in fu._nodes]), g["ug_w"])
-    assert np.array_equal(np.array(fu._neighbor_look_up), g["ug_lookup"])
-    assert fu._curr_tsdf is None and fu._correspondences == []
+    assert np.array_equal(np.array([n[0] for n in nodes2]), g["ug_idx"])
+    assert np.array_equal(np.array([n[1] for n in nodes2]), g["ug_pos"])
+    assert np.abs(np.array([np.asarray(n[2], dtype=np.float64) for n in nodes2]) - g["ug_dq"]).max() <= 1e-14
+    assert np.array_equal(np.array([n[3] for n in nodes2]), g["ug_w"])
+    assert np.array_equal(np.array(lookup2), g["ug_lookup"])
 
 
 def test_file_formats(golden, tmp_path):
@@ -89,3 +96,20 @@ def test_compute_sparsity_pattern():
             for nidx in fu._neighbor_look_up[fu._nodes[idx][0]]:
                 want[V + 3 * idx + r, 8 * nidx:8 * nidx + 8] = 1
     assert np.array_equal(S, want)
+
+
+def test_product_dq_helpers_against_the_reference(golden):
+    """dynamicfusion_body_amd.dq.DQTSE3 / SE3TDQ (host helpers of the product: FusionDM.solve, the drivers) directly against the
+    reference's outputs in golden g1 (core/util.py:79-89), not through the oracle's twins."""
+    from dynamicfusion_body_amd import dq
+    g = golden("g1_primitives")
+    for d, M, rt in zip(g["warp_dq_unit"], g["dqtse3_out"], g["se3tdq_roundtrip"]):
+        assert np.allclose(dq.DQTSE3(d), M, atol=1e-14)
+        mine = dq.SE3TDQ(M)
+        if mine[0] * rt[0] < 0:                                    # q and -q are the same pose; the reference's sign follows its branch
+            mine = -mine
+        assert np.allclose(mine, rt, atol=1e-9)
+        assert np.allclose(dq.DQTSE3(dq.SE3TDQ(M)), M, atol=1e-12)
+    # non-unit real part: the rotation is that of the normalised quaternion (core/util.py:86-89)
+    d = g["warp_dq_non"][0]
+    assert np.allclose(dq.DQTSE3(d)[:3, :3] @ dq.DQTSE3(d)[:3, :3].T, np.eye(3), atol=1e-12)

@@ -12,10 +12,13 @@ ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--nodes", type=int, default=512)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--lib", default=None, help="alternative libdfusion_hip.so (kernel experiments)")
+ap.add_argument("--options", default="", help="library switches, e.g. k3_exact=1 (the fp64 chain on float32 volumes)")
 a = ap.parse_args()
+from dynamicfusion_body_amd import _lib
 if a.lib:
-    from dynamicfusion_body_amd import _lib
     _lib.LIB_PATH = os.path.abspath(a.lib)
+for kv in filter(None, a.options.split(",")):
+    _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 R, N, k = a.res, a.nodes, 4
 tdist = 4.0
 g = torch.arange(R, device="cuda", dtype=torch.float32)
@@ -53,3 +56,4 @@ for level, what in ((1, "node indices"), (2, "indices + weights")):
           % (what, ms * 1e3, ms_c * 1e3, R ** 3 / ms / 1e3, alg_c / ms / 1e6, alg_c / ms / 1e6 / 80))
     del wsc
 print("   candidates per brick: mean %.1f max %d, overflow bricks %d of %d" % (float(cnt.clamp(min=0).float().mean()), int(cnt.max()), int((cnt < 0).sum()), cnt.numel()))
+

@@ -538,12 +538,14 @@ __device__ __forceinline__ DqbNorm dqb_normalise(const double (&wg)[4], double w
     return e;
 }
 
-// is `v` within 1e-11 |v| of a float32 rounding tie (vf = (float)v)?
-__device__ __forceinline__ bool near_f32_tie(double v, float vf) {
-    const double d = fabs(v - (double)vf);                                   // exact
-    const float hulp = __uint_as_float((__float_as_uint(vf) & 0x7f800000u) - (24u << 23));   // half an ulp of vf (normal range)
-    // (below 2^-10 the float32 grid is no coarser than 1e4 times this path's own error: those few voxels go the exact way)
-    return !(fabs(d - (double)hulp) > 1e-11 * fabs(v)) || !(fabs(v) > 0x1p-10);
+// is `v` within 2^-36 |v| (1.5e-11) of a float32 rounding tie?  The 29 mantissa bits a conversion to float32 drops sit at the
+// bottom of the double's low word; a tie is 0x10000000 there, and this path's x1 is good to ~1e-13 relative (a few hundred
+// units of the last place), so a window of +-2^16 units decides on integers.  Below 2^-10 the float32 grid is no coarser than
+// 1e4 times that error: those few voxels (and NaN / inf) go the exact way.
+__device__ __forceinline__ bool near_f32_tie(double v) {
+    const unsigned lo = (unsigned)__double2loint(v);
+    const bool tie = ((lo & 0x1fffffffu) - (0x10000000u - 0x10000u)) <= 0x20000u;
+    return tie | !(fabs(v) > 0x1p-10) | !(fabs(v) < 0x1p+100);
 }
 
 // the reference's chain for one voxel from scratch (weights from the node positions), written to float32 volumes
@@ -591,6 +593,7 @@ struct DqLds {
 // runs them back to back with the exact chain inline).  Same operations in the same order either way: the same bits.
 struct DqbWarped {
     double qx, qy, qz;          // sample position in the live volume
+    double fx, fy, fz;          // its floor (valid when ok)
     bool ok;                    // inside the live volume
     bool redo;                  // a decision is too close to call: this voxel goes through the exact chain
 };
@@ -639,7 +642,7 @@ __device__ __forceinline__ DqbWarped dqb_stage_warp(const DqSrc dqs, const int (
     const double x1d = u0 * inv, y1d = u1 * inv, z1d = u2 * inv;
     // the float32 re-rounding of x1 inside the second dqb_warp (core/util.py:69)
     const float x1f = (float)x1d, y1f = (float)y1d, z1f = (float)z1d;
-    redo = redo | near_f32_tie(x1d, x1f) | near_f32_tie(y1d, y1f) | near_f32_tie(z1d, z1f);
+    redo = redo | near_f32_tie(x1d) | near_f32_tie(y1d) | near_f32_tie(z1d);
     const double ax = (double)x1f, ay = (double)y1f, az = (double)z1f;
     o.qx = __builtin_fma(f.M[2], az, __builtin_fma(f.M[1], ay, __builtin_fma(f.M[0], ax, f.t[0])));
     o.qy = __builtin_fma(f.M[5], az, __builtin_fma(f.M[4], ay, __builtin_fma(f.M[3], ax, f.t[1])));
@@ -650,9 +653,11 @@ __device__ __forceinline__ DqbWarped dqb_stage_warp(const DqSrc dqs, const int (
     o.ok = (lo >= 0.0) & (hi >= 0.0);
     // (NaN-safe: every comparison is written so that a NaN lands in `redo`)
     redo = redo | !(fmin(fabs(lo), fabs(hi)) > 1e-9);
+    o.fx = o.fy = o.fz = 0.0;
     if (o.ok) {
         // cell boundaries: the sampler's y / z fractions blend along the other axis, so it jumps where a coordinate crosses an integer
-        const double fx = o.qx - floor(o.qx), fy = o.qy - floor(o.qy), fz = o.qz - floor(o.qz);
+        o.fx = floor(o.qx); o.fy = floor(o.qy); o.fz = floor(o.qz);
+        const double fx = o.qx - o.fx, fy = o.qy - o.fy, fz = o.qz - o.fz;
         redo = redo | !(fmin(fmin(fmin(fx, fy), fz), fmin(fmin(1.0 - fx, 1.0 - fy), 1.0 - fz)) > 1e-9);
     }
     o.redo = redo;
@@ -667,14 +672,26 @@ __device__ __forceinline__ void dqb_stage_gather(const LiveT *__restrict__ live,
         for (int i = 0; i < 8; ++i) c[i] = (LiveT)(0.25 * i + wp.qz * 1e-3);
         return;
     }
-    const double qx = wp.ok ? wp.qx : 0.0, qy = wp.ok ? wp.qy : 0.0, qz = wp.ok ? wp.qz : 0.0;
-    const int x0 = (int)floor(qx), y0 = (int)floor(qy), z0 = (int)floor(qz);
-    const int x1 = (int)ceil(qx), y1 = (int)ceil(qy), z1 = (int)ceil(qz);
-    const size_t sx = (size_t)p.LY * p.LZ, sy = (size_t)p.LZ;
-    c[0] = live[x0 * sx + y0 * sy + z0]; c[1] = live[x1 * sx + y0 * sy + z0];       // c000, c100 of sample_fast
-    c[2] = live[x0 * sx + y1 * sy + z0]; c[3] = live[x1 * sx + y1 * sy + z0];       // c001, c101  (y1)
-    c[4] = live[x0 * sx + y0 * sy + z1]; c[5] = live[x1 * sx + y0 * sy + z1];       // c010, c110  (z1)
-    c[6] = live[x0 * sx + y1 * sy + z1]; c[7] = live[x1 * sx + y1 * sy + z1];       // c011, c111
+    // (outside: fx = fy = fz = 0 and the "ceil" corners are taken at +0: voxel 0, never used)
+    const int x0 = (int)wp.fx, y0 = (int)wp.fy, z0 = (int)wp.fz;
+    // ceil(q) = floor(q) + (q > floor(q)); a position inside the volume has ceil <= R - 1
+    const int dxs = (wp.ok && wp.qx > wp.fx) ? 1 : 0, dys = (wp.ok && wp.qy > wp.fy) ? 1 : 0, dzs = (wp.ok && wp.qz > wp.fz) ? 1 : 0;
+    if ((long)p.LX * p.LY * p.LZ < (1L << 31)) {           // (uniform) 32-bit element offsets
+        const int sy = p.LZ, sx = p.LY * p.LZ;
+        const int b000 = (x0 * p.LY + y0) * p.LZ + z0;
+        const int ox = dxs ? sx : 0, oy = dys ? sy : 0, oz = dzs;
+        c[0] = live[b000]; c[1] = live[b000 + ox];                                          // c000, c100 of sample_fast
+        c[2] = live[b000 + oy]; c[3] = live[b000 + oy + ox];                                // c001, c101  (y1)
+        c[4] = live[b000 + oz]; c[5] = live[b000 + oz + ox];                                // c010, c110  (z1)
+        c[6] = live[b000 + oy + oz]; c[7] = live[b000 + oy + oz + ox];                      // c011, c111
+    } else {
+        const size_t sx = (size_t)p.LY * p.LZ, sy = (size_t)p.LZ;
+        const size_t x1 = x0 + dxs, y1 = y0 + dys, z1 = z0 + dzs;
+        c[0] = live[x0 * sx + y0 * sy + z0]; c[1] = live[x1 * sx + y0 * sy + z0];
+        c[2] = live[x0 * sx + y1 * sy + z0]; c[3] = live[x1 * sx + y1 * sy + z0];
+        c[4] = live[x0 * sx + y0 * sy + z1]; c[5] = live[x1 * sx + y0 * sy + z1];
+        c[6] = live[x0 * sx + y1 * sy + z1]; c[7] = live[x1 * sx + y1 * sy + z1];
+    }
 }
 
 // `redo` voxels of the steady-state kernel are not re-evaluated in place -- the exact chain inlined into that kernel costs it
@@ -697,7 +714,7 @@ __device__ __forceinline__ void dqb_stage_finish(float *__restrict__ tsdf, float
     bool ok = wp.ok;
     double sv = 0.0;
     if (ok) {
-        const double xd = wp.qx - floor(wp.qx), yd = wp.qy - floor(wp.qy), zd = wp.qz - floor(wp.qz);
+        const double xd = wp.qx - wp.fx, yd = wp.qy - wp.fy, zd = wp.qz - wp.fz;
         const double c000 = (double)c[0], c100 = (double)c[1], c001 = (double)c[2], c101 = (double)c[3];
         const double c010 = (double)c[4], c110 = (double)c[5], c011 = (double)c[6], c111 = (double)c[7];
         const double c00 = __builtin_fma(xd, c100 - c000, c000), c01 = __builtin_fma(xd, c101 - c001, c001);
@@ -973,6 +990,9 @@ static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const dou
 #define DFH_K3L(TPB) hipLaunchKernelGGL((fuse_volume_dqb_lds_kernel<LiveT, TPB>), dim3((unsigned)wgs), dim3(TPB), lds, s, (float *)tsdf, (float *)tsdf_w, \
                                         (const LiveT *)live, node_pos, node_dq, node_w, knn_cache, w_cache, p, f, (int)n_runs, redo_list)
         if (tpb == 256) DFH_K3L(256); else if (tpb == 512) DFH_K3L(512); else DFH_K3L(1024);
+        // ... and right behind it the voxels it put on its redo list, through the exact chain
+        hipLaunchKernelGGL((dqb_redo_kernel<LiveT>), dim3(64), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq,
+                           node_w, knn_cache, p, redo_list);
 #undef DFH_K3L
     } else if (mode == 0) DFH_K3F(0); else if (mode == 1) DFH_K3F(1); else if (mode == 2) DFH_K3F(2); else DFH_K3F(3);
 #undef DFH_K3F

@@ -20,6 +20,8 @@
 // so the contraction stays on the VALU (BASELINE north_star: "MFMA only if ...").
 #include "dfh_dq.h"
 
+#include <cstring>
+
 namespace dfh {
 
 constexpr int kKMaxS = 8;
@@ -546,13 +548,22 @@ __device__ __forceinline__ double blend_static(const double *__restrict__ node_d
     return nb;
 }
 
-// Projective association of one warped sample xp (index space): project with the reference's primitives, take the
-// nearest depth pixel, back-project, gate.  Returns validity; c = correspondence in index space (0 when invalid).
+// One live view of a frame in device memory (dfh_gn_pack_views): extrinsic, the inverse of its 3x3 part, the depth map.
+struct AssocView {
+    double lw_cam[12];
+    double Rinv[9];
+    const void *depth;
+    double pad[2];           // 192 bytes
+};
+
+// Projective association of one warped sample xp (index space) against ONE view: project with the reference's primitives,
+// take the nearest depth pixel, back-project.  Returns validity (before the distance gate); c = correspondence in index
+// space, d2 = its squared distance from xp.
 template <typename DepthT>
-__device__ __forceinline__ bool associate_point(const AssocParams &p, const DepthT *__restrict__ depth, const D3 &xp, double (&c)[3]) {
+__device__ __forceinline__ bool associate_view(const AssocParams &p, const double *lw, const double *Rinv, const DepthT *__restrict__ depth,
+                                               const D3 &xp, double &c0, double &c1, double &c2, double &d2) {
     // index -> world -> camera -> pixel (fusion_dm.py:191-195)
     const double wx = p.scale * (xp.x - p.half) + p.cx, wy = p.scale * (xp.y - p.half) + p.cy, wz = p.scale * (xp.z - p.half) + p.cz;
-    const double *lw = p.lw_cam.m;
     const double l0 = ((lw[0] * wx + lw[1] * wy) + lw[2] * wz) + lw[3];
     const double l1 = ((lw[4] * wx + lw[5] * wy) + lw[6] * wz) + lw[7];
     const double l2 = ((lw[8] * wx + lw[9] * wy) + lw[10] * wz) + lw[11];
@@ -562,7 +573,7 @@ __device__ __forceinline__ bool associate_point(const AssocParams &p, const Dept
     bool ok = p2 != 0.0;
     const double u = p0 / p2, v = p1 / p2;
     ok = ok && (u >= 0.0) && (u < (double)(p.W - 1)) && (v >= 0.0) && (v < (double)(p.H - 1));
-    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    c0 = 0.0; c1 = 0.0; c2 = 0.0; d2 = 0.0;
     if (ok) {
         const int ui = (int)rint(u), vi = (int)rint(v);
         const double z = -1.0 * (double)depth[(size_t)vi * p.W + ui];                  // :196
@@ -572,19 +583,46 @@ __device__ __forceinline__ bool associate_point(const AssocParams &p, const Dept
         const double q0 = (p.Kinv.m[0] * a0 + p.Kinv.m[1] * a1) + p.Kinv.m[2] * a2 - lw[3];
         const double q1 = (p.Kinv.m[3] * a0 + p.Kinv.m[4] * a1) + p.Kinv.m[5] * a2 - lw[7];
         const double q2 = (p.Kinv.m[6] * a0 + p.Kinv.m[7] * a1) + p.Kinv.m[8] * a2 - lw[11];
-        const double X = (p.Rinv.m[0] * q0 + p.Rinv.m[1] * q1) + p.Rinv.m[2] * q2;
-        const double Y = (p.Rinv.m[3] * q0 + p.Rinv.m[4] * q1) + p.Rinv.m[5] * q2;
-        const double Z = (p.Rinv.m[6] * q0 + p.Rinv.m[7] * q1) + p.Rinv.m[8] * q2;
+        const double X = (Rinv[0] * q0 + Rinv[1] * q1) + Rinv[2] * q2;
+        const double Y = (Rinv[3] * q0 + Rinv[4] * q1) + Rinv[5] * q2;
+        const double Z = (Rinv[6] * q0 + Rinv[7] * q1) + Rinv[8] * q2;
         c0 = (X - p.cx) / p.scale + p.half;
         c1 = (Y - p.cy) / p.scale + p.half;
         c2 = (Z - p.cz) / p.scale + p.half;
-        if (ok && p.max_dist > 0.0) {
-            const double dx = c0 - xp.x, dy = c1 - xp.y, dz = c2 - xp.z;
-            ok = (dx * dx + dy * dy + dz * dz) <= p.max_dist * p.max_dist;
-        }
+        const double dx = c0 - xp.x, dy = c1 - xp.y, dz = c2 - xp.z;
+        d2 = dx * dx + dy * dy + dz * dz;
     }
+    return ok;
+}
+
+// One view (the parameters inside p): validity includes the distance gate; c = 0 when invalid.
+template <typename DepthT>
+__device__ __forceinline__ bool associate_point(const AssocParams &p, const DepthT *__restrict__ depth, const D3 &xp, double (&c)[3]) {
+    double c0, c1, c2, d2;
+    bool ok = associate_view<DepthT>(p, p.lw_cam.m, p.Rinv.m, depth, xp, c0, c1, c2, d2);
+    if (ok && p.max_dist > 0.0) ok = d2 <= p.max_dist * p.max_dist;
     c[0] = ok ? c0 : 0.0; c[1] = ok ? c1 : 0.0; c[2] = ok ? c2 : 0.0;
     return ok;
+}
+
+// Several views (BASELINE config 5: the live frame is eight depth maps): every view is tried in turn, the sample keeps the
+// correspondence of the view in which it lies CLOSEST to the observed surface (smallest |c - x'|; the gate is applied per
+// view; ties go to the lower view index) -- one data row per sample, as with one view, so the block pattern and the plan do
+// not depend on the number of views.  The reference has no counterpart: its correspondences are mesh-to-mesh
+// (core/fusion.py:255-276); restated in oracle/gn_np.py:associate_depth_views.
+template <typename DepthT>
+__device__ __forceinline__ bool associate_views(const AssocParams &p, const AssocView *__restrict__ views, int n_views, const D3 &xp,
+                                                double (&c)[3]) {
+    bool any = false;
+    double best = __builtin_huge_val();
+    c[0] = 0.0; c[1] = 0.0; c[2] = 0.0;
+    for (int v = 0; v < n_views; ++v) {                    // (uniform: the views' parameters come through scalar loads)
+        double c0, c1, c2, d2;
+        bool ok = associate_view<DepthT>(p, views[v].lw_cam, views[v].Rinv, static_cast<const DepthT *>(views[v].depth), xp, c0, c1, c2, d2);
+        if (ok && p.max_dist > 0.0) ok = d2 <= p.max_dist * p.max_dist;
+        if (ok && d2 < best) { best = d2; c[0] = c0; c[1] = c1; c[2] = c2; any = true; }
+    }
+    return any;
 }
 
 // Warp every sample with the current field, project it into the live depth frame with the
@@ -594,7 +632,7 @@ __global__ __launch_bounds__(256) void associate_kernel(const double *__restrict
                                                          const double *__restrict__ wts, int S,
                                                          const double *__restrict__ node_dq, const DepthT *__restrict__ depth,
                                                          const AssocParams p, double *__restrict__ corr,
-                                                         unsigned char *__restrict__ valid) {
+                                                         unsigned char *__restrict__ valid, const AssocView *__restrict__ views, int n_views) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= S) return;
     int idx[kKMaxS];
@@ -610,7 +648,7 @@ __global__ __launch_bounds__(256) void associate_kernel(const double *__restrict
     const D3 x1 = dqb_warp_exact(b, round_f32(px), round_f32(py), round_f32(pz));
     const D3 xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
     double c[3];
-    const bool ok = associate_point<DepthT>(p, depth, xp, c);
+    const bool ok = views ? associate_views<DepthT>(p, views, n_views, xp, c) : associate_point<DepthT>(p, depth, xp, c);
     corr[3 * (size_t)i] = c[0];
     corr[3 * (size_t)i + 1] = c[1];
     corr[3 * (size_t)i + 2] = c[2];
@@ -745,6 +783,8 @@ __device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N,
 struct AssocArgs {
     AssocParams ap;
     const float *depth;
+    const AssocView *views;     // non-null: n_views float32 views from a dfh_gn_pack_views table (depth / ap.lw_cam unused)
+    int n_views;
 };
 
 #ifdef DFH_BUILD_TRACE   // experiment builds only: wall-clock stamps of every tile's phases
@@ -807,7 +847,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         a_pf[0] = round_f32(spos[3 * (size_t)s]); a_pf[1] = round_f32(spos[3 * (size_t)s + 1]); a_pf[2] = round_f32(spos[3 * (size_t)s + 2]);
         const D3 x1 = dqb_warp_exact(a_bh, a_pf[0], a_pf[1], a_pf[2]);
         a_xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
-        a_ok = associate_point<float>(aa.ap, aa.depth, a_xp, a_c);
+        a_ok = aa.views ? associate_views<float>(aa.ap, aa.views, aa.n_views, a_xp, a_c) : associate_point<float>(aa.ap, aa.depth, a_xp, a_c);
     }
     // corr / valid are outputs only: stored after the last global load of the kernel (stored here, every later s_waitcnt for a
     // load also waited for these stores' acknowledgements)
@@ -2402,31 +2442,93 @@ int dfh_permute_samples(const long *order, int n_samples, int knn, const double 
     return DFH_OK;
 }
 
-int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *weights, int n_samples, int knn,
-                     const double *node_dq, const double lw_dq[8], const void *depth, int depth_dtype, int H, int W,
-                     const double K[9], const double Kinv[9], const double lw_cam[12], double scale,
-                     const double center[3], double half, double max_dist, double *corr_out,
-                     unsigned char *valid_out, void *stream) {
+// views: a dfh_gn_pack_views table (then depth / lw_cam are unused), or nullptr for the one view (depth, lw_cam)
+static int gn_associate_impl(const char *what, const double *sample_pos, const int *nbr, const double *weights, int n_samples, int knn,
+                             const double *node_dq, const double lw_dq[8], const void *depth, int depth_dtype, const void *views, int n_views,
+                             int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12], double scale,
+                             const double center[3], double half, double max_dist, double *corr_out, unsigned char *valid_out, void *stream) {
     using namespace dfh;
-    DFH_REQUIRE(n_samples >= 0 && knn >= 1 && knn <= kKMaxS, "dfh_gn_associate: bad sizes");
-    DFH_REQUIRE(depth_dtype == DFH_F32 || depth_dtype == DFH_F64, "dfh_gn_associate: bad depth_dtype");
-    DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "dfh_gn_associate: bad depth map / scale");
+    DFH_REQUIRE(n_samples >= 0 && knn >= 1 && knn <= kKMaxS, "%s: bad sizes", what);
+    DFH_REQUIRE(depth_dtype == DFH_F32 || depth_dtype == DFH_F64, "%s: bad depth_dtype", what);
+    DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "%s: bad depth map / scale", what);
     if (n_samples == 0) return DFH_OK;
-    DFH_REQUIRE(sample_pos && nbr && weights && node_dq && lw_dq && depth && K && Kinv && lw_cam && center && corr_out && valid_out,
-                "dfh_gn_associate: null pointer");
+    DFH_REQUIRE(sample_pos && nbr && weights && node_dq && lw_dq && (depth || views) && K && Kinv && lw_cam && center && corr_out && valid_out,
+                "%s: null pointer", what);
     AssocParams p;
     {
         const int rc = fill_assoc_params(p, lw_dq, H, W, K, Kinv, lw_cam, scale, center, half, max_dist, knn);
         if (rc != DFH_OK) return rc;
     }
     dim3 grid((n_samples + 255) / 256), block(256);
+    const AssocView *vw = static_cast<const AssocView *>(views);
     if (depth_dtype == DFH_F32) {
         hipLaunchKernelGGL(associate_kernel<float>, grid, block, 0, (hipStream_t)stream, sample_pos, nbr, weights, n_samples,
-                           node_dq, (const float *)depth, p, corr_out, valid_out);
+                           node_dq, (const float *)depth, p, corr_out, valid_out, vw, n_views);
     } else {
         hipLaunchKernelGGL(associate_kernel<double>, grid, block, 0, (hipStream_t)stream, sample_pos, nbr, weights, n_samples,
-                           node_dq, (const double *)depth, p, corr_out, valid_out);
+                           node_dq, (const double *)depth, p, corr_out, valid_out, vw, n_views);
     }
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *weights, int n_samples, int knn,
+                     const double *node_dq, const double lw_dq[8], const void *depth, int depth_dtype, int H, int W,
+                     const double K[9], const double Kinv[9], const double lw_cam[12], double scale,
+                     const double center[3], double half, double max_dist, double *corr_out,
+                     unsigned char *valid_out, void *stream) {
+    return gn_associate_impl("dfh_gn_associate", sample_pos, nbr, weights, n_samples, knn, node_dq, lw_dq, depth, depth_dtype, nullptr, 0, H, W,
+                             K, Kinv, lw_cam, scale, center, half, max_dist, corr_out, valid_out, stream);
+}
+
+static const double kIdentity34[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+
+int dfh_gn_associate_views(const double *sample_pos, const int *nbr, const double *weights, int n_samples, int knn,
+                           const double *node_dq, const double lw_dq[8], const void *views, int n_views, int depth_dtype, int H, int W,
+                           const double K[9], const double Kinv[9], double scale, const double center[3], double half,
+                           double max_dist, double *corr_out, unsigned char *valid_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(views && n_views >= 1 && n_views <= DFH_GN_MAX_VIEWS, "dfh_gn_associate_views: needs 1..%d packed views", DFH_GN_MAX_VIEWS);
+    return gn_associate_impl("dfh_gn_associate_views", sample_pos, nbr, weights, n_samples, knn, node_dq, lw_dq, nullptr, depth_dtype, views,
+                             n_views, H, W, K, Kinv, kIdentity34, scale, center, half, max_dist, corr_out, valid_out, stream);
+}
+
+size_t dfh_gn_views_bytes(int n_views) { return n_views > 0 ? (size_t)n_views * sizeof(dfh::AssocView) : 0; }
+
+// The table travels as kernel arguments of a one-workgroup launch that writes it to device memory (a hipMemcpyAsync from
+// pageable host memory is staged by the runtime and stalls the stream for tens of microseconds)
+namespace dfh {
+constexpr int kViewChunk = 16;
+struct ViewChunk { AssocView v[kViewChunk]; };
+static_assert(sizeof(ViewChunk) + 16 <= 4096, "the chunk must fit the kernel-argument segment");
+__global__ __launch_bounds__(256) void upload_views_kernel(AssocView *dst, const ViewChunk c, int n) {
+    typedef const unsigned long long __attribute__((address_space(4))) *KernArgWords;
+    KernArgWords ka = (KernArgWords)__builtin_amdgcn_kernarg_segment_ptr() + 1;                                          // behind `dst`
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(dst);
+    const int words = n * (int)(sizeof(AssocView) / 8);
+    for (int i = threadIdx.x; i < words; i += 256) out[i] = ka[i];
+    (void)c;
+}
+}  // namespace dfh
+
+int dfh_gn_pack_views(void *views_out, int n_views, const void *const *depth, const double *lw_cam, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(views_out && depth && lw_cam, "dfh_gn_pack_views: null pointer");
+    DFH_REQUIRE(n_views >= 1 && n_views <= DFH_GN_MAX_VIEWS, "dfh_gn_pack_views: %d views (1..%d)", n_views, DFH_GN_MAX_VIEWS);
+    static_assert(DFH_GN_MAX_VIEWS <= kViewChunk, "one upload launch");
+    ViewChunk c;
+    std::memset(&c, 0, sizeof c);
+    for (int v = 0; v < n_views; ++v) {
+        DFH_REQUIRE(depth[v], "dfh_gn_pack_views: depth map %d is null", v);
+        AssocParams tmp;                                  // (for the inverse of the extrinsic's 3x3 part)
+        const double zero3[3] = {0, 0, 0}, eye9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ident8[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+        const int rc = fill_assoc_params(tmp, ident8, 2, 2, eye9, eye9, lw_cam + 12 * v, 1.0, zero3, 0.0, 0.0, 1);
+        if (rc != DFH_OK) return rc;
+        for (int i = 0; i < 12; ++i) c.v[v].lw_cam[i] = lw_cam[12 * v + i];
+        for (int i = 0; i < 9; ++i) c.v[v].Rinv[i] = tmp.Rinv.m[i];
+        c.v[v].depth = depth[v];
+    }
+    hipLaunchKernelGGL(upload_views_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<AssocView *>(views_out), c, n_views);
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }
@@ -2598,6 +2700,30 @@ static int fill_assoc_params(dfh::AssocParams &p, const double lw_dq[8], int H, 
     return DFH_OK;
 }
 
+static int gn_build_planned_assoc_impl(const char *what, const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                               double *corr_out, unsigned char *valid_out, int n_samples, int knn, const double *node_dq,
+                               const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                               const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                               double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                               const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                               const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                               const float *depth, const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
+                               const double lw_cam[12], double scale, const double center[3], double half, double max_dist, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(blk_ptr, "%s: null blk_ptr", what);
+    DFH_REQUIRE((depth || views) && K && Kinv && lw_cam && center && lw_dq && corr_out && valid_out, "%s: null pointer", what);
+    DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "%s: bad depth map / scale", what);
+    AssocArgs aa;
+    const int rc = fill_assoc_params(aa.ap, lw_dq, H, W, K, Kinv, lw_cam, scale, center, half, max_dist, knn);
+    if (rc != DFH_OK) return rc;
+    aa.depth = depth;
+    aa.views = static_cast<const AssocView *>(views);
+    aa.n_views = n_views;
+    return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
+                         n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
+                         blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream, &aa);
+}
+
 int dfh_gn_build_planned_assoc(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
                                double *corr_out, unsigned char *valid_out, int n_samples, int knn, const double *node_dq,
                                const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
@@ -2607,17 +2733,29 @@ int dfh_gn_build_planned_assoc(const double *sample_pos, const double *sample_nr
                                const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
                                const float *depth, int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12],
                                double scale, const double center[3], double half, double max_dist, void *stream) {
+    return gn_build_planned_assoc_impl("dfh_gn_build_planned_assoc", sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn,
+                                       node_dq, node_pos, node_w, node_nbr, n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count,
+                                       run_id, n_rows, partial, blk_ptr, blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent,
+                                       rnode_ptr, rnode_ent, huber_delta, depth, nullptr, 0, H, W, K, Kinv, lw_cam, scale, center, half,
+                                       max_dist, stream);
+}
+
+int dfh_gn_build_planned_assoc_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                               double *corr_out, unsigned char *valid_out, int n_samples, int knn, const double *node_dq,
+                               const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                               const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                               double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                               const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                               const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                               const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
+                               double scale, const double center[3], double half, double max_dist, void *stream) {
     using namespace dfh;
-    DFH_REQUIRE(blk_ptr, "dfh_gn_build_planned_assoc: null blk_ptr");
-    DFH_REQUIRE(depth && K && Kinv && lw_cam && center && lw_dq && corr_out && valid_out, "dfh_gn_build_planned_assoc: null pointer");
-    DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "dfh_gn_build_planned_assoc: bad depth map / scale");
-    AssocArgs aa;
-    const int rc = fill_assoc_params(aa.ap, lw_dq, H, W, K, Kinv, lw_cam, scale, center, half, max_dist, knn);
-    if (rc != DFH_OK) return rc;
-    aa.depth = depth;
-    return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
-                         n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
-                         blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream, &aa);
+    DFH_REQUIRE(views && n_views >= 1 && n_views <= DFH_GN_MAX_VIEWS, "dfh_gn_build_planned_assoc_views: needs 1..%d packed views", DFH_GN_MAX_VIEWS);
+    return gn_build_planned_assoc_impl("dfh_gn_build_planned_assoc_views", sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples,
+                                       knn, node_dq, node_pos, node_w, node_nbr, n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs,
+                                       cost_count, run_id, n_rows, partial, blk_ptr, blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr,
+                                       rblk_ent, rnode_ptr, rnode_ent, huber_delta, nullptr, views, n_views, H, W, K, Kinv, kIdentity34, scale,
+                                       center, half, max_dist, stream);
 }
 
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
@@ -2843,27 +2981,29 @@ int dfh_pcg_solve_update(const int *row_ptr, const int *col, double *vals, const
     return pcg_solve_impl(row_ptr, col, vals, rhs, n_nodes, iters, lm_abs, lm_rel, x_out, workspace, workspace_bytes, node_dq, step, stream);
 }
 
-int dfh_gn_iteration(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+static int gn_iteration_impl(const char *what, const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
                      double *corr_out, unsigned char *valid_out, int n_samples, int knn, double *node_dq,
                      const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
                      const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
                      double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
                      const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
                      const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
-                     const float *depth, int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12],
-                     double scale, const double center[3], double half, double max_dist,
+                     const float *depth, const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
+                     const double lw_cam[12], double scale, const double center[3], double half, double max_dist,
                      int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
                      double step, void *stream) {
     using namespace dfh;
-    DFH_REQUIRE(blk_ptr, "dfh_gn_iteration: null blk_ptr");
-    DFH_REQUIRE(depth && K && Kinv && lw_cam && center && lw_dq && corr_out && valid_out && node_dq, "dfh_gn_iteration: null pointer");
-    DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "dfh_gn_iteration: bad depth map / scale");
-    DFH_REQUIRE(n_nodes >= 1 && pcg_iters >= 1 && x_out && pcg_workspace, "dfh_gn_iteration: bad solve arguments");
-    DFH_REQUIRE(pcg_workspace_bytes >= dfh_pcg_workspace_bytes(n_nodes, pcg_iters), "dfh_gn_iteration: solve workspace too small");
+    DFH_REQUIRE(blk_ptr, "%s: null blk_ptr", what);
+    DFH_REQUIRE((depth || views) && K && Kinv && lw_cam && center && lw_dq && corr_out && valid_out && node_dq, "%s: null pointer", what);
+    DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "%s: bad depth map / scale", what);
+    DFH_REQUIRE(n_nodes >= 1 && pcg_iters >= 1 && x_out && pcg_workspace, "%s: bad solve arguments", what);
+    DFH_REQUIRE(pcg_workspace_bytes >= dfh_pcg_workspace_bytes(n_nodes, pcg_iters), "%s: solve workspace too small", what);
     AssocArgs aa;
     int rc = fill_assoc_params(aa.ap, lw_dq, H, W, K, Kinv, lw_cam, scale, center, half, max_dist, knn);
     if (rc != DFH_OK) return rc;
     aa.depth = depth;
+    aa.views = static_cast<const AssocView *>(views);
+    aa.n_views = n_views;
     double *zbegin = nullptr;
     size_t zcount = 0;
     pcg_zero_range(pcg_workspace, n_nodes, pcg_iters, &zbegin, &zcount);
@@ -2875,6 +3015,44 @@ int dfh_gn_iteration(const double *sample_pos, const double *sample_nrm, const i
     if (rc != DFH_OK) return rc;
     return pcg_solve_impl(row_ptr, col, vals, rhs, n_nodes, pcg_iters, lm_abs, lm_rel, x_out, pcg_workspace, pcg_workspace_bytes, node_dq,
                           step, stream, zeroed);
+}
+
+int dfh_gn_iteration(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                     double *corr_out, unsigned char *valid_out, int n_samples, int knn, double *node_dq,
+                     const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                     const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                     double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                     const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                     const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                     const float *depth, int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12],
+                     double scale, const double center[3], double half, double max_dist,
+                     int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
+                     double step, void *stream) {
+    return gn_iteration_impl("dfh_gn_iteration", sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos,
+                             node_w, node_nbr, n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
+                             blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, depth, nullptr, 0,
+                             H, W, K, Kinv, lw_cam, scale, center, half, max_dist, pcg_iters, lm_abs, lm_rel, x_out, pcg_workspace,
+                             pcg_workspace_bytes, step, stream);
+}
+
+int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                     double *corr_out, unsigned char *valid_out, int n_samples, int knn, double *node_dq,
+                     const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                     const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                     double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                     const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                     const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                     const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
+                     double scale, const double center[3], double half, double max_dist,
+                     int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
+                     double step, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(views && n_views >= 1 && n_views <= DFH_GN_MAX_VIEWS, "dfh_gn_iteration_views: needs 1..%d packed views", DFH_GN_MAX_VIEWS);
+    return gn_iteration_impl("dfh_gn_iteration_views", sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq,
+                             node_pos, node_w, node_nbr, n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial,
+                             blk_ptr, blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, nullptr,
+                             views, n_views, H, W, K, Kinv, kIdentity34, scale, center, half, max_dist, pcg_iters, lm_abs, lm_rel, x_out,
+                             pcg_workspace, pcg_workspace_bytes, step, stream);
 }
 
 int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream) {

@@ -210,7 +210,7 @@ class SlabFrame:
         return n_new
 
     def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5, stage_ms=None,
-             update_graph=False, on_updated=None):
+             update_graph=False, on_updated=None, data_views=None):
         """Defaults (regulariser weight, LM damping, association gate and Huber threshold in voxels) are the ones under which the loop tracks
         a +-0.5 voxel oscillation of the bench scene for hundreds of frames without drift (tools/soak.py); with a 4-voxel
         gate and weak damping, nodes without data support wander and the TSDF update then corrupts the canonical volume.
@@ -230,12 +230,16 @@ class SlabFrame:
                 t0[0] = now
         R = self.R
         # `depth` / `lw_cam` may be lists: the live volume is then fused from all of them (as the reference's
-        # compute_live_tsdf does, core/fusion_dm.py:166-170); the warp solve associates against the first one
+        # compute_live_tsdf does, core/fusion_dm.py:166-170) and the warp solve associates every sample against all of them
+        # (the view in which it lies closest to the observed surface: dfh_gn_associate_views; data_views=1 keeps round 2's
+        # first-view-only data term)
         depth_list = list(depth) if isinstance(depth, (list, tuple)) else [depth]
         lw_list = list(lw_cam) if isinstance(depth, (list, tuple)) else [lw_cam]
         if len(depth_list) != len(lw_list):
             raise ValueError('length of camera matrix array must equal that of depth maps')
         depth, lw_cam = depth_list[0], lw_list[0]
+        nd = len(depth_list) if data_views is None else max(1, min(int(data_views), len(depth_list)))
+        solve_depth, solve_lw = (depth_list[:nd], lw_list[:nd]) if nd > 1 else (depth, lw_cam)
         def sweep_live():
             if self.ws_views is None:
                 self.ws_views = kernels.integrate_workspace(min(len(depth_list), 16), depth.shape[0], depth.shape[1], (R, R, R), (self.a, self.b), self.live.device)
@@ -260,7 +264,7 @@ class SlabFrame:
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
         mark("allgather")
         for _ in range(gn_iters):
-            self.fs.gn_iteration(depth, lw_cam, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist, huber=huber)
+            self.fs.gn_iteration(solve_depth, solve_lw, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist, huber=huber)
         mark("solve")
         sv = self.fs.solver
         kernels.fuse_volume_dqb(self.T, self.Wt, live_full, sv.node_pos, sv.node_dq, sv.node_w, self.knn, self.ident_lw, self.tvox,

@@ -10,6 +10,8 @@ node tuple, unique node pairs); every per-iteration step is a HIP kernel behind 
 """
 import os
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -532,8 +534,54 @@ class WarpSolver:
             v = v.to(device="cuda", dtype=torch.uint8)
             self.valid = v[self._order_index()].contiguous() if self.order is not None else v.contiguous()
 
+    # -- several live views -----------------------------------------------------------------
+    @staticmethod
+    def _one_or_many(depth, lw_cam):
+        """(depth, lw_cam) of a single view, or (list of depths, list of extrinsics) with more than one entry."""
+        if isinstance(depth, (list, tuple)):
+            depths, lws = list(depth), list(lw_cam)
+            if len(depths) != len(lws) or not depths:
+                raise ValueError('length of camera matrix array must equal that of depth maps')
+            if len(depths) == 1:
+                return depths[0], lws[0], False
+            return depths, lws, True
+        return depth, lw_cam, False
+
+    def _views_table(self, depths, lw_cams):
+        """Device table of a frame's views (dfh_gn_pack_views: extrinsics, their inverses, depth pointers), rebuilt only when
+        the depth tensors or the extrinsics change (a frame's iterations share it).  Returns (table, n_views, H, W)."""
+        for d in depths:
+            if not (isinstance(d, torch.Tensor) and d.is_cuda and d.dim() == 2 and d.is_contiguous()):
+                raise ValueError("depth must be a contiguous 2-D CUDA tensor")
+            if d.shape != depths[0].shape or d.dtype != depths[0].dtype:
+                raise ValueError("the depth maps of one frame must share a shape and a dtype")
+        n = len(depths)
+        lw = np.ascontiguousarray(np.stack([np.asarray(m, dtype=np.float64).reshape(12) for m in lw_cams]))
+        key = (tuple(int(d.data_ptr()) for d in depths), lw.tobytes(), current_stream_ptr())
+        if getattr(self, "_views_key", None) != key:
+            nbytes = self.lib.dfh_gn_views_bytes(n)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            ptrs = (ctypes.c_void_p * n)(*[int(d.data_ptr()) for d in depths])
+            _lib.check(self.lib.dfh_gn_pack_views(buf.data_ptr(), n, ptrs, lw.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                  current_stream_ptr()), "dfh_gn_pack_views")
+            self._views_key, self._views_buf, self._views_keep = key, buf, list(depths)
+        H, W = depths[0].shape
+        return self._views_buf, n, int(H), int(W)
+
     def associate_depth(self, depth, K, Kinv, lw_cam, scale, center, half, lw_dq, max_dist=0.0):
-        """Projective association of the warped samples against a live depth map (CUDA tensor)."""
+        """Projective association of the warped samples against a live depth map (CUDA tensor) -- or against several
+        (lists of depth maps and extrinsics): each sample keeps the correspondence of the view in which it lies closest to
+        the observed surface (dfh_gn_associate_views)."""
+        depth, lw_cam, many = self._one_or_many(depth, lw_cam)
+        if many:
+            tab, n, H, W = self._views_table(depth, lw_cam)
+            _lib.check(self.lib.dfh_gn_associate_views(self.spos.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.S, self.knn,
+                                                       self.node_dq.data_ptr(), _lib.darr(lw_dq, 8), tab.data_ptr(), n, dtype_code(depth[0]),
+                                                       H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
+                                                       _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist),
+                                                       self.corr.data_ptr(), self.valid.data_ptr(), current_stream_ptr()),
+                       "dfh_gn_associate_views")
+            return
         if not (isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dim() == 2 and depth.is_contiguous()):
             raise ValueError("depth must be a contiguous 2-D CUDA tensor")
         H, W = depth.shape
@@ -579,13 +627,32 @@ class WarpSolver:
         for bit; float32 depth maps and the planned build only (otherwise the two calls are made)."""
         if self._pattern is None:
             self._build_pattern()
-        fused = (isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dim() == 2 and depth.is_contiguous() and
-                 depth.dtype == torch.float32 and self.S > 0 and not os.environ.get("DFH_GN_ATOMIC") and not os.environ.get("DFH_GN_NO_FUSED_ASSOC"))
+        depth, lw_cam, many = self._one_or_many(depth, lw_cam)
+        d0 = depth[0] if many else depth
+        fused = (isinstance(d0, torch.Tensor) and d0.is_cuda and d0.dim() == 2 and d0.is_contiguous() and
+                 d0.dtype == torch.float32 and self.S > 0 and not os.environ.get("DFH_GN_ATOMIC") and not os.environ.get("DFH_GN_NO_FUSED_ASSOC"))
         if not fused:
             self.associate_depth(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, max_dist)
             return self.build(lw_dq, rw, huber)
         reg_here = (not self.distributed) or _dist.world()[0] == 0
         nn = 0 if (self.node_nbr is None or rw == 0.0 or not reg_here) else self.node_nbr.data_ptr()
+        if many:
+            tab, nv, H, W = self._views_table(depth, lw_cam)
+            _lib.check(self.lib.dfh_gn_build_planned_assoc_views(
+                self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.corr.data_ptr(),
+                self.valid.data_ptr(), self.S, self.knn, self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(),
+                nn, self.N, _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
+                self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(), self.run_id.data_ptr(), self.n_rows,
+                self.partial.data_ptr(), self.blk_ptr.data_ptr(), self.blk_ent.data_ptr(), self.node_ptr.data_ptr(),
+                self.node_ent.data_ptr(), *((self.partial_reg.data_ptr(), self.rblk_ptr.data_ptr(), self.rblk_ent.data_ptr(),
+                                             self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
+                                            if self.partial_reg is not None else (0, 0, 0, 0, 0)),
+                float(huber), tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
+                _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), current_stream_ptr()),
+                "dfh_gn_build_planned_assoc_views")
+            if self.distributed:
+                _dist.allreduce_system(self.system)
+            return
         H, W = depth.shape
         _lib.check(self.lib.dfh_gn_build_planned_assoc(
             self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.corr.data_ptr(),
@@ -607,14 +674,32 @@ class WarpSolver:
         dfh_gn_iteration, one call in which the clearing of the solve's workspace rides in the data-row launch: same bits."""
         if self._pattern is None:
             self._build_pattern()
-        one_call = (isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dim() == 2 and depth.is_contiguous() and
-                    depth.dtype == torch.float32 and self.S > 0 and not os.environ.get("DFH_GN_ATOMIC") and
+        depth, lw_cam, many = self._one_or_many(depth, lw_cam)
+        d0 = depth[0] if many else depth
+        one_call = (isinstance(d0, torch.Tensor) and d0.is_cuda and d0.dim() == 2 and d0.is_contiguous() and
+                    d0.dtype == torch.float32 and self.S > 0 and not os.environ.get("DFH_GN_ATOMIC") and
                     not os.environ.get("DFH_GN_NO_FUSED_ASSOC") and not os.environ.get("DFH_GN_NO_FUSED_ITER") and
                     not (self.distributed and _dist.world()[1] > 1))
         if not one_call:
             self.build_associated(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist, huber)
             return self.solve_update(lm_abs, lm_rel)
         nn = 0 if (self.node_nbr is None or rw == 0.0) else self.node_nbr.data_ptr()
+        if many:
+            tab, nv, H, W = self._views_table(depth, lw_cam)
+            _lib.check(self.lib.dfh_gn_iteration_views(
+                self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.corr.data_ptr(),
+                self.valid.data_ptr(), self.S, self.knn, self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(),
+                nn, self.N, _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
+                self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(), self.run_id.data_ptr(), self.n_rows,
+                self.partial.data_ptr(), self.blk_ptr.data_ptr(), self.blk_ent.data_ptr(), self.node_ptr.data_ptr(),
+                self.node_ent.data_ptr(), *((self.partial_reg.data_ptr(), self.rblk_ptr.data_ptr(), self.rblk_ent.data_ptr(),
+                                             self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
+                                            if self.partial_reg is not None else (0, 0, 0, 0, 0)),
+                float(huber), tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
+                _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist),
+                self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(), self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, 1.0,
+                current_stream_ptr()), "dfh_gn_iteration_views")
+            return
         H, W = depth.shape
         _lib.check(self.lib.dfh_gn_iteration(
             self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.corr.data_ptr(),

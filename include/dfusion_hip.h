@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DFH_ABI_VERSION 2
+#define DFH_ABI_VERSION 3
 
 #define DFH_F32 0
 #define DFH_F64 1
@@ -261,6 +261,23 @@ int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *wei
                      const double center[3], double half, double max_dist, double *corr_out,
                      unsigned char *valid_out, void *stream);
 
+/* Association against SEVERAL live views (BASELINE config 5: the live frame is eight depth maps).  Every view is tried in
+ * turn with the arithmetic of dfh_gn_associate; a sample keeps the correspondence of the view in which it lies closest to
+ * the observed surface (smallest |c - x'| among the views where it is valid; max_dist gates every view; ties go to the lower
+ * view index), so it still contributes ONE data row and the block pattern / plan do not depend on the number of views.  One
+ * view gives dfh_gn_associate's result bit for bit.  No reference counterpart (its correspondences are mesh-to-mesh,
+ * core/fusion.py:255-276; its view loop is the TSDF fusion's, core/fusion_dm.py:166-170); oracle: gn_np.associate_depth_views.
+ *   dfh_gn_pack_views writes the views' table (extrinsics, their inverses, depth pointers) into `views_out`, a device buffer
+ *   of dfh_gn_views_bytes(n_views) bytes: once per frame; depth[v]: device pointers to H x W maps of one dtype; lw_cam: 12
+ *   doubles per view (host).  The *_views calls take that table instead of (depth, lw_cam). */
+#define DFH_GN_MAX_VIEWS 16
+size_t dfh_gn_views_bytes(int n_views);
+int dfh_gn_pack_views(void *views_out, int n_views, const void *const *depth, const double *lw_cam, void *stream);
+int dfh_gn_associate_views(const double *sample_pos, const int *nbr, const double *weights, int n_samples, int knn,
+                           const double *node_dq, const double lw_dq[8], const void *views, int n_views, int depth_dtype, int H, int W,
+                           const double K[9], const double Kinv[9], double scale, const double center[3], double half,
+                           double max_dist, double *corr_out, unsigned char *valid_out, void *stream);
+
 /* Gauss-Newton normal equations of 0.5*|computef|^2 in 6-DoF left twists (dq_a <- exp(xi_a) (x) dq_a):
  * vals (n_blocks x 36, block-sparse rows row_ptr/col with sorted columns) <- J^T J, rhs (6 n_nodes) <-
  * J^T r, cost_count[0] <- 0.5 |r|^2, cost_count[1] <- number of valid samples.  Data rows use the static
@@ -362,6 +379,29 @@ int dfh_gn_iteration(const double *sample_pos, const double *sample_nrm, const i
                      const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
                      const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
                      const float *depth, int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12],
+                     double scale, const double center[3], double half, double max_dist,
+                     int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
+                     double step, void *stream);
+
+/* dfh_gn_build_planned_assoc / dfh_gn_iteration with the association of dfh_gn_associate_views (float32 depth maps): the same
+ * arguments with (views, n_views) in place of (depth, lw_cam). */
+int dfh_gn_build_planned_assoc_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                               double *corr_out, unsigned char *valid_out, int n_samples, int knn, const double *node_dq,
+                               const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                               const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                               double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                               const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                               const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                               const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
+                               double scale, const double center[3], double half, double max_dist, void *stream);
+int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                     double *corr_out, unsigned char *valid_out, int n_samples, int knn, double *node_dq,
+                     const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                     const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                     double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                     const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                     const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                     const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
                      double scale, const double center[3], double half, double max_dist,
                      int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
                      double step, void *stream);

@@ -241,6 +241,28 @@ def associate_depth(points_idx, K, Kinv, lw_cam, dm, scale, center, half):
     return np.where(valid[:, None], cidx, 0.0), valid
 
 
+def associate_depth_views(points_idx, K, Kinv, lw_cams, dms, scale, center, half, max_dist=0.0):
+    """Association against several live views (the device's dfh_gn_associate_views; no reference counterpart): every view is
+    tried with associate_depth, a point keeps the correspondence of the view in which it lies closest to the observed surface
+    -- smallest |c - x'| among the views where it is valid and (max_dist > 0) within the gate; ties go to the lower view
+    index.  Returns (corr_idx (S,3), valid (S,), chosen view (S,), -1 where invalid)."""
+    P = np.asarray(points_idx, dtype=np.float64)
+    best = np.full(len(P), np.inf)
+    corr = np.zeros_like(P)
+    view = np.full(len(P), -1, dtype=np.int64)
+    for v, (lw_cam, dm) in enumerate(zip(lw_cams, dms)):
+        c, ok = associate_depth(P, K, Kinv, np.asarray(lw_cam, dtype=np.float64), dm, scale, center, half)
+        d = c - P
+        d2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]
+        if max_dist > 0:
+            ok = ok & (d2 <= max_dist * max_dist)
+        take = ok & (d2 < best)
+        best = np.where(take, d2, best)
+        corr = np.where(take[:, None], c, corr)
+        view = np.where(take, v, view)
+    return corr, view >= 0, view
+
+
 # ---------------------------------------------------------------- block-sparse assembly + truncated PCG
 # (what the HIP build ships: csrc/dfh_solve.hip gn_build_* + pcg_cg1_kernel).  Same algorithm as assemble_dense
 # + a dense solve, but sized for BASELINE configs 3/4 (512 / 2 048 nodes, 1e5..1e6 samples) and with the SAME

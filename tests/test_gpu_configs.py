@@ -212,7 +212,7 @@ def test_config5_thirty_frame_sequence():
     n0 = sf.refresh_samples()
     assert n0 > 400000
     amp = np.array([0.8, -0.5, 0.4])                                 # voxels
-    front = node_pos[:, 2] < R / 2 - 0.25 * (scene.SPHERE_R / scale)  # nodes facing camera 0, the view the solve associates against
+    front = node_pos[:, 2] < R / 2 - 0.25 * (scene.SPHERE_R / scale)  # nodes facing camera 0
     counts, tmax, err_front = [], [], []
     for t in range(30):
         off_vox = amp * np.sin(2 * np.pi * (t + 1) / 30.0)
@@ -238,3 +238,71 @@ def test_config5_thirty_frame_sequence():
     assert max(counts) < 1.7 * min(counts)
     cost, cnt = sf.fs.solver.cost()
     assert np.isfinite(cost) and cnt > 50000
+    # the data term sees ALL eight views (round 2: the first only): with one view the samples camera 0 cannot see -- the far
+    # side of the sphere, two thirds of the surface -- had no data row at all
+    sv = sf.fs.solver
+    half = R / 2
+    sv.associate_depth(ds[0], sf.K, sf.Kinv, lws[0], sf.scale, sf.center, half, sf.fs.lw, 2.0)
+    n_one = int(sv.valid.sum())
+    sv.associate_depth(ds, sf.K, sf.Kinv, lws, sf.scale, sf.center, half, sf.fs.lw, 2.0)
+    n_all = int(sv.valid.sum())
+    print("config5: valid samples against view 0 only %d, against all 8 views %d (of %d)" % (n_one, n_all, sv.S))
+    assert n_all > 2 * n_one and cnt >= 0.9 * n_all
+
+
+def test_multi_view_association_and_gn_loop_vs_oracle():
+    """Data term over several live views (dfh_gn_associate_views / dfh_gn_iteration_views) at R = 64, three views 50 degrees
+    apart: the chosen correspondences (closest valid view, ties to the lower index) equal oracle/gn_np.associate_depth_views',
+    one view through the same entry points equals dfh_gn_associate bit for bit, and six GN iterations with the benched
+    settings follow the CPU loop (same truncated PCG) to 1e-4 relative in cost at every iteration -- with MORE valid samples
+    than any single view gives."""
+    R, N, iters = 64, 96, 6
+    rw, lm_abs, lm_rel, max_dist, huber, pcg_iters = 5.0, 10.0, 1e-2, 2.0, 0.5, 10
+    K, Kinv, (H, W), scale, center, tdist, T, Wt = canonical(R, "C1", angles=(0.0, 50.0, -50.0, 130.0, -130.0))
+    fs = FrameSolver(K, scale, center, R / 2, knn=4, pcg_iters=pcg_iters, distributed=False)
+    node_pos, node_w = scene.fibonacci_nodes(N, R)
+    ident = np.tile(IDENT, (N, 1))
+    fs.set_graph(node_pos, ident, node_w)
+    S = fs.set_canonical(T, Wt, band=3.0)
+    assert S > 3000
+    off = np.array([0.5, -0.35, 0.25]) * scale
+    lws = [scene.view_extrinsic(a) for a in (0.0, 50.0, -50.0)]
+    lives = [scene.render_depth(K, lw, H, W, dtype=np.float32, sphere_offset=off, sphere_r=scene.SPHERE_R * 1.02) for lw in lws]
+    depths = [torch.from_numpy(d).cuda() for d in lives]
+    sv = fs.solver
+    pos, nrm, nbr, node_nbr = host_arrays(sv)
+    from oracle import oracle_np as O
+    # association alone, off the identity
+    rng = np.random.default_rng(11)
+    dq0 = G.apply_twists(ident, rng.normal(scale=[2e-3] * 3 + [0.15] * 3, size=(N, 6)))
+    sv.node_dq.copy_(torch.from_numpy(dq0).cuda())
+    warped = O.warp(pos, dq0[nbr], node_pos[nbr], node_w[nbr], m_lw=IDENT)
+    sv.associate_depth(depths, K, Kinv, lws, scale, center, R / 2, fs.lw, max_dist)
+    co, vo, view = G.associate_depth_views(warped, K, Kinv, lws, lives, scale, center, R / 2, max_dist)
+    assert np.array_equal(sv.valid.cpu().numpy().astype(bool), vo)
+    assert np.abs(sv.corr.cpu().numpy() - co).max() <= 1e-9
+    per_view = []
+    for d, lw in zip(depths, lws):
+        sv.associate_depth(d, K, Kinv, lw, scale, center, R / 2, fs.lw, max_dist)
+        per_view.append((sv.corr.clone(), sv.valid.clone()))
+        sv.associate_depth([d], K, Kinv, [lw], scale, center, R / 2, fs.lw, max_dist)      # one view as a list: same entry point as before
+        assert torch.equal(sv.corr, per_view[-1][0]) and torch.equal(sv.valid, per_view[-1][1])
+    assert int(vo.sum()) > max(int(v.sum()) for _, v in per_view) and len(set(view[vo])) == 3
+    # the GN loop on all three views against the CPU loop
+    sv.node_dq.copy_(torch.from_numpy(ident).cuda())
+
+    def assoc(w):
+        c, v, _ = G.associate_depth_views(w, K, Kinv, lws, lives, scale, center, R / 2, max_dist)
+        return c, v
+    gpu_costs, gpu_counts = [], []
+    for _ in range(iters):
+        fs.gn_iteration(depths, lws, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist, huber=huber)
+        c, n = sv.cost()
+        gpu_costs.append(c); gpu_counts.append(n)
+    or_costs, or_counts, dq_or = G.gn_loop_truncated(ident, pos, nrm, nbr, node_nbr, node_pos, node_w, IDENT, assoc, iters, rw,
+                                                    lm_abs, lm_rel, huber, pcg_iters)
+    rel = np.abs(np.array(gpu_costs) - np.array(or_costs)) / np.array(or_costs)
+    assert rel.max() <= 1e-4, (gpu_costs, or_costs)
+    assert max(abs(a - b) for a, b in zip(gpu_counts, or_counts)) <= 3
+    assert np.abs(sv.node_dq.cpu().numpy() - dq_or).max() <= 1e-5
+    assert gpu_costs[-1] / gpu_counts[-1] < gpu_costs[0] / gpu_counts[0]

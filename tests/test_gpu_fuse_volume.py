@@ -286,3 +286,48 @@ def test_dqb_config3_scale_properties():
     T3, W3 = torch.full_like(T, tdist), torch.ones_like(T)
     kernels.fuse_volume_dqb(T3, W3, live, node_pos, node_dq, node_w, k, ident, tdist)
     assert torch.equal(T3, T) and torch.equal(W3, W)           # deterministic
+
+
+@pytest.mark.parametrize("field", ["random", "identity"])
+def test_dqb_float32_paths_give_the_same_bits(field):
+    """float32 volumes, knn = 4: the fast path in every mode -- search every call, search + store, stored neighbourhoods on
+    the persistent LDS kernel (undecidable voxels deferred to the redo list) and on the plain kernel -- gives the same bits;
+    the fp64 chain on the same volumes (option k3_exact) gives the same update mask and values within one float32 rounding.
+    `identity`: every sample lands on a lattice point, i.e. EVERY voxel takes the exact chain (all of them go through the
+    redo list of the LDS kernel)."""
+    from dynamicfusion_body_amd import _lib
+    from dynamicfusion_body_amd.dq import twist_exp_dq
+    R, N, k, tdist = 64, 150, 4, 3.0
+    g = torch.arange(R, device="cuda", dtype=torch.float32)
+    d = torch.sqrt((g[:, None, None] - R / 2) ** 2 + (g[None, :, None] - R / 2) ** 2 + (g[None, None, :] - R / 2) ** 2)
+    live = torch.clamp(d - 0.3125 * R + 0.7, -1.5 * tdist, 1.5 * tdist).contiguous()
+    T0 = torch.clamp(d - 0.3125 * R, -tdist, tdist).contiguous()
+    W0 = (torch.rand((R, R, R), device="cuda") < 0.7).float() * 2.0           # (zeros: the first-touch rule)
+    rng = np.random.default_rng(5)
+    node_pos, node_w = scene.fibonacci_nodes(N, R)
+    if field == "random":
+        dqs = twist_exp_dq(rng.normal(size=(N, 6)) * np.array([.02, .02, .02, .4, .4, .4]))
+        lw = twist_exp_dq(np.array([0.01, -0.02, 0.015, 0.3, -0.2, 0.1]))
+    else:
+        dqs = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
+        lw = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+
+    def run(ws, rebuild, opts=()):
+        for o in opts:
+            _lib.set_option(o, 1)
+        T, W = T0.clone(), W0.clone()
+        kernels.fuse_volume_dqb(T, W, live, node_pos, dqs, node_w, k, lw, tdist, 9.0, workspace=ws, rebuild_candidates=rebuild)
+        torch.cuda.synchronize()
+        for o in opts:
+            _lib.set_option(o, None)
+        return T, W
+    ref = run(kernels.dqb_workspace((R, R, R)), True)
+    ws2 = kernels.dqb_workspace((R, R, R), knn=k, n_nodes=N, level=2)
+    for name, out in (("search + store", run(ws2, True)), ("stored, LDS kernel", run(ws2, False)), ("stored, LDS kernel again", run(ws2, False)),
+                      ("stored, plain kernel", run(ws2, False, ("k3_no_lds",)))):
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), name
+    ex = run(kernels.dqb_workspace((R, R, R)), True, ("k3_exact",))
+    assert torch.equal((ex[0] != T0) | (ex[1] != W0), (ref[0] != T0) | (ref[1] != W0))
+    assert float(((ex[0] - ref[0]).abs() / (1 + ref[0].abs())).max()) <= f32_tol(1)
+    assert float(((ex[1] - ref[1]).abs() / (1 + ref[1].abs())).max()) <= f32_tol(1)
+    assert int(((ref[0] != T0) | (ref[1] != W0)).sum()) > 10000

@@ -98,6 +98,9 @@ def test_frame_loop_inserts_nodes_where_the_graph_has_none():
     T1, W1 = sf.T.clone(), sf.Wt.clone()
     T2, W2 = sf.T.clone(), sf.Wt.clone()
     live = sf.live.clone()
+    if sf._first:                                # the last frame still inserted a node: its workspace is new, nothing stored in it yet
+        Ts, Ws = sf.T.clone(), sf.Wt.clone()
+        kernels.fuse_volume_dqb(Ts, Ws, live, sv.node_pos, sv.node_dq, sv.node_w, 4, sf.ident_lw, sf.tvox, workspace=sf.ws_dqb, rebuild_candidates=True)
     kernels.fuse_volume_dqb(T1, W1, live, sv.node_pos, sv.node_dq, sv.node_w, 4, sf.ident_lw, sf.tvox, workspace=sf.ws_dqb, rebuild_candidates=False)
     kernels.fuse_volume_dqb(T2, W2, live, sv.node_pos, sv.node_dq, sv.node_w, 4, sf.ident_lw, sf.tvox)
     assert torch.equal(T1, T2) and torch.equal(W1, W2)

@@ -60,6 +60,7 @@ def parse():
                                                                    "rank 0 prints the line without them and every rank leaves (0 = off)")
     ap.add_argument("--no-frame", action="store_true", help="skip the end-to-end per-frame leg")
     ap.add_argument("--gn-nodes", type=int, default=512)
+    ap.add_argument("--gn-mode", default="auto", choices=("auto", "sharded", "replicated"), help="N > 1: how the warp solve runs")
     ap.add_argument("--gn-solves", type=int, default=5, help="timed solves of 10 GN iterations each")
     return ap.parse_args()
 
@@ -86,20 +87,28 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
         d = torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0)).cuda()
         kernels.integrate_depth(T, Wt, d, K, Kinv, lw, scale, center, tdist)
     N, k, iters = args.gn_nodes, 4, 10
-    fs = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=10)
     node_pos, node_w = scene.fibonacci_nodes(N, R)
     ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
+    # Several GPUs: the solve runs sharded (every rank builds the normal equations of its slab's samples, one all-reduce per
+    # iteration: BASELINE north star) or replicated (every rank solves the whole system on all samples, no per-iteration
+    # collective), whichever dist.solve_mode's latency model predicts faster (--gn-mode forces); DESIGN.md section 6.
+    band_voxels = int(((Wt > 0) & (T.abs() < tdist)).sum().item()) if world > 1 else 0       # ~ the sample count (band = 4 voxels = tdist)
+    mode = "replicated" if world == 1 else (args.gn_mode if args.gn_mode != "auto" else D.solve_mode(max(band_voxels, 1), N, 12 * N, world))
+    fs = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=10, distributed=(world > 1 and mode == "sharded"))
     fs.set_graph(node_pos, ident, node_w)
     a, b = D.slab_range(R, rank, world)
-    # this rank's samples; normals are central differences across the slab faces too: one halo plane each side with
-    # weight 0 (gradients only), so the union over ranks is the single-GPU sample set
-    lo, hi = max(a - 1, 0), min(b + 1, R)
-    Wp = Wt[lo:hi].clone()
-    if lo < a:
-        Wp[0] = 0
-    if hi > b:
-        Wp[-1] = 0
-    S = fs.set_canonical(T[lo:hi].contiguous(), Wp, band=4.0, x0=lo)
+    if mode == "sharded":
+        # this rank's samples; normals are central differences across the slab faces too: one halo plane each side with
+        # weight 0 (gradients only), so the union over ranks is the single-GPU sample set
+        lo, hi = max(a - 1, 0), min(b + 1, R)
+        Wp = Wt[lo:hi].clone()
+        if lo < a:
+            Wp[0] = 0
+        if hi > b:
+            Wp[-1] = 0
+        S = fs.set_canonical(T[lo:hi].contiguous(), Wp, band=4.0, x0=lo)
+    else:
+        S = fs.set_canonical(T, Wt, band=4.0)            # (in the frame loop: the slabs' samples all-gathered once per frame)
     lw_cam = scene.view_extrinsic(0.0)
     live = scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=np.array([0.6, -0.4, 0.3]) * scale,
                               sphere_r=scene.SPHERE_R * 1.02)
@@ -124,8 +133,9 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
     launch = "eager"
     dt = dt_eager
     graph_ms = None
-    # one solve captured as a HIP graph and replayed (single GPU only: no collective inside a capture)
-    if world == 1 and not os.environ.get("DFH_NO_GRAPH"):
+    # one solve captured as a HIP graph and replayed.  Sharded solves hold an all-reduce per iteration: RCCL collectives can be
+    # captured (tools/rccl_sanity.py: a live communicator inside a capture); gloo's cannot, a failed capture keeps the eager number
+    if (world == 1 or mode == "replicated" or dist.get_backend() == "nccl") and not os.environ.get("DFH_NO_GRAPH"):
         try:
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
@@ -150,8 +160,8 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
             launch = "eager (graph capture failed: %s)" % str(e)[:80]
     dt = D.max_over_ranks([dt])[0]
     cost, cnt = sv.cost()
-    tot = torch.tensor([float(S)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    tot = torch.tensor([float(S)], dtype=torch.float64, device="cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu")
+    if world > 1 and mode == "sharded":
         dist.all_reduce(tot)
     A = int(tot.item())
     B = sv.B
@@ -175,6 +185,11 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
     return {**oracle, "gn_iters_per_s": n_it / dt, "ms_per_gn_iter": dt / n_it * 1e3, "gn_iters_per_solve": iters,
             "solves_timed": args.gn_solves, "active_samples": A, "nodes": N, "knn": k, "blocks_6x6": B,
             "pcg_iters": sv.pcg_iters, "scaling": "strong" if world > 1 else "n/a", "launch": launch,
+            "solve_mode": mode if world > 1 else "single GPU",
+            "solve_mode_note": None if world == 1 else "sharded = slab samples + one all-reduce of the upper block triangle per iteration; "
+                               "replicated = every rank solves the whole system (no per-iteration collective); chosen by "
+                               "dynamicfusion_body_amd.dist.solve_mode, a latency model whose collective term is an estimate "
+                               "(no multi-GPU node was available while this was written)",
             "eager_ms_per_gn_iter": dt_eager / n_it * 1e3, "graph_ms_per_gn_iter": graph_ms, "host_issue_ms_per_gn_iter": t_issue / n_it * 1e3,
             "final_cost": cost, "valid_samples_rank0": cnt,
             "hbm_bytes_per_iter_algorithmic": alg, "hbm_GBps_algorithmic": alg / (dt / n_it) / 1e9,
@@ -184,7 +199,8 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
                      "MFMA pipe busy 3.57 M cycles per launch, LDS bank conflicts 14 % of LDS cycles; gather moves 46 MB for 22 MB of live "
                      "sub-blocks; PCG iteration 3.0 us of which ~1.8 us hand-off",
             "workload": "%d^3 canonical volume, %d-node warp field, DQB warp + projective association + %d GN "
-                        "iterations per solve (fp64), samples sharded by axis-0 slab" % (R, N, iters)}
+                        "iterations per solve (fp64), %s" % (R, N, iters, "samples sharded by axis-0 slab" if mode == "sharded" else
+                                                           "all samples on every rank")}
 
 
 def frame_leg(args, torch, dist, scene, rank, world, barrier):

@@ -3045,14 +3045,74 @@ int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, c
                      const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
                      double scale, const double center[3], double half, double max_dist,
                      int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
-                     double step, void *stream) {
+                     double step, int n_iters, void *stream) {
     using namespace dfh;
     DFH_REQUIRE(views && n_views >= 1 && n_views <= DFH_GN_MAX_VIEWS, "dfh_gn_iteration_views: needs 1..%d packed views", DFH_GN_MAX_VIEWS);
-    return gn_iteration_impl("dfh_gn_iteration_views", sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq,
-                             node_pos, node_w, node_nbr, n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial,
-                             blk_ptr, blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, nullptr,
-                             views, n_views, H, W, K, Kinv, kIdentity34, scale, center, half, max_dist, pcg_iters, lm_abs, lm_rel, x_out,
-                             pcg_workspace, pcg_workspace_bytes, step, stream);
+    DFH_REQUIRE(n_iters >= 0 && n_iters <= 1000, "dfh_gn_iteration_views: %d iterations", n_iters);
+    // the frame's iterations are queued back to back from here: nothing between them depends on the host
+    for (int it = 0; it < n_iters; ++it) {
+        const int rc = gn_iteration_impl("dfh_gn_iteration_views", sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq,
+                                         node_pos, node_w, node_nbr, n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows,
+                                         partial, blk_ptr, blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent,
+                                         huber_delta, nullptr, views, n_views, H, W, K, Kinv, kIdentity34, scale, center, half, max_dist,
+                                         pcg_iters, lm_abs, lm_rel, x_out, pcg_workspace, pcg_workspace_bytes, step, stream);
+        if (rc != DFH_OK) return rc;
+    }
+    return DFH_OK;
+}
+
+// J^T J is symmetric: block (b, a) is the transpose of block (a, b).  Between ranks only the blocks with col >= row travel
+// (about half of `vals`), followed by J^T r and {cost, count}; `src[b]` = index among the travelling blocks of the one that
+// holds block b's data (its own, or its mirror's for col < row).  One launch each way, a thread per double.
+namespace dfh {
+__global__ __launch_bounds__(256) void gn_pack_upper_kernel(const double *__restrict__ system, const int *__restrict__ row_of, const int *__restrict__ col,
+                                                             const int *__restrict__ src, int n_blocks, int n_tail, double *__restrict__ packed,
+                                                             int n_upper) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nv = (long)n_blocks * 36;
+    if (i < nv) {
+        const int b = (int)(i / 36);
+        if (col[b] >= row_of[b]) packed[(long)src[b] * 36 + (i - (long)b * 36)] = system[i];
+    } else if (i < nv + n_tail) {
+        packed[(long)n_upper * 36 + (i - nv)] = system[i];
+    }
+}
+__global__ __launch_bounds__(256) void gn_unpack_upper_kernel(double *__restrict__ system, const int *__restrict__ row_of, const int *__restrict__ col,
+                                                               const int *__restrict__ src, int n_blocks, int n_tail, const double *__restrict__ packed,
+                                                               int n_upper) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nv = (long)n_blocks * 36;
+    if (i < nv) {
+        const int b = (int)(i / 36), e = (int)(i - (long)b * 36);
+        const bool upper = col[b] >= row_of[b];
+        const int es = upper ? e : (e % 6) * 6 + e / 6;               // the mirror's entry (ib, ia)
+        system[i] = packed[(long)src[b] * 36 + es];
+    } else if (i < nv + n_tail) {
+        system[i] = packed[(long)n_upper * 36 + (i - nv)];
+    }
+}
+}  // namespace dfh
+
+int dfh_gn_pack_upper(const double *system, const int *row_of, const int *col, const int *src, int n_blocks, int n_nodes, int n_upper,
+                      double *packed, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(system && row_of && col && src && packed && n_blocks >= 0 && n_nodes >= 0 && n_upper >= 0, "dfh_gn_pack_upper: bad arguments");
+    const long n = (long)n_blocks * 36 + 6L * n_nodes + 2;
+    hipLaunchKernelGGL(gn_pack_upper_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, system, row_of, col, src,
+                       n_blocks, 6 * n_nodes + 2, packed, n_upper);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_gn_unpack_upper(double *system, const int *row_of, const int *col, const int *src, int n_blocks, int n_nodes, int n_upper,
+                        const double *packed, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(system && row_of && col && src && packed && n_blocks >= 0 && n_nodes >= 0 && n_upper >= 0, "dfh_gn_unpack_upper: bad arguments");
+    const long n = (long)n_blocks * 36 + 6L * n_nodes + 2;
+    hipLaunchKernelGGL(gn_unpack_upper_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, system, row_of, col, src,
+                       n_blocks, 6 * n_nodes + 2, packed, n_upper);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
 }
 
 int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream) {

@@ -144,6 +144,60 @@ def gather_rows(rows, device=None):
     return np.concatenate([p_[:n_].cpu().numpy() for p_, n_ in zip(parts, sizes)])
 
 
+def allgather_ragged(t):
+    """Rank-ordered concatenation of 2-D tensors whose row counts differ from rank to rank (same dtype, same columns, all on
+    the collective's device): sizes (one tiny all-gather), then ONE all-gather of buffers padded to the longest.  Every rank
+    gets the same (sum n_r, C) tensor.  Used once per frame by the replicated solve (the slabs' samples)."""
+    _, ws = world()
+    if ws == 1:
+        return t
+    if t.dim() != 2:
+        raise ValueError("allgather_ragged expects a 2-D tensor")
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s_) for s_ in sizes]
+    m = max(1, max(sizes))
+    buf = torch.zeros((m, t.shape[1]), dtype=t.dtype, device=t.device)
+    buf[:t.shape[0]] = t
+    out = torch.empty((ws * m, t.shape[1]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, buf)
+    return torch.cat([out[r * m:r * m + sizes[r]] for r in range(ws)])
+
+
+# ---- which way to run the warp solve on P GPUs -------------------------------------------------------------------------
+# Per GN iteration (microseconds; single-GPU parts measured on MI355X: profiles/r2j_kernel_stats.csv, r3_*; the collective's
+# figures are ESTIMATES from the link rates -- no multi-GPU node was available to any round of this build):
+#   rows(S)      the data-row launch: 31 us at 335 k samples, linear in the local sample count
+#   gather(S)    block walk: ~14 us at 335 k samples; the rows it walks are the local ones
+#   pcg(N)       43 us at 512 nodes, 55 at 2 048 (10 iterations, persistent kernel), run by every rank redundantly
+#   allreduce    alpha + bytes * 2 (P - 1) / P / (links * rate): alpha ~ 35 us (RCCL launch + cross-GPU hand-offs of a
+#                latency-bound message), 7 xGMI links at ~48 GB/s sustained each way
+#   eager        ~30 us: a sharded iteration cannot be folded into one host call / one graph with torch's collective in it
+#                unless the capture succeeds (bench.py tries it under RCCL)
+# sharded(P)    = rows / P + gather / P + allreduce + pcg + eager
+# replicated(P) = rows + gather + pcg                 (+ one all-gather of the samples per FRAME: 96 B each)
+# At config 3 (335 k samples, 512 nodes, 1.7 MB system) sharded(8) ~ 4 + 2 + 44 + 43 + 30 = 123 us against 88 replicated: the
+# collective costs more than the 39 us of sample-parallel work it saves -- GN-iters/s would FALL with the GPU count.  At
+# config 4 (828 k samples, 2 048 nodes, 6.8 MB) ~ 10 + 4 + 68 + 55 + 30 = 167 against 165: a wash.  So the default is the
+# replicated solve unless the local work outweighs the collective.
+def solve_mode(n_samples_total, n_nodes, n_blocks, world_size):
+    """'replicated' or 'sharded' for the warp solve on world_size GPUs, by the latency model above."""
+    P = int(world_size)
+    if P <= 1:
+        return "replicated"
+    rows = 31.0 * n_samples_total / 335e3
+    gather = 14.0 * n_samples_total / 335e3
+    pcg = 43.0 + 12.0 * max(0.0, (n_nodes - 512) / 1536.0)
+    nbytes = 8.0 * (36.0 * n_blocks + 6.0 * n_nodes + 2.0)
+    allreduce = 35.0 + nbytes * 2.0 * (P - 1) / P / (7 * 48e3)          # bytes / (MB/s -> us): 48 GB/s = 48e3 bytes per us
+    eager = 30.0
+    frame_gather = 96.0 * n_samples_total * (P - 1) / P / (7 * 48e3) / 10.0      # per iteration of a 10-iteration frame
+    sharded = (rows + gather) / P + allreduce + pcg + eager
+    replicated = rows + gather + pcg + frame_gather
+    return "sharded" if sharded < replicated else "replicated"
+
+
 def all_ranks(flag):
     """True iff `flag` is true on every rank (one tiny all-reduce; ranks must take collective decisions alike)."""
     _, ws = world()

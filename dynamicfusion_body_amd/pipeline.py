@@ -95,10 +95,11 @@ class FrameSolver:
         self.solver.set_samples(pos, nrm, knn_bricks=knn_bricks)
         return pos.shape[0]
 
-    def gn_iteration(self, depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.0):
-        """associate -> build (+ all-reduce) -> PCG -> twist update; asynchronous."""
+    def gn_iteration(self, depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.0, n_iters=1):
+        """associate -> build (+ all-reduce) -> PCG -> twist update, n_iters times; asynchronous.  depth / lw_cam may be lists
+        (several live views: every sample associates with the view in which it lies closest to the observed surface)."""
         self.solver.iterate_associated(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, rw, max_dist, huber,
-                                       lm_abs, lm_rel)
+                                       lm_abs, lm_rel, n_iters=n_iters)
 
     def solve(self, depth, lw_cam, rw=5.0, iters=10, **kw):
         costs = []
@@ -116,10 +117,17 @@ class SlabFrame:
     With one rank it is the single-GPU frame."""
 
     def __init__(self, K, scale, center, res, tdist_vox, node_pos, node_w, knn=4, pcg_iters=10, band=4.0, volume_dtype=torch.float32,
-                 distributed=True):
+                 distributed=True, solve_mode="auto"):
+        """solve_mode (several ranks): "sharded" = every rank builds the normal equations of its own slab's samples, one
+        all-reduce per GN iteration (BASELINE north star); "replicated" = the slabs' samples are all-gathered once per frame
+        and every rank solves the whole system, no per-iteration collective (bit-identical warp fields on all ranks, and the
+        single-GPU loop's bits); "auto" = dist.solve_mode's latency model, decided at the first sample refresh."""
         from . import dist as D
         self.D = D
         self.distributed = bool(distributed)
+        if solve_mode not in ("auto", "sharded", "replicated"):
+            raise ValueError("solve_mode must be 'auto', 'sharded' or 'replicated'")
+        self.solve_mode = solve_mode
         self.R = int(res)
         self.K = np.asarray(K, dtype=np.float64)
         self.Kinv = np.linalg.inv(self.K)
@@ -133,7 +141,9 @@ class SlabFrame:
         self.live = torch.empty_like(self.T)
         self.live_w = torch.empty_like(self.T)
         self.band, self.knn = float(band), int(knn)
-        self.fs = FrameSolver(K, scale, center, R / 2, knn=knn, pcg_iters=pcg_iters, distributed=self.distributed)
+        # (replicated / undecided: the solver itself runs no collective; a decision for "sharded" switches it on)
+        self.fs = FrameSolver(K, scale, center, R / 2, knn=knn, pcg_iters=pcg_iters,
+                              distributed=self.distributed and self.ws > 1 and solve_mode == "sharded")
         N = len(node_pos)
         ident = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), (N, 1))
         self.fs.set_graph(node_pos, ident, node_w)
@@ -166,7 +176,29 @@ class SlabFrame:
             Tp.insert(0, lo[None]); Wp.insert(0, torch.zeros_like(lo)[None]); x0 -= 1
         if hi is not None:
             Tp.append(hi[None]); Wp.append(torch.zeros_like(hi)[None])
-        return self.fs.set_canonical(torch.cat(Tp).contiguous(), torch.cat(Wp).contiguous(), band=self.band, x0=x0, knn_bricks=self.knn_bricks)
+        Tp, Wp = torch.cat(Tp).contiguous(), torch.cat(Wp).contiguous()
+        if self.solve_mode == "sharded":
+            return self.fs.set_canonical(Tp, Wp, band=self.band, x0=x0, knn_bricks=self.knn_bricks)
+        # replicated (or still to be decided): this slab's samples with their node tables, then all slabs' in rank order --
+        # the whole-grid sample set in the whole-grid order (slabs are x ranges, samples are emitted x-major)
+        sv = self.fs.solver
+        pos, nrm = extract_surface_samples(Tp, Wp, self.band, x0=x0)
+        nbr, wts = sample_knn(pos, sv.node_pos, sv.node_w, self.knn, bricks=self.knn_bricks) if pos.shape[0] else \
+            (torch.empty((0, self.knn), dtype=torch.int32, device="cuda"), torch.empty((0, self.knn), dtype=torch.float64, device="cuda"))
+        packed = torch.cat([pos, nrm, wts, nbr.to(torch.float64)], dim=1)        # (node indices are exact in fp64)
+        dev = self.D.collective_device()
+        allp = self.D.allgather_ragged(packed.to(dev)).to("cuda")
+        k = self.knn
+        if self.solve_mode == "auto":
+            S_all, N = int(allp.shape[0]), int(sv.N)
+            mode = self.D.solve_mode(S_all, N, 12 * N, self.ws)               # (~11.5 blocks per node row in practice)
+            self.solve_mode = mode
+            if mode == "sharded":                                             # every rank decides alike: same inputs
+                self.fs.solver.distributed = True
+                return self.fs.set_canonical(Tp, Wp, band=self.band, x0=x0, knn_bricks=self.knn_bricks)
+        sv.set_samples(allp[:, 0:3].contiguous(), allp[:, 3:6].contiguous(), nbr=allp[:, 6 + k:6 + 2 * k].to(torch.int32).contiguous(),
+                       weights=allp[:, 6:6 + k].contiguous())
+        return int(allp.shape[0])
 
     def update_graph(self, radius=None):
         """Deformation-graph maintenance after a TSDF update (reference Fusion.update_graph, core/fusion.py:201-239) on the
@@ -182,7 +214,7 @@ class SlabFrame:
             radius = 0.5 * float(sv.node_w[0])
         pts = sv.spos if sv.S > 0 else torch.zeros((0, 3), dtype=torch.float64, device="cuda")
         gather = None
-        if self.ws > 1:
+        if self.ws > 1 and self.solve_mode == "sharded":         # (replicated: every rank already holds every sample)
             def gather(uns):                             # (ragged all-gather on one device: dist.gather_rows)
                 return self.D.gather_rows(np.asarray(uns, dtype=np.float64).reshape(-1, 3))
         # the samples are stored sorted by node tuple; the greedy subsampling depends on the order of its input, so it is
@@ -263,8 +295,8 @@ class SlabFrame:
         mark("live_tsdf")
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
         mark("allgather")
-        for _ in range(gn_iters):
-            self.fs.gn_iteration(solve_depth, solve_lw, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist, huber=huber)
+        # (one host call for the frame's iterations: nothing between them depends on the host)
+        self.fs.gn_iteration(solve_depth, solve_lw, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist, huber=huber, n_iters=gn_iters)
         mark("solve")
         sv = self.fs.solver
         kernels.fuse_volume_dqb(self.T, self.Wt, live_full, sv.node_pos, sv.node_dq, sv.node_w, self.knn, self.ident_lw, self.tvox,

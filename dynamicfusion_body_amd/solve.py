@@ -224,7 +224,7 @@ class WarpSolver:
         self.distributed = bool(distributed)      # False: ignore an initialised process group
         self.node_nbr = None
         self.S = 0
-        if self.distributed and _dist.ranks_share_a_gpu():
+        if _dist.ranks_share_a_gpu():                  # (whether or not THIS solver runs collectives: ADVICE round 2)
             # several processes time-share this GPU (a rehearsal of the multi-GPU job on one card): co-residency of the
             # persistent PCG's workgroups is not guaranteed across processes -> two launches per iteration, no grid barrier
             _lib.check(self.lib.dfh_pcg_set_mode(2), "dfh_pcg_set_mode")
@@ -401,6 +401,17 @@ class WarpSolver:
         self.vals = self.system[:self.B * 36]
         self.rhs = self.system[self.B * 36:self.B * 36 + 6 * N]
         self.cost_count = self.system[self.B * 36 + 6 * N:]
+        # what the multi-GPU all-reduce carries: J^T J is symmetric, only the blocks with col >= row travel (dfh_gn_pack_upper)
+        self._tri = None
+        if self.distributed and _dist.world()[1] > 1 and not os.environ.get("DFH_ALLREDUCE_FULL"):
+            upper = self.col >= rows
+            up_rank = (torch.cumsum(upper.to(torch.int64), 0) - 1)
+            mkey = self.col.to(torch.int64) * N + rows.to(torch.int64)
+            mirror = torch.searchsorted(keys, mkey).clamp(max=self.B - 1)
+            if bool((keys[mirror] == mkey).all()):                  # (the pattern is symmetric by construction; if ever not: whole buffer)
+                src = torch.where(upper, up_rank, up_rank[mirror]).to(torch.int32).contiguous()
+                n_upper = int(upper.sum())
+                self._tri = (rows.contiguous(), src, n_upper, torch.empty(36 * n_upper + 6 * N + 2, dtype=torch.float64, device="cuda"))
         self.dx = torch.empty(6 * N, dtype=torch.float64, device="cuda")
         nbytes = self.lib.dfh_pcg_workspace_bytes(N, self.pcg_iters)
         self.pcg_ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device="cuda")
@@ -619,8 +630,7 @@ class WarpSolver:
                                              self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
                                             if self.partial_reg is not None else (0, 0, 0, 0, 0)),
                 float(huber), current_stream_ptr()), "dfh_gn_build_planned")
-        if self.distributed:
-            _dist.allreduce_system(self.system)   # no-op on one GPU; samples are sharded by slab
+        self._allreduce_system()                  # no-op on one GPU; samples are sharded by slab
 
     def build_associated(self, depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist=0.0, huber=0.0):
         """associate_depth + build in one launch sequence (dfh_gn_build_planned_assoc): same corr / valid, same system, bit
@@ -650,8 +660,7 @@ class WarpSolver:
                 float(huber), tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
                 _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), current_stream_ptr()),
                 "dfh_gn_build_planned_assoc_views")
-            if self.distributed:
-                _dist.allreduce_system(self.system)
+            self._allreduce_system()
             return
         H, W = depth.shape
         _lib.check(self.lib.dfh_gn_build_planned_assoc(
@@ -666,12 +675,15 @@ class WarpSolver:
             float(huber), depth.data_ptr(), int(H), int(W), _lib.darr(K, 9), _lib.darr(Kinv, 9), _lib.darr(lw_cam, 12), float(scale),
             _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), current_stream_ptr()),
             "dfh_gn_build_planned_assoc")
-        if self.distributed:
-            _dist.allreduce_system(self.system)
+        self._allreduce_system()
 
-    def iterate_associated(self, depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist=0.0, huber=0.0, lm_abs=0.0, lm_rel=0.0):
-        """One GN iteration: build_associated + solve_update.  On one GPU (no all-reduce between the halves) through
-        dfh_gn_iteration, one call in which the clearing of the solve's workspace rides in the data-row launch: same bits."""
+    def iterate_associated(self, depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist=0.0, huber=0.0, lm_abs=0.0, lm_rel=0.0,
+                           n_iters=1):
+        """n_iters GN iterations: build_associated + solve_update each.  On one GPU (no all-reduce between the halves) they
+        are ONE call, dfh_gn_iteration_views (the views' table holds one or several depth maps): the iterations are queued
+        back to back without returning to Python, and in each the clearing of the solve's workspace rides in the data-row
+        launch -- the same bits as separate calls.  DFH_GN_ITER_PER_CALL=1: one dfh_gn_iteration call per iteration (single
+        view), as before round 3."""
         if self._pattern is None:
             self._build_pattern()
         depth, lw_cam, many = self._one_or_many(depth, lw_cam)
@@ -681,39 +693,50 @@ class WarpSolver:
                     not os.environ.get("DFH_GN_NO_FUSED_ASSOC") and not os.environ.get("DFH_GN_NO_FUSED_ITER") and
                     not (self.distributed and _dist.world()[1] > 1))
         if not one_call:
-            self.build_associated(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist, huber)
-            return self.solve_update(lm_abs, lm_rel)
-        nn = 0 if (self.node_nbr is None or rw == 0.0) else self.node_nbr.data_ptr()
-        if many:
-            tab, nv, H, W = self._views_table(depth, lw_cam)
-            _lib.check(self.lib.dfh_gn_iteration_views(
-                self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.corr.data_ptr(),
-                self.valid.data_ptr(), self.S, self.knn, self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(),
-                nn, self.N, _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
-                self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(), self.run_id.data_ptr(), self.n_rows,
-                self.partial.data_ptr(), self.blk_ptr.data_ptr(), self.blk_ent.data_ptr(), self.node_ptr.data_ptr(),
-                self.node_ent.data_ptr(), *((self.partial_reg.data_ptr(), self.rblk_ptr.data_ptr(), self.rblk_ent.data_ptr(),
-                                             self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
-                                            if self.partial_reg is not None else (0, 0, 0, 0, 0)),
-                float(huber), tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
-                _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist),
-                self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(), self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, 1.0,
-                current_stream_ptr()), "dfh_gn_iteration_views")
+            for _ in range(int(n_iters)):
+                self.build_associated(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist, huber)
+                self.solve_update(lm_abs, lm_rel)
             return
-        H, W = depth.shape
-        _lib.check(self.lib.dfh_gn_iteration(
-            self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.corr.data_ptr(),
-            self.valid.data_ptr(), self.S, self.knn, self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(),
-            nn, self.N, _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
-            self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(), self.run_id.data_ptr(), self.n_rows,
-            self.partial.data_ptr(), self.blk_ptr.data_ptr(), self.blk_ent.data_ptr(), self.node_ptr.data_ptr(),
-            self.node_ent.data_ptr(), *((self.partial_reg.data_ptr(), self.rblk_ptr.data_ptr(), self.rblk_ent.data_ptr(),
-                                         self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
-                                        if self.partial_reg is not None else (0, 0, 0, 0, 0)),
-            float(huber), depth.data_ptr(), int(H), int(W), _lib.darr(K, 9), _lib.darr(Kinv, 9), _lib.darr(lw_cam, 12), float(scale),
-            _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist),
-            self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(), self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, 1.0,
-            current_stream_ptr()), "dfh_gn_iteration")
+        nn = 0 if (self.node_nbr is None or rw == 0.0) else self.node_nbr.data_ptr()
+        common = (self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.corr.data_ptr(),
+                  self.valid.data_ptr(), self.S, self.knn, self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(),
+                  nn, self.N, _lib.darr(lw_dq, 8), float(rw), self.row_ptr.data_ptr(), self.col.data_ptr(), self.B,
+                  self.vals.data_ptr(), self.rhs.data_ptr(), self.cost_count.data_ptr(), self.run_id.data_ptr(), self.n_rows,
+                  self.partial.data_ptr(), self.blk_ptr.data_ptr(), self.blk_ent.data_ptr(), self.node_ptr.data_ptr(),
+                  self.node_ent.data_ptr(), *((self.partial_reg.data_ptr(), self.rblk_ptr.data_ptr(), self.rblk_ent.data_ptr(),
+                                               self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
+                                              if self.partial_reg is not None else (0, 0, 0, 0, 0)),
+                  float(huber))
+        tail = (self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(), self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, 1.0)
+        if not many and os.environ.get("DFH_GN_ITER_PER_CALL"):
+            H, W = depth.shape
+            for _ in range(int(n_iters)):
+                _lib.check(self.lib.dfh_gn_iteration(
+                    *common, depth.data_ptr(), int(H), int(W), _lib.darr(K, 9), _lib.darr(Kinv, 9), _lib.darr(lw_cam, 12), float(scale),
+                    _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), *tail, current_stream_ptr()),
+                    "dfh_gn_iteration")
+            return
+        tab, nv, H, W = self._views_table(depth if many else [depth], lw_cam if many else [lw_cam])
+        _lib.check(self.lib.dfh_gn_iteration_views(
+            *common, tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
+            _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), *tail, int(n_iters), current_stream_ptr()),
+            "dfh_gn_iteration_views")
+
+    def _allreduce_system(self):
+        """Sum of the normal equations over ranks, in place: the upper block triangle + J^T r + {cost, count} in one collective
+        (pack, all-reduce of ~55 % of the system's bytes, unpack with the mirrored blocks transposed), or the whole flat buffer
+        (DFH_ALLREDUCE_FULL=1).  One GPU / replicated solve: nothing."""
+        if not self.distributed or _dist.world()[1] == 1:
+            return
+        if self._tri is None:
+            _dist.allreduce_system(self.system)
+            return
+        rows, src, n_upper, packed = self._tri
+        _lib.check(self.lib.dfh_gn_pack_upper(self.system.data_ptr(), rows.data_ptr(), self.col.data_ptr(), src.data_ptr(), self.B, self.N,
+                                              n_upper, packed.data_ptr(), current_stream_ptr()), "dfh_gn_pack_upper")
+        _dist.allreduce_system(packed)
+        _lib.check(self.lib.dfh_gn_unpack_upper(self.system.data_ptr(), rows.data_ptr(), self.col.data_ptr(), src.data_ptr(), self.B, self.N,
+                                                n_upper, packed.data_ptr(), current_stream_ptr()), "dfh_gn_unpack_upper")
 
     def solve_update(self, lm_abs=0.0, lm_rel=0.0):
         """PCG + twist update of the node DQs for the system of the last build (asynchronous)."""

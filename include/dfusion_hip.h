@@ -384,7 +384,8 @@ int dfh_gn_iteration(const double *sample_pos, const double *sample_nrm, const i
                      double step, void *stream);
 
 /* dfh_gn_build_planned_assoc / dfh_gn_iteration with the association of dfh_gn_associate_views (float32 depth maps): the same
- * arguments with (views, n_views) in place of (depth, lw_cam). */
+ * arguments with (views, n_views) in place of (depth, lw_cam).  dfh_gn_iteration_views queues `n_iters` whole iterations back to
+ * back (a frame's ten iterations in one call: nothing between them depends on the host; the same bits as n_iters calls). */
 int dfh_gn_build_planned_assoc_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
                                double *corr_out, unsigned char *valid_out, int n_samples, int knn, const double *node_dq,
                                const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
@@ -404,7 +405,17 @@ int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, c
                      const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
                      double scale, const double center[3], double half, double max_dist,
                      int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
-                     double step, void *stream);
+                     double step, int n_iters, void *stream);
+
+/* Multi-GPU solve: what travels in the per-iteration all-reduce.  `system` = {J^T J blocks (n_blocks x 36) | J^T r (6 n_nodes) |
+ * cost, count} as the builds write it; J^T J is symmetric, so only the blocks with col >= row are packed (then J^T r and
+ * {cost, count}): (36 n_upper + 6 n_nodes + 2) doubles in `packed`, about 55 % of the system.  row_of[b] / col[b]: block b's
+ * row and column node; src[b]: index among the packed blocks of the one that holds block b's data (its own, or its mirror's
+ * when col < row: the unpack transposes it).  No reference counterpart (the reference has no collective). */
+int dfh_gn_pack_upper(const double *system, const int *row_of, const int *col, const int *src, int n_blocks, int n_nodes, int n_upper,
+                      double *packed, void *stream);
+int dfh_gn_unpack_upper(double *system, const int *row_of, const int *col, const int *src, int n_blocks, int n_nodes, int n_upper,
+                        const double *packed, void *stream);
 
 /* The persistent PCG kernel (one launch per solve; its workgroups synchronise through grid-wide reductions) is used
  * when all its workgroups are co-resident: the occupancy query admits a workgroup per CU and the grid needs at most

@@ -130,9 +130,9 @@ def _frame_worker(rank, ws, port, out, sphere_r=None):
             frames.append(torch.from_numpy(scene.render_depth(K, lw_cam, H, W, dtype=np.float32, sphere_offset=off,
                                                               sphere_r=sr * 1.01, wall_z=None if sphere_r is not None else scene.WALL_Z)).cuda())
         res = {}
-        for mode in ("sharded", "whole"):
+        for mode in ("sharded", "replicated", "whole"):
             sf = SlabFrame(K, scale, center, R, tdist / scale, node_pos, node_w, knn=4, pcg_iters=300, band=2.0,
-                           distributed=(mode == "sharded"))
+                           distributed=(mode != "whole"), solve_mode=mode if mode != "whole" else "auto")
             for ang in (0.0, 40.0, -40.0):
                 lw = scene.view_extrinsic(ang)
                 d = torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0, sphere_r=sr,
@@ -146,11 +146,19 @@ def _frame_worker(rank, ws, port, out, sphere_r=None):
             res[mode] = sf
         a, b = res["sharded"].a, res["sharded"].b
         assert (a, b) == D.slab_range(R, rank, ws) and (res["whole"].a, res["whole"].b) == (0, R)
+        assert res["sharded"].solve_mode == "sharded" and res["replicated"].solve_mode == "replicated"
         Ts, Tw = res["sharded"].T, res["whole"].T[a:b]
         Ws, Ww = res["sharded"].Wt, res["whole"].Wt[a:b]
         dq_s, dq_w = res["sharded"].fs.solver.node_dq, res["whole"].fs.solver.node_dq
+        # the replicated solve (slabs' samples all-gathered once per frame, no per-iteration collective) IS the whole-grid solve:
+        # the same samples in the same order -> the same bits, on every rank
+        rp = res["replicated"]
+        assert rp.fs.solver.S == res["whole"].fs.solver.S
+        rep_exact = bool(torch.equal(rp.fs.solver.node_dq, dq_w) and torch.equal(rp.T, Tw) and torch.equal(rp.Wt, Ww))
         out.put((rank, float((Ts - Tw).abs().max()), float((Ws - Ww).abs().max()), float(((Ws > 0) != (Ww > 0)).float().mean()),
-                 float((dq_s - dq_w).abs().max()), float((Tw - tdist / scale).abs().max()), None, n_mine))
+                 float((dq_s - dq_w).abs().max()), float((Tw - tdist / scale).abs().max()),
+                 None if rep_exact else "replicated solve differs from the whole-grid run: dq %.3g, T %.3g" %
+                 (float((rp.fs.solver.node_dq - dq_w).abs().max()), float((rp.T - Tw).abs().max())), n_mine))
     except Exception as e:                                                  # pragma: no cover
         import traceback
         out.put((rank, 0, 0, 0, 0, 0, traceback.format_exc(), -1))
@@ -280,3 +288,27 @@ def test_config4_two_rank_split():
         assert n_valid == n_valid_whole and n_valid > 100000                # the all-reduced count is the whole grid's
         assert same_pattern
         assert 0 <= dv <= 1e-11 and dr <= 1e-11 and dc <= 1e-12
+
+
+def test_bench_with_a_failed_leg_exits_non_zero_and_still_prints_its_line():
+    """bench.py --gpus 2 with an injected failure of rank 1 inside the warp-solve leg (DFH_TEST_FAIL_GN_RANK): the headline line is
+    still printed by rank 0 (with an `error` in the failed leg), every rank leaves within seconds -- the failed rank posts its
+    state in the process group's store, the others' watchdogs look there twice a second -- and the command's exit code is NOT 0:
+    a stalled collective must not look like a clean run to whoever launched it (round-2 ADVICE)."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DFH_TEST_FAIL_GN_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--leg-timeout", "120", "--res", "64", "--gn-nodes", "48"], env=env, capture_output=True, text=True, timeout=280)
+    took = time.time() - t0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode != 0, (r.returncode, r.stderr[-400:])
+    assert len(lines) == 1, (r.stdout[-400:], r.stderr[-400:])
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["n_gpus"] == 2
+    assert "error" in d["gn"]
+    assert took < 110, took                       # (well inside the legs' own time limit: the ranks told each other)

@@ -239,8 +239,8 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
         off = np.array([0.4, -0.25, 0.15]) * np.sin(0.5 * (f + 1)) * scale
         frames.append([torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0, sphere_offset=off)).cuda() for lw in lws])
 
-    def run(env, timed):
-        for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX", "DFH_GN_NO_FUSED_ITER"):
+    def run(env, timed, data_views=None):
+        for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX", "DFH_GN_NO_FUSED_ITER", "DFH_GN_ITER_PER_CALL"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setattr(HostScalar, "enabled", "NO_HOST_SCALARS" not in env)
         from dynamicfusion_body_amd import _lib
@@ -252,7 +252,7 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
         for d, lw in zip(first, lws):
             sf.integrate(d, lw)
         sf.refresh_samples()
-        counts = [sf.step(ds, lws, gn_iters=6, stage_ms={} if timed else None) for ds in frames]
+        counts = [sf.step(ds, lws, gn_iters=6, stage_ms={} if timed else None, data_views=data_views) for ds in frames]
         torch.cuda.synchronize()
         return counts, sf.fs.solver.node_dq.clone(), sf.T.clone(), sf.Wt.clone()
     ref = run((), False)
@@ -263,7 +263,15 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
         assert got[0] == ref[0], (env, timed)
         for a, b in zip(got[1:], ref[1:]):
             assert torch.equal(a, b), (env, timed)
-    for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX", "DFH_GN_NO_FUSED_ITER"):
+    # the data term on the first view only (round 2's): the frame's iterations in one call through a one-view table against one
+    # dfh_gn_iteration call per iteration (DFH_GN_ITER_PER_CALL) -- the same bits; and the three-view data term is a different solve
+    ref1 = run((), False, data_views=1)
+    got1 = run(("DFH_GN_ITER_PER_CALL",), False, data_views=1)
+    assert got1[0] == ref1[0]
+    for a, b in zip(got1[1:], ref1[1:]):
+        assert torch.equal(a, b)
+    assert not torch.equal(ref1[1], ref[1])
+    for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX", "DFH_GN_NO_FUSED_ITER", "DFH_GN_ITER_PER_CALL"):
         monkeypatch.delenv(k, raising=False)
 
 

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "dfh_gn_unpack_upper": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "dfh_gn_sort_workspace_bytes": (ctypes.c_size_t, [_int]),
     "dfh_gn_sort_samples": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dfh_gn_tile_samples": (_int, []),
     "dfh_gn_plan_count": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "dfh_gn_plan_workspace_bytes": (ctypes.c_size_t, [_int, _int]),
     "dfh_gn_plan_build": (_int, [_vp, _int, _int, _int, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

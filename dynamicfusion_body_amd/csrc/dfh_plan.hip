@@ -1,5 +1,5 @@
 // Per-frame bookkeeping of the warp-field solve on the device: samples sorted by node tuple, and the static plan of
-// dfh_gn_build_planned (rows = runs of equal tuples inside 256-sample tiles; per 6x6 block and per node the list of
+// dfh_gn_build_planned (rows = runs of equal tuples inside kGnTile-sample tiles; per 6x6 block and per node the list of
 // (row, slot) entries that contribute to it).  The host used to assemble all this from ~35 torch launches per frame
 // (pack, sort, cumsum, searchsorted, ...): host-bound at ~0.6 ms.  Here it is a handful of launches behind three C
 // entry points; the two key sorts are rocPRIM's device radix sort (stable, so every list comes out in ascending entry
@@ -21,7 +21,8 @@ namespace dfh {
 using SortCfg = rocprim::radix_sort_config<rocprim::default_config,
                                            rocprim::merge_sort_config<512, 512, DFH_SORT_BLOCK_ITEMS, 128, 256, 8>,
                                            rocprim::default_config>;
-constexpr int kPlanTile = 256;          // == kTile of dfh_solve.hip: a row never spans two tiles
+constexpr int kPlanTile = kGnTile;      // == kTile of dfh_solve.hip: a row never spans two tiles
+constexpr int kPlanWaves = kPlanTile / 64;
 constexpr int kKMaxP = 8;
 
 __device__ __forceinline__ int plan_find_block(const int *__restrict__ row_ptr, const int *__restrict__ col, int a, int b) {
@@ -74,14 +75,18 @@ __device__ __forceinline__ bool plan_is_head(const int *__restrict__ nbr, int s,
 }
 
 // rows per tile
-__global__ __launch_bounds__(256) void plan_heads_kernel(const int *__restrict__ nbr, int S, int k, int *__restrict__ tile_rows) {
-    __shared__ int cnt[4];
+__global__ __launch_bounds__(kPlanTile) void plan_heads_kernel(const int *__restrict__ nbr, int S, int k, int *__restrict__ tile_rows) {
+    __shared__ int cnt[kPlanWaves];
     const int s = blockIdx.x * kPlanTile + threadIdx.x;
     const bool head = s < S && plan_is_head(nbr, s, k);
     const unsigned long long b = __ballot(head);
     if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = __popcll(b);
     __syncthreads();
-    if (threadIdx.x == 0) tile_rows[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int w = 0; w < kPlanWaves; ++w) n += cnt[w];
+        tile_rows[blockIdx.x] = n;
+    }
 }
 
 // exclusive scan of the tile counts in place (one workgroup; tile_rows[n_tiles] = total = *n_rows_out)
@@ -113,9 +118,9 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(int *__restrict__ tile_
 }
 
 // run_id of every sample and the first sample of every row
-__global__ __launch_bounds__(256) void plan_runid_kernel(const int *__restrict__ nbr, int S, int k, const int *__restrict__ tile_off,
+__global__ __launch_bounds__(kPlanTile) void plan_runid_kernel(const int *__restrict__ nbr, int S, int k, const int *__restrict__ tile_off,
                                                           int *__restrict__ run_id, int *__restrict__ row_first) {
-    __shared__ int cnt[4];
+    __shared__ int cnt[kPlanWaves];
     const int s = blockIdx.x * kPlanTile + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool head = s < S && plan_is_head(nbr, s, k);
@@ -374,13 +379,15 @@ int dfh_gn_sort_samples(const double *pos, const double *nrm, const int *nbr, co
     return DFH_OK;
 }
 
+int dfh_gn_tile_samples(void) { return dfh::kGnTile; }
+
 int dfh_gn_plan_count(const int *nbr, int n_samples, int knn, int *tile_off, int *n_rows_out, void *stream) {
     using namespace dfh;
     DFH_REQUIRE(n_samples >= 1 && knn >= 1 && knn <= kKMaxP, "dfh_gn_plan_count: bad sizes");
     DFH_REQUIRE(nbr && tile_off && n_rows_out, "dfh_gn_plan_count: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = (n_samples + kPlanTile - 1) / kPlanTile;
-    hipLaunchKernelGGL(plan_heads_kernel, dim3(n_tiles), dim3(256), 0, s, nbr, n_samples, knn, tile_off);
+    hipLaunchKernelGGL(plan_heads_kernel, dim3(n_tiles), dim3(kPlanTile), 0, s, nbr, n_samples, knn, tile_off);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, tile_off, n_tiles, n_rows_out);
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
@@ -415,7 +422,7 @@ int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const
     int *unc_ws = reinterpret_cast<int *>(w + align16(temp));     // (the 16 spare bytes of the workspace) the flag while atomics set it
     const int n_tiles = (n_samples + kPlanTile - 1) / kPlanTile;
     DFH_HIP_CHECK(hipMemsetAsync(unc_ws, 0, sizeof(int), s));
-    hipLaunchKernelGGL(plan_runid_kernel, dim3(n_tiles), dim3(256), 0, s, nbr, n_samples, knn, tile_off, run_id, row_first);
+    hipLaunchKernelGGL(plan_runid_kernel, dim3(n_tiles), dim3(kPlanTile), 0, s, nbr, n_samples, knn, tile_off, run_id, row_first);
     if (on(opt().plan_radix)) {              // the lists through two stable device radix sorts (round 2, first half): kept for A/B
         hipLaunchKernelGGL(plan_zero2_kernel, dim3((unsigned)((n_blocks + n_nodes + 2 + 255) / 256)), dim3(256), 0, s, blk_ptr, n_blocks + 1,
                            node_ptr, n_nodes + 1);

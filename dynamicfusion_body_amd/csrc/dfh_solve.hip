@@ -526,7 +526,7 @@ struct AssocParams {
     Mat34 lw_cam;
     Mat3 Rinv;            // inverse of lw_cam's 3x3 part
     DQ lw;
-    double scale, cx, cy, cz, half, max_dist;
+    double scale, inv_scale, cx, cy, cz, half, max_dist;
     int H, W, k;
 };
 
@@ -544,7 +544,10 @@ __device__ __forceinline__ double blend_static(const double *__restrict__ node_d
     double nb = sqrt(((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3])) +
                      ((b[4] * b[4] + b[5] * b[5]) + (b[6] * b[6] + b[7] * b[7])));
     if (nb == 0.0) { bh[0] = 1.0; for (int c = 1; c < 8; ++c) bh[c] = 0.0; nb = 1.0; }
-    else { for (int c = 0; c < 8; ++c) bh[c] = b[c] / nb; }
+    else {
+        const double inv = 1.0 / nb;                      // one division, eight products (each within 1 ulp of b / nb): the GN path has
+        for (int c = 0; c < 8; ++c) bh[c] = b[c] * inv;   // no reference rounding to meet (the residual evaluators use blend_from_indices)
+    }
     return nb;
 }
 
@@ -571,7 +574,12 @@ __device__ __forceinline__ bool associate_view(const AssocParams &p, const doubl
     const double p1 = (p.K.m[3] * l0 + p.K.m[4] * l1) + p.K.m[5] * l2;
     const double p2 = (p.K.m[6] * l0 + p.K.m[7] * l1) + p.K.m[8] * l2;
     bool ok = p2 != 0.0;
-    const double u = p0 / p2, v = p1 / p2;
+    // one corrected reciprocal instead of two IEEE divisions (u, v within 1.5 ulp: the association has no reference counterpart
+    // whose rounding would have to be met; the oracle comparison is to 1e-9)
+    double rp = __builtin_amdgcn_rcp(p2);
+    rp = __builtin_fma(rp, __builtin_fma(-p2, rp, 1.0), rp);
+    rp = __builtin_fma(rp, __builtin_fma(-p2, rp, 1.0), rp);
+    const double u = p0 * rp, v = p1 * rp;
     ok = ok && (u >= 0.0) && (u < (double)(p.W - 1)) && (v >= 0.0) && (v < (double)(p.H - 1));
     c0 = 0.0; c1 = 0.0; c2 = 0.0; d2 = 0.0;
     if (ok) {
@@ -586,9 +594,9 @@ __device__ __forceinline__ bool associate_view(const AssocParams &p, const doubl
         const double X = (Rinv[0] * q0 + Rinv[1] * q1) + Rinv[2] * q2;
         const double Y = (Rinv[3] * q0 + Rinv[4] * q1) + Rinv[5] * q2;
         const double Z = (Rinv[6] * q0 + Rinv[7] * q1) + Rinv[8] * q2;
-        c0 = (X - p.cx) / p.scale + p.half;
-        c1 = (Y - p.cy) / p.scale + p.half;
-        c2 = (Z - p.cz) / p.scale + p.half;
+        c0 = (X - p.cx) * p.inv_scale + p.half;
+        c1 = (Y - p.cy) * p.inv_scale + p.half;
+        c2 = (Z - p.cz) * p.inv_scale + p.half;
         const double dx = c0 - xp.x, dy = c1 - xp.y, dz = c2 - xp.z;
         d2 = dx * dx + dy * dy + dz * dz;
     }
@@ -675,7 +683,8 @@ struct BuildParams {
     double huber;             // > 0: IRLS weight min(1, huber / |r|) on the data rows (the reference's solver runs
 };                            //      least_squares(loss='huber'), f_scale 1: core/fusion.py:389); 0: plain least squares
 
-constexpr int kTile = 256;
+constexpr int kTile = kGnTile;                  // samples (= threads) per tile, dfh_common.h
+constexpr int kTileWaves = kTile / 64;
 
 // scratch row of the planned build: {Gram matrix of the row's 6K Jacobian columns as 6x6 sub-blocks (slot sa <= slot sb), each
 // stored WHOLE and row-major (36 contiguous doubles; the diagonal ones with both triangles) | J^T r | cost | count | live flag},
@@ -750,7 +759,7 @@ __device__ __forceinline__ double data_row_from(const double *__restrict__ node_
     return r;
 }
 
-// One 256-sample tile per block.  Samples must be sorted by their k-tuple of nodes (any order
+// One kTile-sample tile per block.  Samples must be sorted by their k-tuple of nodes (any order
 // is CORRECT; sorted order just means few runs per tile and therefore few atomics).
 // PLANNED: the (tile, tuple) runs are static per frame, so each run owns a row of `partial`
 // ({upper triangle of its (6K)^2 Gram matrix | J^T r | 0.5 r^2 | count}, row = run_id[first sample]) and the
@@ -770,7 +779,7 @@ struct RegTail {
     unsigned long long zero_count;
     int first_zero_wg;
 };
-constexpr int kZeroPerWg = 1024;                 // doubles one workgroup clears (256 threads x 4)
+constexpr int kZeroPerWg = 4 * kTile;            // doubles one workgroup clears (kTile threads x 4)
 __device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N, int k, const double *__restrict__ node_dq,
                              const double *__restrict__ node_pos, const double *__restrict__ node_w, double rw,
                              const int *__restrict__ row_ptr, const int *__restrict__ col, double *__restrict__ vals,
@@ -795,7 +804,7 @@ __device__ unsigned long long g_build_trace[8192][8];
 #endif
 
 template <int K, bool PLANNED, bool ASSOC>
-__global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
+__global__ __launch_bounds__(kTile) void gn_build_data_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
                                                              const int *__restrict__ nbr, const double *__restrict__ wts,
                                                              double *__restrict__ corr,
                                                              unsigned char *__restrict__ valid,
@@ -821,7 +830,9 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     constexpr int NJ = 6 * K;                   // Jacobian entries per sample
     constexpr int LD = NJ + 1;                  // + residual
     __shared__ double sJ[kTile * LD];
-    __shared__ int sIdx[kTile * K];
+    // (the planned build tells runs apart by their scratch-row ids and needs no node tuples in LDS; without them and with 16-bit
+    // row ids the workgroup's LDS drops from 58.4 to 52.8 KB: three workgroups per CU instead of two)
+    __shared__ int sIdx[PLANNED ? 1 : kTile * K];
     const int tid = threadIdx.x;
     const int s = blockIdx.x * kTile + tid;
     const int tile_n = min(kTile, p.S - blockIdx.x * kTile);
@@ -859,14 +870,16 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     };
     const bool act = ASSOC ? a_ok : (tid < tile_n && valid[s] != 0);
     BT_STAMP(1);
-    __shared__ int sWaveCnt[4];
+    __shared__ int sWaveCnt[kTileWaves];
     const unsigned long long bal = __ballot(act);
     const int lane = tid & 63, wv = tid >> 6;
     if (lane == 0) sWaveCnt[wv] = __popcll(bal);
     __syncthreads();
     int pos = __popcll(bal & ((1ull << lane) - 1ull));
     for (int w_ = 0; w_ < wv; ++w_) pos += sWaveCnt[w_];
-    const int n_valid = sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
+    int n_valid = 0;
+#pragma unroll
+    for (int w_ = 0; w_ < kTileWaves; ++w_) n_valid += sWaveCnt[w_];
     constexpr int ST_ = gn_row_stride(K);
     double *live = PLANNED ? tile_cost + 2 * (size_t)rt.n_tiles : nullptr;      // one flag per row, dense: 0 = row not written this iteration
     const int row_first = PLANNED ? run_id[blockIdx.x * kTile] : 0;
@@ -878,11 +891,11 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         return;
     }
     if (!PLANNED && tid == 0) atomicAdd(cost_count + 1, (double)n_valid);        // valid-sample count
-    __shared__ int sRow[PLANNED ? kTile : 1];                        // partial row of every compacted sample
-    __shared__ double sObj[4];
+    __shared__ unsigned short sRow[PLANNED ? kTile : 1];             // partial row of every compacted sample, relative to the tile's first
+    __shared__ double sObj[kTileWaves];
     double obj = 0.0;
     if (act) {
-        if (PLANNED) sRow[pos] = run_id[s];
+        if (PLANNED) sRow[pos] = (unsigned short)(run_id[s] - row_first);
         double Jrow[NJ];
         double r;
         if (ASSOC) {
@@ -906,8 +919,10 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
 #pragma unroll
             for (int j = 0; j < NJ; ++j) Jrow[j] *= sc;
         }
+        if (!PLANNED) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) sIdx[pos * K + j] = idx[j];
+            for (int j = 0; j < K; ++j) sIdx[pos * K + j] = idx[j];
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) sJ[pos * LD + j] = Jrow[j];
         sJ[pos * LD + NJ] = r;
@@ -921,7 +936,10 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     }
     __syncthreads();
     if (PLANNED && tid == 0) {
-        tile_cost[2 * blockIdx.x] = ((sObj[0] + sObj[1]) + sObj[2]) + sObj[3];
+        double o = sObj[0];                                          // (fixed order)
+#pragma unroll
+        for (int w_ = 1; w_ < kTileWaves; ++w_) o += sObj[w_];
+        tile_cost[2 * blockIdx.x] = o;
         tile_cost[2 * blockIdx.x + 1] = (double)n_valid;
     }
     // run boundaries: sRun[0..n_runs] are the offsets in the compacted list where the node tuple changes
@@ -932,8 +950,12 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         if (tid < n_valid) {
             head = tid == 0;
             if (!head) {
+                if (PLANNED) {
+                    head = sRow[tid] != sRow[tid - 1];               // (a scratch row = a run of equal tuples inside the tile)
+                } else {
 #pragma unroll
-                for (int j = 0; j < K; ++j) head = head || (sIdx[tid * K + j] != sIdx[(tid - 1) * K + j]);
+                    for (int j = 0; j < K; ++j) head = head || (sIdx[tid * K + j] != sIdx[(tid - 1) * K + j]);
+                }
             }
         }
         // positions of the heads by ballot + prefix (same scheme as the compaction above)
@@ -944,7 +966,8 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         for (int w_ = 0; w_ < wv; ++w_) hp += sWaveCnt[w_];
         if (head) sRun[hp] = tid;
         if (tid == 0) {
-            const int n = sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
+            int n = 0;
+            for (int w_ = 0; w_ < kTileWaves; ++w_) n += sWaveCnt[w_];
             sRun[n] = n_valid;
             sNRuns = n;
         }
@@ -959,7 +982,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     constexpr bool kBlkTable = K <= 4 && !PLANNED;         // 256 runs x K^2 ints must fit next to sJ
     __shared__ int sBlk[kBlkTable ? kTile * K * K : 1];
     if (kBlkTable) {
-        for (int q = tid; q < n_runs * K * K; q += 256) {
+        for (int q = tid; q < n_runs * K * K; q += kTile) {
             const int rn = q / (K * K), pr = q - rn * (K * K);
             const int t0 = sRun[rn];
             sBlk[q] = find_block(row_ptr, col, sIdx[t0 * K + pr / K], sIdx[t0 * K + pr % K]);
@@ -970,13 +993,13 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
     // entries of J^T r, then the cost
     constexpr int NUP = PLANNED ? gn_row_gram(K) : NJ * (NJ + 1) / 2;
     if (PLANNED) {
-        if (tid < n_runs) partial[(size_t)sRow[sRun[tid]] * ST_ + NUP + NJ + 1] = (double)(sRun[tid + 1] - sRun[tid]);
+        if (tid < n_runs) partial[(size_t)(row_first + sRow[sRun[tid]]) * ST_ + NUP + NJ + 1] = (double)(sRun[tid + 1] - sRun[tid]);
         // live flags of this tile's rows: 1 where a run has valid samples this iteration, 0 elsewhere (dead rows are
         // neither cleared here nor read by the gather)
         __shared__ int sTouched[kTile];
         if (tid < rows_tile) sTouched[tid] = 0;
         __syncthreads();
-        if (tid < n_runs) sTouched[sRow[sRun[tid]] - row_first] = 1;
+        if (tid < n_runs) sTouched[sRow[sRun[tid]]] = 1;
         __syncthreads();
         if (tid < rows_tile) live[row_first + tid] = sTouched[tid] ? 1.0 : 0.0;
     }
@@ -1011,7 +1034,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
 #pragma unroll
                     for (int bj = bi; bj < NT; ++bj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[bi], x[bj], acc[q], 0, 0, 0);
             }
-            double *dst = partial + (size_t)sRow[t0] * ST_;
+            double *dst = partial + (size_t)(row_first + sRow[t0]) * ST_;
             int q = 0;
 #pragma unroll
             for (int bi = 0; bi < NT; ++bi)
@@ -1039,7 +1062,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
         BT_STAMP(5);
         return;
     }
-    for (int e = tid; e < NUP + NJ + 1; e += 256) {
+    for (int e = tid; e < NUP + NJ + 1; e += kTile) {
         int pa, pb;                              // Jacobian columns of this entry (pb == NJ: residual)
         if (e < NUP && PLANNED) {
             int sub = e / 36, sa = 0;
@@ -1070,7 +1093,7 @@ __global__ __launch_bounds__(256) void gn_build_data_kernel(const double *__rest
             for (; t < t1; ++t) acc0 += sJ[t * LD + pa] * sJ[t * LD + pb];
             const double acc = (acc0 + acc1) + (acc2 + acc3);
             if (PLANNED) {
-                partial[(size_t)sRow[t0] * ST_ + e] = pa == NJ ? 0.5 * acc : acc;
+                partial[(size_t)(row_first + sRow[t0]) * ST_ + e] = pa == NJ ? 0.5 * acc : acc;
                 continue;
             }
             if (acc == 0.0) continue;
@@ -1449,7 +1472,7 @@ __device__ void gn_reg_pairs(int block, const int *__restrict__ node_nbr, int N,
     // J^T rho | 0.5 rho^2 | 0} is STORED in row t (92 doubles) and gathered like a 2-node data row: no atomics.
     // rows of the K = 2 layout: sub-blocks (i,i) (i,j) (j,j) | J^T rho (12) | cost | count | live flag
     constexpr int NE2 = gn_row_stride(2), kLive2 = gn_row_entries(2), kJtr2 = gn_row_gram(2), kCost2 = gn_row_gram(2) + 12;
-    const int t = block * 4 + (threadIdx.x >> 6);
+    const int t = block * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per node pair
     const int lane = threadIdx.x & 63;
     if (t >= N * k) return;
     const int i = t / k;
@@ -2584,13 +2607,13 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
             rt.node_nbr = node_nbr; rt.node_pos = node_pos; rt.node_w = node_w; rt.partial_reg = partial_reg;
             rt.rw = rw; rt.N = n_nodes; rt.k = knn;
         }
-        unsigned n_wg = (unsigned)(n_tiles + (reg_in_data_launch ? (n_nodes * knn + 3) / 4 : 0));
+        unsigned n_wg = (unsigned)(n_tiles + (reg_in_data_launch ? (n_nodes * knn + kTileWaves - 1) / kTileWaves : 0));
         if (planned && zero_ptr && zero_count > 0 && (zero_count + kZeroPerWg - 1) / kZeroPerWg < (1u << 20)) {
             rt.zero_ptr = zero_ptr; rt.zero_count = zero_count; rt.first_zero_wg = (int)n_wg;
             n_wg += (unsigned)((zero_count + kZeroPerWg - 1) / kZeroPerWg);
             if (zeroed) *zeroed = true;
         }
-        dim3 grid(n_wg), block(256);
+        dim3 grid(n_wg), block(kTile);
         const AssocArgs aa = assoc ? *assoc : AssocArgs{};
 #define DFH_BUILD(KK)                                                                                               \
     case KK:                                                                                                        \
@@ -2695,7 +2718,7 @@ static int fill_assoc_params(dfh::AssocParams &p, const double lw_dq[8], int H, 
         p.Rinv.m[3] = (f * g - d * i) * id; p.Rinv.m[4] = (a * i - c * g) * id; p.Rinv.m[5] = (c * d - a * f) * id;
         p.Rinv.m[6] = (d * h - e * g) * id; p.Rinv.m[7] = (b * g - a * h) * id; p.Rinv.m[8] = (a * e - b * d) * id;
     }
-    p.scale = scale; p.cx = center[0]; p.cy = center[1]; p.cz = center[2]; p.half = half; p.max_dist = max_dist;
+    p.scale = scale; p.inv_scale = 1.0 / scale; p.cx = center[0]; p.cy = center[1]; p.cz = center[2]; p.half = half; p.max_dist = max_dist;
     p.H = H; p.W = W; p.k = knn;
     return DFH_OK;
 }

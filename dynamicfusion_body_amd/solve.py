@@ -428,7 +428,8 @@ class WarpSolver:
         if self.S == 0 or self._tuple_key is None or os.environ.get("DFH_PLAN_TORCH"):
             return self._build_plan_torch(keys, reg)
         N, k, S, dev = self.N, self.knn, self.S, "cuda"
-        n_tiles = (S + 255) // 256
+        tile = int(self.lib.dfh_gn_tile_samples())
+        n_tiles = (S + tile - 1) // tile
         tile_off = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
         # (the row count sizes the plan arrays: the scan kernel stores it straight into pinned host memory)
         n_rows_d = None if HostScalar.enabled else torch.empty(1, dtype=torch.int32, device=dev)
@@ -513,7 +514,7 @@ class WarpSolver:
             head = torch.empty(S, dtype=torch.bool, device=dev)
             head[1:] = (self._tuple_key[1:] != self._tuple_key[:-1]) if self._tuple_key is not None else \
                 (self.snbr[1:] != self.snbr[:-1]).any(dim=1)
-            head[::256] = True                                        # a row never spans two 256-sample tiles
+            head[::int(self.lib.dfh_gn_tile_samples())] = True        # a row never spans two tiles
             self.run_id = torch.cumsum(head, 0, dtype=torch.int32).sub_(1)
             self._row_first = torch.nonzero(head).reshape(-1).to(torch.int32)
             tup = self.snbr[head].long()
@@ -523,7 +524,8 @@ class WarpSolver:
         if reg:
             self._build_reg_plan(keys)
         ne = int(self.lib.dfh_gn_partial_doubles(k))
-        self.partial = torch.empty(max(1, R * ne) + 2 * ((S + 255) // 256) + R, dtype=torch.float64, device=dev)   # rows | {cost, count} per tile | live flag per row
+        tile = int(self.lib.dfh_gn_tile_samples())
+        self.partial = torch.empty(max(1, R * ne) + 2 * ((S + tile - 1) // tile) + R, dtype=torch.float64, device=dev)   # rows | {cost, count} per tile | live flag per row
         if R * k * k >= 2 ** 31:
             raise ValueError("too many sample runs for 32-bit plan entries")
         return bool(covered) if not reg else True          # (reg=True is the call that follows a pattern build: covered by construction)

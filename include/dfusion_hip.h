@@ -332,6 +332,10 @@ int dfh_gn_build_planned_assoc(const double *sample_pos, const double *sample_nr
                                const float *depth, int H, int W, const double K[9], const double Kinv[9], const double lw_cam[12],
                                double scale, const double center[3], double half, double max_dist, void *stream);
 
+/* Samples per tile of the planned build (a scratch row = a run of equal node tuples inside one tile; callers size tile_off,
+ * the per-tile {cost, count} pairs behind the scratch rows and the torch restatement of the plan with it). */
+int dfh_gn_tile_samples(void);
+
 /* ---- per-frame bookkeeping of the planned build, on the device ---------------------------------------------------------
  * dfh_gn_sort_samples: the four per-sample arrays in the order of their node tuples (lexicographic, stable: equal tuples
  *   keep their input order), key_out[i] = the i-th sorted tuple as a knn-digit number in base n_nodes, order_out[i] =

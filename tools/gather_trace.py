@@ -36,7 +36,7 @@ if hasattr(sv.lib, "dfh_debug_build_trace"):
     fn.restype = ctypes.c_int
     buf = (ctypes.c_ulonglong * (8192 * 8))()
     assert fn(buf) == 0
-    nt = (sv.S + 255) // 256
+    nt = (sv.S + 127) // 128
     tr = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)[:nt]
     tr = tr[tr[:, 5] > 0]                      # tiles with valid samples (the others leave early)
     t0 = tr[:, 0].min()

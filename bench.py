@@ -54,6 +54,7 @@ def parse():
                          "weak: --gpus cubes stacked along axis 0")
     ap.add_argument("--launch", default="auto", choices=("auto", "eager", "graph"),
                     help="how the timed K1 steps are issued: eager ctypes calls, one hipGraph replay, auto = the faster")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the streaming micro-benchmark (a child process; profiler runs skip it)")
     ap.add_argument("--no-k1-512", action="store_true", help="skip the 512^3 K1 roofline leg (1 GPU only)")
     ap.add_argument("--job-timeout", type=int, default=1500, help="--gpus N started by this script: seconds after which all ranks are killed")
     ap.add_argument("--leg-timeout", type=int, default=300, help="N > 1: seconds the secondary legs (gn, frame) may take before "
@@ -576,7 +577,7 @@ def main():
     # copy and an in-place read-modify-write of two 512^3 float32 volumes (far beyond the 256 MiB Infinity Cache) as 1-KiB rows and
     # as 4 x 2 x 32 bricks, default and non-temporal cache policy.  The sweep's ceiling is the best RMW figure.  Run as a child
     # process on rank 0 only (its own 1 GiB of HBM).
-    if rank == 0:
+    if rank == 0 and not args.no_ceiling:
         try:
             import subprocess
             ub = os.path.join(ROOT, "tools", "ubench", "rmw_stream")

@@ -2838,8 +2838,9 @@ int dfh_pcg_status(void *stream, long *aborted_solves_out) {
     }
     if (aborted_solves_out) *aborted_solves_out = (long)n;
     if (n)
-        return fail(DFH_E_TIMEOUT, "persistent PCG: %llu solve(s) timed out in a grid barrier (workgroups not co-resident?); x = NaN, "
-                                   "node_dq was left unchanged", n);
+        return fail(DFH_E_TIMEOUT, "persistent PCG: %llu solve(s) timed out in a grid barrier (workgroups not co-resident?); x = NaN; "
+                                   "node_dq is unchanged unless the time-out fell into the LAST reduction (rows whose workgroup had "
+                                   "already passed it applied their step): restore the warp field from before the solve", n);
     return DFH_OK;
 }
 

@@ -396,6 +396,69 @@ class Fusion:
         d = lambda a, b: float(np.sqrt(np.sum((a - b) ** 2)))
         return (d(v1, v2) + d(v1, v3) + d(v2, v3)) / 3
 
+    def fuseDepths(self, dm, lw, tsdf, tsdfw, wmax=100.0, scale=1.0, center=np.zeros(3)):
+        """Integrate one depth map into (tsdf, tsdfw).  The reference's Fusion.fuseDepths (core/fusion.py:127-150) does not run
+        at HEAD (`current_dm`, a three-argument project_to_pixel, a distance that mixes camera and index coordinates); what it
+        sets out to do is what FusionDM.fuseDepths does (core/fusion_dm.py:180-217), so this method IS that sweep (K1,
+        dfh_integrate_depth) with the intrinsics given to InitializeCanonicalSpace -- numpy volumes updated in place and
+        returned, CUDA tensors updated in place."""
+        if getattr(self, '_K', None) is None:
+            raise ValueError('fuseDepths needs the intrinsics: call InitializeCanonicalSpace(..., K=K) first')
+        lw = np.asarray(lw, dtype=np.float64)
+        if lw.shape != (3, 4):
+            raise ValueError('lw must be a 3x4 camera extrinsic')
+        if _is_tensor(tsdf) != _is_tensor(tsdfw):
+            raise ValueError('tsdf and tsdfw must both be numpy arrays or both CUDA tensors')
+        dmn = dm if _is_tensor(dm) else np.asarray(dm)
+        if dmn.ndim != 2 if not _is_tensor(dm) else dm.dim() != 2:
+            raise ValueError('depth map must be 2-D')
+        depth = to_device(dmn, dtype=torch.float32 if (_is_tensor(dm) and dm.dtype == torch.float32) or (not _is_tensor(dm) and f32_exact(dmn))
+                          else torch.float64)
+        if _is_tensor(tsdf):
+            kernels.integrate_depth(tsdf, tsdfw, depth, self._K, self._Kinv, lw, scale, center, self._tdist, wmax, tsdf_res=tsdf.shape[0])
+            return (tsdf, tsdfw)
+        if tsdf.ndim != 3 or tsdf.shape != tsdfw.shape:
+            raise ValueError('tsdf and tsdfw must be 3-D arrays of the same shape')
+        T, Wt = to_device(tsdf, dtype=self._vol_dtype), to_device(tsdfw, dtype=self._vol_dtype)
+        kernels.integrate_depth(T, Wt, depth, self._K, self._Kinv, lw, scale, center, self._tdist, wmax, tsdf_res=tsdf.shape[0])
+        tsdf[...] = T.cpu().numpy()
+        tsdfw[...] = Wt.cpu().numpy()
+        return (tsdf, tsdfw)
+
+    def InitializeCanonicalSpace(self, tsdf=None, depths=None, lws=None, K=None, tsdf_size=256, scale=1.0, center=np.zeros(3)):
+        """The canonical volume from a given TSDF or from depth maps, then the initial mesh and deformation graph: what the
+        reference's method of this name sets out to do (core/fusion.py:73-99; at HEAD it reads an undefined `tsdf.shape`, calls a
+        free `fuseDepths` and iterates `len(depths)`).  From depth maps: the volume starts at +tdist with weight 0
+        (core/fusion.py:80, core/fusion_dm.py:100-101) and the views are fused in order in ONE sweep of the volume
+        (dfh_integrate_depth_multi: the same bits as one fuseDepths call per view, FusionDM.compute_live_tsdf's loop,
+        core/fusion_dm.py:166-170).  scale / center: FusionDM.fuseDepths' voxel -> world map (defaults as there)."""
+        if tsdf is not None:
+            if not _is_tensor(tsdf) and (type(tsdf) is not np.ndarray or tsdf.ndim != 3):
+                raise ValueError('Only 3D numpy array is accepted as tsdf')
+            self._T = to_device(tsdf, dtype=self._vol_dtype)
+            self._tsdf_host = None
+            self._Wt = torch.zeros_like(self._T)                                   # :74
+        elif depths is not None and lws is not None and K is not None:
+            if len(depths) != len(lws):
+                raise ValueError('length of camera matrix array must equal that of depth maps')
+            self._K = np.asarray(K, dtype=np.float64)
+            self._Kinv = np.linalg.inv(self._K)
+            require_gpu()
+            R = int(tsdf_size)
+            self._T = torch.empty((R, R, R), dtype=self._vol_dtype, device="cuda")
+            self._Wt = torch.empty_like(self._T)
+            self._tsdf_host = None
+            ds = [to_device(d if _is_tensor(d) else np.asarray(d), dtype=torch.float32) for d in depths]
+            kernels.integrate_depth_views(self._T, self._Wt, ds, self._K, self._Kinv, [np.asarray(m, dtype=np.float64) for m in lws],
+                                          scale, center, self._tdist, fresh=float(self._tdist))
+        else:
+            raise ValueError('InitializeCanonicalSpace needs a tsdf, or depths, lws and K')
+        if K is not None and getattr(self, '_K', None) is None:
+            self._K = np.asarray(K, dtype=np.float64)
+            self._Kinv = np.linalg.inv(self._K)
+        self._workspace_key = None
+        self.initialize_canonical()
+
     def initialize_canonical(self):
         """What the reference's constructor does after storing the volume (core/fusion.py:86-96): initial
         marching cubes, `_radius` = subsample_rate x mean edge length of the faces, deformation graph.

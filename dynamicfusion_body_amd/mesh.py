@@ -26,7 +26,12 @@ def marching_cubes(volume, level=None, step_size=1, as_numpy=False, order="refer
 class marching_cubes_begin:
     """marching_cubes in two halves: the constructor launches the count pass (on the current stream) and returns; finish() waits
     for the totals, launches the emit passes and returns the mesh.  A caller with other work to queue in between (a frame loop
-    that has just updated the canonical volume) starts the count early and collects the mesh later."""
+    that has just updated the canonical volume) starts the count early and collects the mesh later.
+    Ordering: the count pass's stream is remembered and an event is recorded behind it; finish() may run on any stream -- it
+    makes that stream wait for the event before the emit passes read the count pass's workspace.  The volume must not change
+    between the two halves (the totals that size the outputs were counted on it): finish() checks the volume tensor's
+    version counter and refuses a volume that was written through torch in between (a write through the C ABI is the caller's
+    responsibility)."""
 
     def __init__(self, volume, level=None, step_size=1):
         require_gpu()
@@ -47,11 +52,20 @@ class marching_cubes_begin:
         self.totals = HostScalar(torch.int64, 3)      # (vertices, faces, active tiles: stored into pinned host memory by the scan)
         _lib.check(lib.dfh_mc_count(volume.data_ptr(), dtype_code(volume), self.res, step, self.level, self.ws.data_ptr(),
                                     self.ws.numel() * 8, self.totals.ptr(), current_stream_ptr()), "dfh_mc_count")
+        self._count_stream = current_stream_ptr()
+        self._counted = torch.cuda.Event()
+        self._counted.record()
+        self._version = volume._version
 
     def finish(self, as_numpy=False, order="reference", visit_all_tiles=False):
         if order not in ("reference", "lattice"):
             raise ValueError("order must be 'reference' or 'lattice'")
         lib, volume, ws = self.lib, self.volume, self.ws
+        if volume._version != self._version:
+            raise RuntimeError("the volume was modified between marching_cubes_begin() and finish(): the counted totals no longer "
+                               "describe it")
+        if current_stream_ptr() != self._count_stream:
+            torch.cuda.current_stream().wait_event(self._counted)       # the emit passes read the count pass's workspace
         nv, nf, nactive = self.totals.get()
         if nv >= (1 << 29) or nf >= (1 << 31) // 3:
             raise ValueError("surface too large for 32-bit mesh indices (%d vertices, %d faces)" % (nv, nf))

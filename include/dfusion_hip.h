@@ -423,10 +423,12 @@ int dfh_gn_unpack_upper(double *system, const int *row_of, const int *col, const
 
 /* The persistent PCG kernel (one launch per solve; its workgroups synchronise through grid-wide reductions) is used
  * when all its workgroups are co-resident: the occupancy query admits a workgroup per CU and the grid needs at most
- * half the CUs.  That cannot be known when several PROCESSES time-share one GPU: such callers declare it with
+ * one workgroup per CU.  That cannot be known when several PROCESSES time-share one GPU: such callers declare it with
  * dfh_pcg_set_mode(2) and every solve then takes the two-launches-per-iteration path (0 = auto, the default).
  * A barrier of the persistent kernel that does not complete within its spin bound (seconds) makes every workgroup
- * leave: x_out = NaN, node_dq untouched, and a per-device counter is bumped.  dfh_pcg_status() synchronises `stream`,
+ * leave: x_out = NaN, node_dq untouched (unless the time-out fell into the very last reduction of dfh_pcg_solve_update: the
+ * workgroups that had passed it have applied their rows' steps -- a caller that wants to go on restores node_dq from
+ * before the solve), and a per-device counter is bumped.  dfh_pcg_status() synchronises `stream`,
  * reads and clears that counter: DFH_OK, or DFH_E_TIMEOUT when a solve since the last call timed out
  * (*aborted_solves_out = how many; may be NULL).  Call it wherever the host synchronises anyway. */
 int dfh_pcg_set_mode(int mode);

@@ -494,3 +494,35 @@ def test_ocl_mode_matches_the_float32_restatement(k1_path):
     assert torch.equal(Td.cpu(), torch.from_numpy(To)) and np.array_equal(T3.cpu().numpy(), T3o) and np.array_equal(W3.cpu().numpy(), W3o)
     with pytest.raises(ValueError):
         f.fuseDepths(dm, lw, To, Wo, mode="opencl")
+
+
+def test_fusion_initialize_canonical_space_from_depth_maps():
+    """Fusion.InitializeCanonicalSpace(depths, lws, K) / Fusion.fuseDepths (broken at the reference's HEAD, core/fusion.py:73-99,
+    127-150; here: FusionDM.fuseDepths' sweep): the canonical volume equals FusionDM's for the same views bit for bit, numpy
+    volumes are updated in place, and the object ends up with a mesh and a deformation graph."""
+    from dynamicfusion_body_amd import Fusion
+    R = 48
+    H, W, fx, cx, cy = scene.CAMERAS["C1"]
+    K = scene.intrinsics(fx, cx, cy)
+    scale, center, tdist = scene.grid_params(R)
+    lws = [scene.view_extrinsic(a) for a in (0.0, 45.0, -45.0)]
+    dms = [scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0) for lw in lws]
+    fu = Fusion(np.zeros((4, 4, 4)), tdist, knn=4, write_warpfield=False)
+    fu.InitializeCanonicalSpace(depths=dms, lws=lws, K=K, tsdf_size=R, scale=scale, center=center)
+    fd = FusionDM(tdist, K, tsdf_res=R)
+    T, Wt = fd._new_volume_pair()
+    for d, lw in zip(dms, lws):
+        fd.fuseDepths(torch.from_numpy(d).cuda(), lw, T, Wt, scale=scale, center=center)
+    assert torch.equal(fu._T, T) and torch.equal(fu._Wt, Wt)
+    assert len(fu._nodes) > 4 and len(fu._vertices) > 100 and fu._kdtree is not None
+    # the method itself on numpy volumes (in place + returned), one view
+    Tn, Wn = np.zeros((R, R, R)) + tdist, np.zeros((R, R, R))
+    out = fu.fuseDepths(dms[0], lws[0], Tn, Wn, scale=scale, center=center)
+    assert out[0] is Tn and out[1] is Wn
+    T1, W1 = fd._new_volume_pair()
+    fd.fuseDepths(torch.from_numpy(dms[0]).cuda(), lws[0], T1, W1, scale=scale, center=center)
+    assert np.array_equal(Tn.astype(np.float32), T1.cpu().numpy()) and np.array_equal(Wn.astype(np.float32), W1.cpu().numpy())
+    with pytest.raises(ValueError):
+        fu.InitializeCanonicalSpace()
+    with pytest.raises(ValueError):
+        Fusion(np.zeros((4, 4, 4)), tdist).fuseDepths(dms[0], lws[0], Tn, Wn)          # no intrinsics yet

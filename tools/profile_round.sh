@@ -12,9 +12,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-ceiling > $OUT/bench_trace.json 2> $OUT/trace.err
 echo trace done
-SHORT="--no-cpu-baseline --steps 8 --warmup 4 --gn-solves 1 --launch eager"
+SHORT="--no-cpu-baseline --no-ceiling --steps 8 --warmup 4 --gn-solves 1 --launch eager"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $SHORT > $OUT/bench_fetch.json 2> $OUT/fetch.err
 echo fetch done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $SHORT > $OUT/bench_write.json 2> $OUT/write.err

@@ -12,7 +12,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getsize)      # (the bench process, not a child)
 shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
 out = {"tag": tag, "kernels": {}}
 for r in csv.DictReader(open(stats)):

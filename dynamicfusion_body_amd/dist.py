@@ -177,10 +177,10 @@ def allgather_ragged(t):
 #                unless the capture succeeds (bench.py tries it under RCCL)
 # sharded(P)    = rows / P + gather / P + allreduce + pcg + eager
 # replicated(P) = rows + gather + pcg                 (+ one all-gather of the samples per FRAME: 96 B each)
-# At config 3 (335 k samples, 512 nodes, 1.7 MB system) sharded(8) ~ 4 + 2 + 44 + 43 + 30 = 123 us against 88 replicated: the
-# collective costs more than the 39 us of sample-parallel work it saves -- GN-iters/s would FALL with the GPU count.  At
-# config 4 (828 k samples, 2 048 nodes, 6.8 MB) ~ 10 + 4 + 68 + 55 + 30 = 167 against 165: a wash.  So the default is the
-# replicated solve unless the local work outweighs the collective.
+# At config 3 (335 k samples, 512 nodes, 0.93 MB of upper triangle) sharded(8) ~ 4 + 2 + 40 + 43 + 30 = 119 us against 96 replicated:
+# the collective costs more than the 39 us of sample-parallel work it saves -- GN-iters/s would FALL with the GPU count.  At
+# config 4 (828 k samples, 2 048 nodes, 3.7 MB) ~ 10 + 4 + 54 + 55 + 30 = 153 against 187: sharded wins from P = 4 up.  So the
+# default is the replicated solve unless the local work outweighs the collective (DESIGN.md section 6 has the table).
 def solve_mode(n_samples_total, n_nodes, n_blocks, world_size):
     """'replicated' or 'sharded' for the warp solve on world_size GPUs, by the latency model above."""
     P = int(world_size)
@@ -189,7 +189,7 @@ def solve_mode(n_samples_total, n_nodes, n_blocks, world_size):
     rows = 31.0 * n_samples_total / 335e3
     gather = 14.0 * n_samples_total / 335e3
     pcg = 43.0 + 12.0 * max(0.0, (n_nodes - 512) / 1536.0)
-    nbytes = 8.0 * (36.0 * n_blocks + 6.0 * n_nodes + 2.0)
+    nbytes = 8.0 * (36.0 * (n_blocks + n_nodes) / 2.0 + 6.0 * n_nodes + 2.0)    # upper block triangle | J^T r | cost, count
     allreduce = 35.0 + nbytes * 2.0 * (P - 1) / P / (7 * 48e3)          # bytes / (MB/s -> us): 48 GB/s = 48e3 bytes per us
     eager = 30.0
     frame_gather = 96.0 * n_samples_total * (P - 1) / P / (7 * 48e3) / 10.0      # per iteration of a 10-iteration frame

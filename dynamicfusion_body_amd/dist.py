@@ -173,13 +173,16 @@ def allgather_ragged(t):
 #   pcg(N)       43 us at 512 nodes, 55 at 2 048 (10 iterations, persistent kernel), run by every rank redundantly
 #   allreduce    alpha + bytes * 2 (P - 1) / P / (links * rate): alpha ~ 35 us (RCCL launch + cross-GPU hand-offs of a
 #                latency-bound message), 7 xGMI links at ~48 GB/s sustained each way
-#   eager        ~30 us: a sharded iteration cannot be folded into one host call / one graph with torch's collective in it
-#                unless the capture succeeds (bench.py tries it under RCCL)
+#   eager        ~10 us: a sharded iteration is two library calls with torch's collective between them instead of one call per
+#                frame.  MEASURED with a 1-rank RCCL group on one MI355X (tools/rccl_capture_check.py,
+#                profiles/r3_rccl_capture_1rank.json): +17 us per iteration eager (110.5 against 93.2), of which 7 us are device
+#                time (pack + a 1-rank all-reduce + unpack: 98.6 against 91.5 us as hipGraph replays -- the all-reduce CAPTURES
+#                into a hipGraph with the solve's kernels around it and replays to the same bits)
 # sharded(P)    = rows / P + gather / P + allreduce + pcg + eager
 # replicated(P) = rows + gather + pcg                 (+ one all-gather of the samples per FRAME: 96 B each)
-# At config 3 (335 k samples, 512 nodes, 0.93 MB of upper triangle) sharded(8) ~ 4 + 2 + 40 + 43 + 30 = 119 us against 96 replicated:
-# the collective costs more than the 39 us of sample-parallel work it saves -- GN-iters/s would FALL with the GPU count.  At
-# config 4 (828 k samples, 2 048 nodes, 3.7 MB) ~ 10 + 4 + 54 + 55 + 30 = 153 against 187: sharded wins from P = 4 up.  So the
+# At config 3 (335 k samples, 512 nodes, 0.93 MB of upper triangle) sharded(8) ~ 4 + 2 + 40 + 43 + 10 = 99 us against 96 replicated
+# and 88 on one GPU: the collective costs what the sample-parallel work saves -- GN-iters/s would not rise with the GPU count.  At
+# config 4 (828 k samples, 2 048 nodes, 3.7 MB) ~ 10 + 4 + 54 + 55 + 10 = 133 against 187 (166 on one GPU): sharded wins from P = 2 up.  So the
 # default is the replicated solve unless the local work outweighs the collective (DESIGN.md section 6 has the table).
 def solve_mode(n_samples_total, n_nodes, n_blocks, world_size):
     """'replicated' or 'sharded' for the warp solve on world_size GPUs, by the latency model above."""
@@ -191,7 +194,7 @@ def solve_mode(n_samples_total, n_nodes, n_blocks, world_size):
     pcg = 43.0 + 12.0 * max(0.0, (n_nodes - 512) / 1536.0)
     nbytes = 8.0 * (36.0 * (n_blocks + n_nodes) / 2.0 + 6.0 * n_nodes + 2.0)    # upper block triangle | J^T r | cost, count
     allreduce = 35.0 + nbytes * 2.0 * (P - 1) / P / (7 * 48e3)          # bytes / (MB/s -> us): 48 GB/s = 48e3 bytes per us
-    eager = 30.0
+    eager = 10.0
     frame_gather = 96.0 * n_samples_total * (P - 1) / P / (7 * 48e3) / 10.0      # per iteration of a 10-iteration frame
     sharded = (rows + gather) / P + allreduce + pcg + eager
     replicated = rows + gather + pcg + frame_gather
@@ -208,10 +211,11 @@ def all_ranks(flag):
     return bool(int(t[0]))
 
 
-def allreduce_system(flat):
-    """Sum the flat normal-equation buffer over ranks (in place, one collective)."""
+def allreduce_system(flat, force=False):
+    """Sum the flat normal-equation buffer over ranks (in place, one collective).  force: issue the collective in a group of one
+    too (a rehearsal of the RCCL path on one GPU)."""
     _, ws = world()
-    if ws > 1:
+    if ws > 1 or (force and dist.is_initialized()):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 

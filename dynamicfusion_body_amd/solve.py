@@ -222,6 +222,8 @@ class WarpSolver:
         self.knn = int(knn)
         self.pcg_iters = int(pcg_iters)
         self.distributed = bool(distributed)      # False: ignore an initialised process group
+        self.force_collective = False             # True: run the sharded solve's pack / all-reduce / unpack even in a group of one
+                                                  # (tools/rccl_capture_check.py: the RCCL path rehearsed on a one-GPU box)
         self.node_nbr = None
         self.S = 0
         if _dist.ranks_share_a_gpu():                  # (whether or not THIS solver runs collectives: ADVICE round 2)
@@ -403,7 +405,7 @@ class WarpSolver:
         self.cost_count = self.system[self.B * 36 + 6 * N:]
         # what the multi-GPU all-reduce carries: J^T J is symmetric, only the blocks with col >= row travel (dfh_gn_pack_upper)
         self._tri = None
-        if self.distributed and _dist.world()[1] > 1 and not os.environ.get("DFH_ALLREDUCE_FULL"):
+        if self.distributed and (_dist.world()[1] > 1 or self.force_collective) and not os.environ.get("DFH_ALLREDUCE_FULL"):
             upper = self.col >= rows
             up_rank = (torch.cumsum(upper.to(torch.int64), 0) - 1)
             mkey = self.col.to(torch.int64) * N + rows.to(torch.int64)
@@ -693,7 +695,7 @@ class WarpSolver:
         one_call = (isinstance(d0, torch.Tensor) and d0.is_cuda and d0.dim() == 2 and d0.is_contiguous() and
                     d0.dtype == torch.float32 and self.S > 0 and not os.environ.get("DFH_GN_ATOMIC") and
                     not os.environ.get("DFH_GN_NO_FUSED_ASSOC") and not os.environ.get("DFH_GN_NO_FUSED_ITER") and
-                    not (self.distributed and _dist.world()[1] > 1))
+                    not (self.distributed and (_dist.world()[1] > 1 or self.force_collective)))
         if not one_call:
             for _ in range(int(n_iters)):
                 self.build_associated(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist, huber)
@@ -728,15 +730,15 @@ class WarpSolver:
         """Sum of the normal equations over ranks, in place: the upper block triangle + J^T r + {cost, count} in one collective
         (pack, all-reduce of ~55 % of the system's bytes, unpack with the mirrored blocks transposed), or the whole flat buffer
         (DFH_ALLREDUCE_FULL=1).  One GPU / replicated solve: nothing."""
-        if not self.distributed or _dist.world()[1] == 1:
+        if not self.distributed or (_dist.world()[1] == 1 and not self.force_collective):
             return
         if self._tri is None:
-            _dist.allreduce_system(self.system)
+            _dist.allreduce_system(self.system, force=self.force_collective)
             return
         rows, src, n_upper, packed = self._tri
         _lib.check(self.lib.dfh_gn_pack_upper(self.system.data_ptr(), rows.data_ptr(), self.col.data_ptr(), src.data_ptr(), self.B, self.N,
                                               n_upper, packed.data_ptr(), current_stream_ptr()), "dfh_gn_pack_upper")
-        _dist.allreduce_system(packed)
+        _dist.allreduce_system(packed, force=self.force_collective)
         _lib.check(self.lib.dfh_gn_unpack_upper(self.system.data_ptr(), rows.data_ptr(), self.col.data_ptr(), src.data_ptr(), self.B, self.N,
                                                 n_upper, packed.data_ptr(), current_stream_ptr()), "dfh_gn_unpack_upper")
 

@@ -69,6 +69,29 @@ __global__ __launch_bounds__(256) void surface_count_kernel(const VolT *__restri
     if (threadIdx.x == 0) block_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// The same counts for float32 volumes whose z rows are a multiple of 4 long: a thread takes FOUR CONSECUTIVE voxels (one 16-byte
+// load of T and of W; the count of a block does not depend on which thread looks at which voxel) and runs band_sample -- the
+// neighbour loads and the gradient test -- only for the few per cent that lie in the band.
+__global__ __launch_bounds__(256) void surface_count_vec_kernel(const float *__restrict__ T, const float *__restrict__ W,
+                                                                 const ExtractParams p, int *__restrict__ block_count) {
+    __shared__ int red[4];
+    const long v0 = (long)blockIdx.x * kExVox + 4 * (long)threadIdx.x;
+    int c = 0;
+    if (v0 < p.nvox) {                                   // nvox % 4 == 0: the pack is inside the volume
+        const float4 t = *reinterpret_cast<const float4 *>(T + v0);
+        const float4 w = *reinterpret_cast<const float4 *>(W + v0);
+        const float tt[4] = {t.x, t.y, t.z, t.w}, ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((double)ww[j] > 0.0 && fabs((double)tt[j]) < p.band) c += band_sample<float>(T, W, p, v0 + j, nullptr, nullptr) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 // exclusive scan of the block counts in place (single workgroup), total -> *total_out.  16 K counts per round: every
 // thread takes 16 of them 1024 apart (coalesced, all loads in flight at once), waves scan by shuffles, wave 0 scans the
 // 256 wave totals, three barriers per round.
@@ -196,7 +219,9 @@ int dfh_surface_count(const void *tsdf, const void *tsdf_w, int vol_dtype, const
     DFH_REQUIRE(nb < (1L << 31), "dfh_surface_count: grid too large");
     hipStream_t s = (hipStream_t)stream;
     int *bc = static_cast<int *>(workspace);
-    if (vol_dtype == DFH_F32) {
+    if (vol_dtype == DFH_F32 && res[2] % 4 == 0 && ((uintptr_t)tsdf & 15) == 0 && ((uintptr_t)tsdf_w & 15) == 0) {
+        hipLaunchKernelGGL(surface_count_vec_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float *)tsdf, (const float *)tsdf_w, p, bc);
+    } else if (vol_dtype == DFH_F32) {
         hipLaunchKernelGGL(surface_count_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float *)tsdf, (const float *)tsdf_w, p, bc);
     } else {
         hipLaunchKernelGGL(surface_count_kernel<double>, dim3((unsigned)nb), dim3(256), 0, s, (const double *)tsdf, (const double *)tsdf_w, p, bc);

@@ -583,10 +583,13 @@ struct DqGlobal {
     const double *__restrict__ q;
     __device__ __forceinline__ const double *row(int n) const { return q + 8 * (size_t)n; }
 };
-constexpr int kDqLdsStride = 10;            // doubles per node in LDS: 80-byte rows spread the 16-byte reads of different nodes over the banks
+// doubles per node in LDS: 80-byte rows spread the 16-byte reads of different nodes over the banks (graphs up to 819 nodes: 64 KB,
+// two workgroups per CU); plain 64-byte rows let graphs up to 2 304 nodes (144 KB, one workgroup per CU) use the table too
+constexpr int kDqLdsStride = 10, kDqLdsStrideBig = 8;
+template <int STRIDE>
 struct DqLds {
     const double *q;                        // (the caller indexes its __shared__ array directly: the address space survives inlining)
-    __device__ __forceinline__ const double *row(int n) const { return q + kDqLdsStride * n; }
+    __device__ __forceinline__ const double *row(int n) const { return q + STRIDE * n; }
 };
 
 // The fast path in three steps (the steady-state kernel calls them itself, with deferred exact re-evaluation; dqb_fast_voxel
@@ -868,7 +871,7 @@ struct DqbRunInputs {
     float wi, t, w;
 };
 
-template <typename LiveT, int TPB>
+template <typename LiveT, int TPB, int STRIDE>
 __global__ __launch_bounds__(TPB) void fuse_volume_dqb_lds_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
                                                                    const LiveT *__restrict__ live,
                                                                    const double *__restrict__ node_pos,
@@ -877,8 +880,8 @@ __global__ __launch_bounds__(TPB) void fuse_volume_dqb_lds_kernel(float *__restr
                                                                    const unsigned short *__restrict__ knn_cache,
                                                                    const double *__restrict__ w_cache, const DqbParams p,
                                                                    const RigidFastParams f, int n_runs, const DqbRedoList redo_list) {
-    extern __shared__ double sdq[];                                           // N rows of kDqLdsStride doubles
-    for (int i = threadIdx.x; i < p.N * 8; i += TPB) sdq[(i >> 3) * kDqLdsStride + (i & 7)] = node_dq[i];
+    extern __shared__ double sdq[];                                           // N rows of STRIDE doubles
+    for (int i = threadIdx.x; i < p.N * 8; i += TPB) sdq[(i >> 3) * STRIDE + (i & 7)] = node_dq[i];
     __syncthreads();
     const size_t nvox = (size_t)p.nx * p.Y * p.Z;
     const float *__restrict__ wi_cache = reinterpret_cast<const float *>(w_cache + 3 * nvox);
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(TPB) void fuse_volume_dqb_lds_kernel(float *__restr
         nodes_of(in.idx, bi);
         DqbNorm e;
         e.w0 = in.w0; e.w1 = in.w1; e.w2 = in.w2; e.wi = in.wi;
-        const DqbWarped wp = dqb_stage_warp(DqLds{sdq}, bi, e, p, f, px, py, pz);
+        const DqbWarped wp = dqb_stage_warp(DqLds<STRIDE>{sdq}, bi, e, p, f, px, py, pz);
         LiveT c[8];
         dqb_stage_gather(live, p, wp, c);
         dqb_stage_finish<LiveT, true>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, e.wi, p, wp, c, px, py, pz, (size_t)r * 64 + lane,
@@ -971,25 +974,36 @@ static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const dou
 #define DFH_K3F(MODE) hipLaunchKernelGGL((fuse_volume_dqb_fast_kernel<LiveT, MODE>), dim3((unsigned)nblocks), dim3(256), 0, s, (float *)tsdf, \
                                          (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, p, f)
     const long n_runs = (long)p.nx * p.Y * (p.Z / 64);
-    const size_t lds = (size_t)p.N * kDqLdsStride * sizeof(double);
-    if (mode == 3 && p.Z % 64 == 0 && n_runs < (1L << 25) && lds <= 64 * 1024 && !on(opt().k3_no_lds)) {
-        // persistent grid: as many 256-thread workgroups as fit the chip with this much LDS (160 KB per CU), at most 8 per CU
+    const bool big = (size_t)p.N * kDqLdsStride * sizeof(double) > 64 * 1024;     // (64 KB: what a kernel may ask for without an attribute)
+    const size_t lds = (size_t)p.N * (big ? kDqLdsStrideBig : kDqLdsStride) * sizeof(double);
+    if (mode == 3 && p.Z % 64 == 0 && n_runs < (1L << 25) && lds <= 144 * 1024 && !on(opt().k3_no_lds)) {
+        // persistent grid: as many workgroups as fit the chip with this much LDS (160 KB per CU)
         int dev = 0;
         DFH_HIP_CHECK(hipGetDevice(&dev));
         DeviceInfo &di = device_info(dev);
         if (di.n_cu == 0) DFH_HIP_CHECK(hipDeviceGetAttribute(&di.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         // workgroups of 1024 threads: sixteen waves share one copy of the table (measured 248 us against 263 for 512 / 256)
-        const int tpb = opt().k3_tpb == 256 || opt().k3_tpb == 512 ? (int)opt().k3_tpb : 1024;
+        const int tpb = (opt().k3_tpb == 256 || opt().k3_tpb == 512) && !big ? (int)opt().k3_tpb : 1024;
         long per_cu = (long)(160 * 1024 / (lds + 512));
         const long max_per_cu = 2048 / tpb;
         if (per_cu > max_per_cu) per_cu = max_per_cu;
-        if (opt().k3_wg_per_cu > 0) per_cu = opt().k3_wg_per_cu;
+        if (opt().k3_wg_per_cu > 0 && opt().k3_wg_per_cu < per_cu) per_cu = opt().k3_wg_per_cu;
         long wgs = per_cu * di.n_cu;
         const int wpb = tpb / 64;
         if (wgs * wpb > n_runs) wgs = (n_runs + wpb - 1) / wpb;
-#define DFH_K3L(TPB) hipLaunchKernelGGL((fuse_volume_dqb_lds_kernel<LiveT, TPB>), dim3((unsigned)wgs), dim3(TPB), lds, s, (float *)tsdf, (float *)tsdf_w, \
-                                        (const LiveT *)live, node_pos, node_dq, node_w, knn_cache, w_cache, p, f, (int)n_runs, redo_list)
-        if (tpb == 256) DFH_K3L(256); else if (tpb == 512) DFH_K3L(512); else DFH_K3L(1024);
+#define DFH_K3L(TPB, STRIDE) hipLaunchKernelGGL((fuse_volume_dqb_lds_kernel<LiveT, TPB, STRIDE>), dim3((unsigned)wgs), dim3(TPB), lds, s, (float *)tsdf, \
+                                                (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, knn_cache, w_cache, p, f, (int)n_runs, redo_list)
+        if (big) {
+            // more than 64 KB of dynamic LDS has to be asked for, once per kernel (the attribute sticks to the function)
+            static std::once_flag asked;
+            static hipError_t asked_rc = hipSuccess;
+            std::call_once(asked, [] {
+                asked_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fuse_volume_dqb_lds_kernel<LiveT, 1024, kDqLdsStrideBig>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            });
+            DFH_HIP_CHECK(asked_rc);
+            DFH_K3L(1024, kDqLdsStrideBig);
+        } else if (tpb == 256) DFH_K3L(256, kDqLdsStride); else if (tpb == 512) DFH_K3L(512, kDqLdsStride); else DFH_K3L(1024, kDqLdsStride);
         // ... and right behind it the voxels it put on its redo list, through the exact chain
         hipLaunchKernelGGL((dqb_redo_kernel<LiveT>), dim3(64), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq,
                            node_w, knn_cache, p, redo_list);

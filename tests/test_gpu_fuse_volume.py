@@ -288,16 +288,16 @@ def test_dqb_config3_scale_properties():
     assert torch.equal(T3, T) and torch.equal(W3, W)           # deterministic
 
 
-@pytest.mark.parametrize("field", ["random", "identity"])
+@pytest.mark.parametrize("field", ["random", "identity", "random-1500-nodes"])
 def test_dqb_float32_paths_give_the_same_bits(field):
     """float32 volumes, knn = 4: the fast path in every mode -- search every call, search + store, stored neighbourhoods on
     the persistent LDS kernel (undecidable voxels deferred to the redo list) and on the plain kernel -- gives the same bits;
     the fp64 chain on the same volumes (option k3_exact) gives the same update mask and values within one float32 rounding.
     `identity`: every sample lands on a lattice point, i.e. EVERY voxel takes the exact chain (all of them go through the
-    redo list of the LDS kernel)."""
+    redo list of the LDS kernel).  1 500 nodes: the node table no longer fits 64 KB of LDS -- unpadded rows, one workgroup per CU."""
     from dynamicfusion_body_amd import _lib
     from dynamicfusion_body_amd.dq import twist_exp_dq
-    R, N, k, tdist = 64, 150, 4, 3.0
+    R, N, k, tdist = 64, (1500 if field.endswith("nodes") else 150), 4, 3.0
     g = torch.arange(R, device="cuda", dtype=torch.float32)
     d = torch.sqrt((g[:, None, None] - R / 2) ** 2 + (g[None, :, None] - R / 2) ** 2 + (g[None, None, :] - R / 2) ** 2)
     live = torch.clamp(d - 0.3125 * R + 0.7, -1.5 * tdist, 1.5 * tdist).contiguous()
@@ -305,7 +305,7 @@ def test_dqb_float32_paths_give_the_same_bits(field):
     W0 = (torch.rand((R, R, R), device="cuda") < 0.7).float() * 2.0           # (zeros: the first-touch rule)
     rng = np.random.default_rng(5)
     node_pos, node_w = scene.fibonacci_nodes(N, R)
-    if field == "random":
+    if field.startswith("random"):
         dqs = twist_exp_dq(rng.normal(size=(N, 6)) * np.array([.02, .02, .02, .4, .4, .4]))
         lw = twist_exp_dq(np.array([0.01, -0.02, 0.015, 0.3, -0.2, 0.1]))
     else:

@@ -36,7 +36,10 @@ constexpr int kWave = 64;             // CDNA wavefront
 // threads per tile, a scratch row never spans two tiles.  128 (round 3; 256 before): a tile's life is a chain of dependent
 // phases (association 4.6 us, Jacobian rows 2.9, run bookkeeping 1.2, Gram 3.7-10 by the longest run), the launch lasts two
 // tile lives whatever the occupancy, so tiles are made shorter and more numerous (25.6 KB of LDS each: five per CU).
-constexpr int kGnTile = 128;
+#ifndef DFH_GN_TILE                 // (experiment builds: tools/build_variant.sh <name> -DDFH_GN_TILE=64)
+#define DFH_GN_TILE 128
+#endif
+constexpr int kGnTile = DFH_GN_TILE;
 
 // ---- development switches (dfh_set_option / DFH_OPTIONS, include/dfusion_hip.h) -----------
 // One table, filled once at the first call into the library; -1 = unset.  The call paths read this struct, never the

@@ -138,27 +138,65 @@ __global__ __launch_bounds__(kPlanTile) void plan_runid_kernel(const int *__rest
 // ---- list keys -----------------------------------------------------------------------------------------------------
 // entry e = row * k^2 + sa * k + sb -> key = index of block (node[sa], node[sb]) in the pattern (B if it is not there);
 // entries with sa == 0 also emit the node entry row * k + sb -> key = node[sb]
+// One returning atomic per DISTINCT key of a wave instead of one per lane: the lanes that hold the same key elect the lowest of
+// them, it adds the group's size to the key's count, every lane takes base + its rank inside the group.  The counts are the same;
+// the slots inside a list come out in another order, which does not matter (the lists are sorted afterwards).  Rows are sorted by
+// node tuple, and a wave holds 64 consecutive rows of ONE slot pair (see the kernel), so long stretches share their key: the
+// hottest counters (a node's diagonal block, its node list: ~200 entries) receive a handful of atomics instead of ~200 that
+// serialise on one address at the memory side.
+__device__ __forceinline__ int plan_count_slot(int *__restrict__ cnt, int key, bool active) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    int leader = lane, rank = 0, size = 0;
+    while (todo) {                                               // (wave-uniform loop over the distinct keys)
+        const int l0 = __ffsll((long long)todo) - 1;
+        const int k0 = __shfl(key, l0, 64);
+        const unsigned long long same = __ballot(active && key == k0) & todo;
+        if (active && key == k0) {
+            leader = l0;
+            rank = __popcll(same & ((1ull << lane) - 1ull));
+            size = __popcll(same);
+        }
+        todo &= ~same;
+    }
+    int base = 0;
+    if (active && leader == lane) base = atomicAdd(cnt + key, size);
+    base = __shfl(base, leader, 64);
+    return base + rank;
+}
+
+// Launch: blockIdx.y = the slot pair pr = sa * k + sb, blockIdx.x * 256 + threadIdx.x = the row.
 __global__ __launch_bounds__(256) void plan_keys_kernel(const int *__restrict__ nbr, const int *__restrict__ row_first, int n_rows, int k,
                                                          const int *__restrict__ row_ptr, const int *__restrict__ col, int B,
                                                          int *__restrict__ blk_key, int *__restrict__ blk_val, int *__restrict__ node_key,
                                                          int *__restrict__ node_val, int *__restrict__ uncovered,
                                                          int *__restrict__ blk_cnt, int *__restrict__ node_cnt) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    const int kk = k * k;
-    if (e >= (long)n_rows * kk) return;
-    const int row = (int)(e / kk), pr = (int)(e - (long)row * kk);
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int pr = blockIdx.y, kk = k * k;
     const int sa = pr / k, sb = pr - sa * k;
-    const size_t s0 = (size_t)row_first[row] * k;
-    const int na = nbr[s0 + sa], nb = nbr[s0 + sb];
-    int blk = plan_find_block(row_ptr, col, na, nb);
-    if (blk < 0) { blk = B; atomicOr(uncovered, 1); }
-    blk_key[e] = blk;
-    // counting pass of the lists: the count's old value is this entry's slot inside its list (any order: the lists are
-    // sorted afterwards, each on its own)
-    blk_val[e] = blk < B ? atomicAdd(blk_cnt + blk, 1) : 0;
-    if (sa == 0) {
-        node_key[(size_t)row * k + sb] = nb;
-        node_val[(size_t)row * k + sb] = atomicAdd(node_cnt + nb, 1);
+    const bool in = row < n_rows;
+    int blk = B, nb = 0;
+    if (in) {
+        const size_t s0 = (size_t)row_first[row] * k;
+        const int na = nbr[s0 + sa];
+        nb = nbr[s0 + sb];
+        blk = plan_find_block(row_ptr, col, na, nb);
+        if (blk < 0) { blk = B; atomicOr(uncovered, 1); }
+    }
+    // counting pass of the lists: the count's old value (+ the rank inside the wave's group) is this entry's slot inside its
+    // list (any order: the lists are sorted afterwards, each on its own)
+    const int slot = plan_count_slot(blk_cnt, blk, in && blk < B);
+    if (in) {
+        const size_t e = (size_t)row * kk + pr;
+        blk_key[e] = blk;
+        blk_val[e] = blk < B ? slot : 0;
+    }
+    if (sa == 0) {                                               // (uniform per workgroup)
+        const int nslot = plan_count_slot(node_cnt, nb, in);
+        if (in) {
+            node_key[(size_t)row * k + sb] = nb;
+            node_val[(size_t)row * k + sb] = nslot;
+        }
     }
 }
 
@@ -426,8 +464,8 @@ int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const
     if (on(opt().plan_radix)) {              // the lists through two stable device radix sorts (round 2, first half): kept for A/B
         hipLaunchKernelGGL(plan_zero2_kernel, dim3((unsigned)((n_blocks + n_nodes + 2 + 255) / 256)), dim3(256), 0, s, blk_ptr, n_blocks + 1,
                            node_ptr, n_nodes + 1);
-        hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, row_first, n_rows, knn, row_ptr, col,
-                           n_blocks, bk_in, bk_out, nk_in, nk_out, unc_ws, blk_ptr, node_ptr);
+        hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((n_rows + 255) / 256), (unsigned)(knn * knn)), dim3(256), 0, s, nbr, row_first, n_rows, knn,
+                           row_ptr, col, n_blocks, bk_in, bk_out, nk_in, nk_out, unc_ws, blk_ptr, node_ptr);
         hipLaunchKernelGGL(plan_flag_out_kernel, dim3(1), dim3(1), 0, s, unc_ws, uncovered_out);
         hipLaunchKernelGGL(plan_iota_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, bv_in, (long)E, nv_in, (long)E2);
         DFH_HIP_CHECK(hipGetLastError());
@@ -446,8 +484,8 @@ int dfh_gn_plan_build(const int *nbr, int n_samples, int knn, int n_nodes, const
     // took 26; the result is the same as a stable sort of the entries by key, element for element.
     hipLaunchKernelGGL(plan_zero2_kernel, dim3((unsigned)((n_blocks + n_nodes + 2 + 255) / 256)), dim3(256), 0, s, blk_ptr, n_blocks + 1,
                        node_ptr, n_nodes + 1);
-    hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, row_first, n_rows, knn, row_ptr, col,
-                       n_blocks, bk_in, bv_in, nk_in, nv_in, unc_ws, blk_ptr, node_ptr);
+    hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((n_rows + 255) / 256), (unsigned)(knn * knn)), dim3(256), 0, s, nbr, row_first, n_rows, knn,
+                       row_ptr, col, n_blocks, bk_in, bv_in, nk_in, nv_in, unc_ws, blk_ptr, node_ptr);
     hipLaunchKernelGGL(plan_scan2_kernel, dim3(2), dim3(1024), 0, s, blk_ptr, n_blocks, node_ptr, n_nodes, unc_ws, uncovered_out);
     hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, bk_in, bv_in, (long)E, n_blocks, blk_ptr, blk_ent,
                        nk_in, nv_in, (long)E2, node_ptr, node_ent);

@@ -562,9 +562,10 @@ struct AssocView {
 // Projective association of one warped sample xp (index space) against ONE view: project with the reference's primitives,
 // take the nearest depth pixel, back-project.  Returns validity (before the distance gate); c = correspondence in index
 // space, d2 = its squared distance from xp.
-template <typename DepthT>
-__device__ __forceinline__ bool associate_view(const AssocParams &p, const double *lw, const double *Rinv, const DepthT *__restrict__ depth,
-                                               const D3 &xp, double &c0, double &c1, double &c2, double &d2) {
+// The two halves of it: up to the pixel (no memory access), and from the pixel's depth on.  associate_views runs the first
+// half for several views, asks for their depth values together and only then goes on: one memory round trip per group of
+// views instead of one per view.
+__device__ __forceinline__ bool associate_project(const AssocParams &p, const double *lw, const D3 &xp, double &u, double &v) {
     // index -> world -> camera -> pixel (fusion_dm.py:191-195)
     const double wx = p.scale * (xp.x - p.half) + p.cx, wy = p.scale * (xp.y - p.half) + p.cy, wz = p.scale * (xp.z - p.half) + p.cz;
     const double l0 = ((lw[0] * wx + lw[1] * wy) + lw[2] * wz) + lw[3];
@@ -579,26 +580,39 @@ __device__ __forceinline__ bool associate_view(const AssocParams &p, const doubl
     double rp = __builtin_amdgcn_rcp(p2);
     rp = __builtin_fma(rp, __builtin_fma(-p2, rp, 1.0), rp);
     rp = __builtin_fma(rp, __builtin_fma(-p2, rp, 1.0), rp);
-    const double u = p0 * rp, v = p1 * rp;
-    ok = ok && (u >= 0.0) && (u < (double)(p.W - 1)) && (v >= 0.0) && (v < (double)(p.H - 1));
+    u = p0 * rp; v = p1 * rp;
+    return ok && (u >= 0.0) && (u < (double)(p.W - 1)) && (v >= 0.0) && (v < (double)(p.H - 1));
+}
+
+// z = -depth[rint(v)][rint(u)] (:196) -> validity, correspondence c in index space, its squared distance d2 from xp
+__device__ __forceinline__ bool associate_backproject(const AssocParams &p, const double *lw, const double *Rinv, double z, double u, double v,
+                                                      const D3 &xp, double &c0, double &c1, double &c2, double &d2) {
+    // back-projection K^-1 (z [u,v,1]) (:198-200), camera -> world -> index
+    const double a0 = z * u, a1 = z * v, a2 = z * 1.0;
+    const double q0 = (p.Kinv.m[0] * a0 + p.Kinv.m[1] * a1) + p.Kinv.m[2] * a2 - lw[3];
+    const double q1 = (p.Kinv.m[3] * a0 + p.Kinv.m[4] * a1) + p.Kinv.m[5] * a2 - lw[7];
+    const double q2 = (p.Kinv.m[6] * a0 + p.Kinv.m[7] * a1) + p.Kinv.m[8] * a2 - lw[11];
+    const double X = (Rinv[0] * q0 + Rinv[1] * q1) + Rinv[2] * q2;
+    const double Y = (Rinv[3] * q0 + Rinv[4] * q1) + Rinv[5] * q2;
+    const double Z = (Rinv[6] * q0 + Rinv[7] * q1) + Rinv[8] * q2;
+    c0 = (X - p.cx) * p.inv_scale + p.half;
+    c1 = (Y - p.cy) * p.inv_scale + p.half;
+    c2 = (Z - p.cz) * p.inv_scale + p.half;
+    const double dx = c0 - xp.x, dy = c1 - xp.y, dz = c2 - xp.z;
+    d2 = dx * dx + dy * dy + dz * dz;
+    return z > 0.0;
+}
+
+template <typename DepthT>
+__device__ __forceinline__ bool associate_view(const AssocParams &p, const double *lw, const double *Rinv, const DepthT *__restrict__ depth,
+                                               const D3 &xp, double &c0, double &c1, double &c2, double &d2) {
+    double u, v;
+    bool ok = associate_project(p, lw, xp, u, v);
     c0 = 0.0; c1 = 0.0; c2 = 0.0; d2 = 0.0;
     if (ok) {
         const int ui = (int)rint(u), vi = (int)rint(v);
         const double z = -1.0 * (double)depth[(size_t)vi * p.W + ui];                  // :196
-        ok = z > 0.0;
-        // back-projection K^-1 (z [u,v,1]) (:198-200), camera -> world -> index
-        const double a0 = z * u, a1 = z * v, a2 = z * 1.0;
-        const double q0 = (p.Kinv.m[0] * a0 + p.Kinv.m[1] * a1) + p.Kinv.m[2] * a2 - lw[3];
-        const double q1 = (p.Kinv.m[3] * a0 + p.Kinv.m[4] * a1) + p.Kinv.m[5] * a2 - lw[7];
-        const double q2 = (p.Kinv.m[6] * a0 + p.Kinv.m[7] * a1) + p.Kinv.m[8] * a2 - lw[11];
-        const double X = (Rinv[0] * q0 + Rinv[1] * q1) + Rinv[2] * q2;
-        const double Y = (Rinv[3] * q0 + Rinv[4] * q1) + Rinv[5] * q2;
-        const double Z = (Rinv[6] * q0 + Rinv[7] * q1) + Rinv[8] * q2;
-        c0 = (X - p.cx) * p.inv_scale + p.half;
-        c1 = (Y - p.cy) * p.inv_scale + p.half;
-        c2 = (Z - p.cz) * p.inv_scale + p.half;
-        const double dx = c0 - xp.x, dy = c1 - xp.y, dz = c2 - xp.z;
-        d2 = dx * dx + dy * dy + dz * dz;
+        ok = associate_backproject(p, lw, Rinv, z, u, v, xp, c0, c1, c2, d2);
     }
     return ok;
 }
@@ -624,11 +638,30 @@ __device__ __forceinline__ bool associate_views(const AssocParams &p, const Asso
     bool any = false;
     double best = __builtin_huge_val();
     c[0] = 0.0; c[1] = 0.0; c[2] = 0.0;
-    for (int v = 0; v < n_views; ++v) {                    // (uniform: the views' parameters come through scalar loads)
-        double c0, c1, c2, d2;
-        bool ok = associate_view<DepthT>(p, views[v].lw_cam, views[v].Rinv, static_cast<const DepthT *>(views[v].depth), xp, c0, c1, c2, d2);
-        if (ok && p.max_dist > 0.0) ok = d2 <= p.max_dist * p.max_dist;
-        if (ok && d2 < best) { best = d2; c[0] = c0; c[1] = c1; c[2] = c2; any = true; }
+    constexpr int G = 4;                                   // views per group: their depth gathers are in flight together
+    for (int v0 = 0; v0 < n_views; v0 += G) {              // (uniform: the views' parameters come through scalar loads)
+        double u[G], vv[G], z[G];
+        bool ok[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            ok[j] = false; z[j] = 0.0; u[j] = 0.0; vv[j] = 0.0;
+            if (v0 + j < n_views) {
+                ok[j] = associate_project(p, views[v0 + j].lw_cam, xp, u[j], vv[j]);
+                if (ok[j]) {
+                    const int ui = (int)rint(u[j]), vi = (int)rint(vv[j]);
+                    z[j] = -1.0 * (double)static_cast<const DepthT *>(views[v0 + j].depth)[(size_t)vi * p.W + ui];     // :196
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {                      // (in view order: ties go to the lower index)
+            if (ok[j]) {
+                double c0, c1, c2, d2;
+                bool good = associate_backproject(p, views[v0 + j].lw_cam, views[v0 + j].Rinv, z[j], u[j], vv[j], xp, c0, c1, c2, d2);
+                if (good && p.max_dist > 0.0) good = d2 <= p.max_dist * p.max_dist;
+                if (good && d2 < best) { best = d2; c[0] = c0; c[1] = c1; c[2] = c2; any = true; }
+            }
+        }
     }
     return any;
 }

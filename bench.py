@@ -296,7 +296,7 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
                                                                      " + marching cubes (on a second stream beside the sample refresh)" if world == 1 else "")}
 
 
-def pmc_traffic(kernel_substr, res):
+def pmc_traffic(kernel_substr, res, instance=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     of this same command (profiles/<tag>_summary.json, written by tools/summarize_profile.py:
     2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md §HBM).  The newest matching profile wins
@@ -311,6 +311,10 @@ def pmc_traffic(kernel_substr, res):
                 continue
             for name, t in d["traffic"].items():
                 if kernel_substr in name:
+                    # the column sweep has several template instances (prefetch, non-temporal) in one profile -- the bench's
+                    # 512^3 leg runs another one than the headline: `instance` (the template tail) picks the headline's
+                    if instance is not None and instance not in name:
+                        continue
                     best = (t["hbm_bytes_per_launch"], os.path.basename(f))
         except Exception:
             continue
@@ -609,7 +613,12 @@ def main():
     except Exception as e:                                                   # a secondary figure must not lose the line
         out["multi_view_sweep"] = {"error": repr(e)}
     if world == 1:
-        tr = pmc_traffic(k1_kernel, R)
+        # (template tail of integrate_depth_column_kernel<DepthT, PINHOLE, BY, PREFETCH, NT>: slabs beyond the 256 MiB Infinity Cache
+        # run with prefetch and non-temporal T / w, csrc/dfh_integrate.hip)
+        big = nx * R * R * 8 > (256 << 20)
+        inst = None if "column" not in k1_kernel else (", true, true>" if (big and sweep_path == "columns_culled") else
+                                                        (", false, true>" if big else ", false, false>"))
+        tr = pmc_traffic(k1_kernel, R, inst)
         if tr is not None:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_source"] = "profiles/" + tr[1]

@@ -428,13 +428,13 @@ def test_brick_culling_never_changes_a_voxel(k1_path, monkeypatch):
             lw[:, 3] += rng.normal(size=3) * 0.02
             views.append((lw, scene.render_depth(K, lw, H, W_, invalid_frac=0.05, seed=len(views), dtype=np.float32, wall_z=wall)))
         outs = {}
-        for path in ("bricks", "rows"):
+        for path in ("bricks", "columns", "rows"):       # culled walk (pre-passes) | walk over every brick, image test in the waves | rows
             if path == "rows":
                 _lib.set_option("k1_no_bricks", 1)
             else:
                 _lib.set_option("k1_no_bricks", None)
                 _lib.set_option("k1_bricks_min", 0)
-                _lib.set_option("k1_cull", 1)
+                _lib.set_option("k1_cull", 1 if path == "bricks" else 0)
             T = torch.full(res, tdist / scale, dtype=torch.float32, device="cuda"); Wt = torch.zeros_like(T)
             Tm, Wm = T.clone(), Wt.clone()
             Tsl, Wsl = T.clone(), Wt.clone()
@@ -449,8 +449,9 @@ def test_brick_culling_never_changes_a_voxel(k1_path, monkeypatch):
                                           scale, center, tdist, 7.0)
             assert torch.equal(Tm, T) and torch.equal(Wm, Wt) and torch.equal(Tsl, T) and torch.equal(Wsl, Wt)
             outs[path] = (T, Wt, per_view)
-        assert torch.equal(outs["bricks"][0], outs["rows"][0]) and torch.equal(outs["bricks"][1], outs["rows"][1])
-        assert outs["bricks"][2] == outs["rows"][2]
+        for path in ("bricks", "columns"):
+            assert torch.equal(outs[path][0], outs["rows"][0]) and torch.equal(outs[path][1], outs["rows"][1]), path
+            assert outs[path][2] == outs["rows"][2], path
         assert 0 < int((outs["rows"][1] > 0).sum()) < outs["rows"][1].numel()
     _lib.set_option("k1_no_bricks", None)
 

@@ -289,8 +289,10 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
             "stage_ms_with_syncs": {kk: vv / (nframes - nwarm) for kk, vv in stages.items()},
             "gn_iters_per_frame": iters, "nodes": N, "samples": int(tot.item()), "mesh_vertices": info["vertices"],
             "mesh_faces": info["faces"], "final_cost": cost,
-            "exchange": "none" if world == 1 else "per frame: all-gather of the live volume (%.0f MB) + face-plane halo; per GN "
-                                                  "iteration: one all-reduce of the normal equations" % (R ** 3 * 4 / 1e6),
+            "solve_mode": "single GPU" if world == 1 else sf.solve_mode,
+            "exchange": "none" if world == 1 else ("per frame: all-gather of the live volume (%.0f MB) + face-plane halo" % (R ** 3 * 4 / 1e6)) +
+                        ("; per GN iteration: one all-reduce of the normal equations' upper block triangle" if sf.solve_mode == "sharded" else
+                         " + all-gather of the slabs' samples (96 B each); no collective inside the GN iterations (every rank solves the whole system)"),
             "workload": "%d^3 grid in %d axis-0 slab(s), %d nodes: live TSDF (%d views of %dx%d, one sweep) + %d GN iterations + DQB "
                         "TSDF update + sample refresh%s, per frame" % (R, world, N, len(lws), W, H, iters,
                                                                      " + marching cubes (on a second stream beside the sample refresh)" if world == 1 else "")}

@@ -69,27 +69,151 @@ __global__ __launch_bounds__(256) void surface_count_kernel(const VolT *__restri
     if (threadIdx.x == 0) block_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// The same counts for float32 volumes whose z rows are a multiple of 4 long: a thread takes FOUR CONSECUTIVE voxels (one 16-byte
-// load of T and of W; the count of a block does not depend on which thread looks at which voxel) and runs band_sample -- the
-// neighbour loads and the gradient test -- only for the few per cent that lie in the band.
+// ---- float32 volumes whose z rows are a multiple of 4 long: a thread takes FOUR CONSECUTIVE voxels along z ------------------
+// One 16-byte load of T and of W per thread; a thread that finds one of its voxels in the band fetches the x and y neighbours
+// of all four with four more 16-byte loads (the neighbours of consecutive voxels are consecutive) and the two z neighbours
+// outside the pack -- one round trip, where band_sample makes seven dependent-free but separate 4-byte loads per voxel behind
+// three 64-bit divisions.  band_pack_eval evaluates band_sample's expressions on those values: the same doubles, the same
+// decisions, the same samples.
+struct BandPack {
+    float t[4], w[4];            // the thread's voxels (x, y, z0 .. z0 + 3)
+    float xm[4], xp[4], ym[4], yp[4];
+    float zm, zp;                // T at z0 - 1 and z0 + 4 (clamped to the pack's own ends at the faces)
+    int x, y, z0;
+    int dx, dy;                  // xh - xl, yh - yl of the central differences (2 inside, 1 at a face, 0 on a one-voxel-thick slab)
+    unsigned in_band;            // bit j: voxel j has w > 0 and |T| < band
+};
+
+__device__ __forceinline__ void ld4(const float *a, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4 *>(a);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+
+// loads the pack at voxel v0 (a multiple of 4, inside the volume); neighbours only if a voxel lies in the band
+__device__ __forceinline__ void band_pack_load(const float *__restrict__ T, const float *__restrict__ W, const ExtractParams &p, long v0, BandPack &k) {
+    ld4(T + v0, k.t);
+    ld4(W + v0, k.w);
+    k.in_band = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((double)k.w[j] > 0.0 && fabs((double)k.t[j]) < p.band) k.in_band |= 1u << j;
+    if (!k.in_band) return;
+    long row;                    // index of the z row
+    if (p.nvox < (1L << 31)) {   // (32-bit divisions where the volume allows them)
+        const unsigned r = (unsigned)v0 / (unsigned)p.Z;
+        k.z0 = (int)((unsigned)v0 - r * (unsigned)p.Z);
+        k.x = (int)(r / (unsigned)p.Y);
+        k.y = (int)(r - (unsigned)k.x * (unsigned)p.Y);
+        row = r;
+    } else {
+        row = v0 / p.Z;
+        k.z0 = (int)(v0 - row * p.Z);
+        k.x = (int)(row / p.Y);
+        k.y = (int)(row - (long)k.x * p.Y);
+    }
+    (void)row;
+    const long sx = (long)p.Y * p.Z, sy = p.Z;
+    const int xl = k.x > 0 ? k.x - 1 : 0, xh = k.x < p.X - 1 ? k.x + 1 : p.X - 1;
+    const int yl = k.y > 0 ? k.y - 1 : 0, yh = k.y < p.Y - 1 ? k.y + 1 : p.Y - 1;
+    k.dx = xh - xl; k.dy = yh - yl;
+    ld4(T + (xl * sx + k.y * sy + k.z0), k.xm);
+    ld4(T + (xh * sx + k.y * sy + k.z0), k.xp);
+    ld4(T + (k.x * sx + yl * sy + k.z0), k.ym);
+    ld4(T + (k.x * sx + yh * sy + k.z0), k.yp);
+    k.zm = k.z0 > 0 ? T[v0 - 1] : k.t[0];
+    k.zp = k.z0 + 4 < p.Z ? T[v0 + 4] : k.t[3];
+}
+
+// band_sample for voxel j of a loaded pack
+__device__ __forceinline__ bool band_pack_eval(const BandPack &k, const ExtractParams &p, int j, double *pos, double *nrm) {
+    if (!((k.in_band >> j) & 1u)) return false;
+    const double t = (double)k.t[j];
+    const int z = k.z0 + j;
+    const int zl = z > 0 ? z - 1 : 0, zh = z < p.Z - 1 ? z + 1 : p.Z - 1;
+    const float tzl = zl == z ? k.t[j] : (j > 0 ? k.t[j - 1] : k.zm);
+    const float tzh = zh == z ? k.t[j] : (j < 3 ? k.t[j + 1] : k.zp);
+    const double gx = k.dx > 0 ? ((double)k.xp[j] - (double)k.xm[j]) / (double)k.dx : 0.0;
+    const double gy = k.dy > 0 ? ((double)k.yp[j] - (double)k.ym[j]) / (double)k.dy : 0.0;
+    const double gz = zh > zl ? ((double)tzh - (double)tzl) / (double)(zh - zl) : 0.0;
+    const double n = sqrt((gx * gx + gy * gy) + gz * gz);
+    if (!(n > 1e-6)) return false;
+    if (pos) {
+        const double nx = gx / n, ny = gy / n, nz = gz / n;
+        nrm[0] = nx; nrm[1] = ny; nrm[2] = nz;
+        const double st = t / fmax(n, 1.0);              // (the bounded Newton step of band_sample)
+        pos[0] = (double)(k.x + p.x0) - st * nx;
+        pos[1] = (double)k.y - st * ny;
+        pos[2] = (double)z - st * nz;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void surface_count_vec_kernel(const float *__restrict__ T, const float *__restrict__ W,
                                                                  const ExtractParams p, int *__restrict__ block_count) {
     __shared__ int red[4];
     const long v0 = (long)blockIdx.x * kExVox + 4 * (long)threadIdx.x;
     int c = 0;
     if (v0 < p.nvox) {                                   // nvox % 4 == 0: the pack is inside the volume
-        const float4 t = *reinterpret_cast<const float4 *>(T + v0);
-        const float4 w = *reinterpret_cast<const float4 *>(W + v0);
-        const float tt[4] = {t.x, t.y, t.z, t.w}, ww[4] = {w.x, w.y, w.z, w.w};
+        BandPack k;
+        band_pack_load(T, W, p, v0, k);
+        if (k.in_band) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((double)ww[j] > 0.0 && fabs((double)tt[j]) < p.band) c += band_sample<float>(T, W, p, v0 + j, nullptr, nullptr) ? 1 : 0;
+            for (int j = 0; j < 4; ++j) c += band_pack_eval(k, p, j, nullptr, nullptr) ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) block_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// the emit pass on packs: samples in voxel order = thread order, then the thread's own four
+__global__ __launch_bounds__(256) void surface_emit_vec_kernel(const float *__restrict__ T, const float *__restrict__ W,
+                                                                const ExtractParams p, const int *__restrict__ block_offset,
+                                                                double *__restrict__ pos_out, double *__restrict__ nrm_out,
+                                                                long capacity) {
+    __shared__ int wave_cnt[4];
+    if (block_offset[blockIdx.x + 1] == block_offset[blockIdx.x]) return;       // nothing to emit: do not re-read the voxels
+    const long v0 = (long)blockIdx.x * kExVox + 4 * (long)threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double pos[4][3], nrm[4][3];
+    bool ok[4] = {false, false, false, false};
+    if (v0 < p.nvox) {
+        BandPack k;
+        band_pack_load(T, W, p, v0, k);
+        if (k.in_band) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ok[j] = band_pack_eval(k, p, j, pos[j], nrm[j]);
+        }
+    }
+    int before = 0, wave_total = 0;                      // samples of lower lanes of this wave; of the whole wave
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long m = __ballot(ok[j]);
+        before += __popcll(m & ((1ull << lane) - 1ull));
+        wave_total += __popcll(m);
+    }
+    if (lane == 0) wave_cnt[wv] = wave_total;
+    __syncthreads();
+    long mine = (long)block_offset[blockIdx.x] + before;
+    for (int w_ = 0; w_ < wv; ++w_) mine += wave_cnt[w_];
+    const long total = (long)block_offset[gridDim.x];    // sentinel written by the scan: number of samples of the volume
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!ok[j]) continue;
+        long dst = mine;
+        bool keep = true;
+        if (capacity < total) {                          // an EVEN subsample in voxel order (see surface_emit_kernel)
+            dst = (long)(((__int128)mine * capacity) / total);
+            keep = mine == 0 || (long)(((__int128)(mine - 1) * capacity) / total) != dst;
+        }
+        if (keep) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { pos_out[3 * dst + a] = pos[j][a]; nrm_out[3 * dst + a] = nrm[j][a]; }
+        }
+        ++mine;
+    }
 }
 
 // exclusive scan of the block counts in place (single workgroup), total -> *total_out.  16 K counts per round: every
@@ -243,7 +367,9 @@ int dfh_surface_emit(const void *tsdf, const void *tsdf_w, int vol_dtype, const 
     const long nb = (p.nvox + kExVox - 1) / kExVox;
     hipStream_t s = (hipStream_t)stream;
     const int *bo = static_cast<const int *>(workspace);
-    if (vol_dtype == DFH_F32) {
+    if (vol_dtype == DFH_F32 && res[2] % 4 == 0 && ((uintptr_t)tsdf & 15) == 0 && ((uintptr_t)tsdf_w & 15) == 0) {
+        hipLaunchKernelGGL(surface_emit_vec_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float *)tsdf, (const float *)tsdf_w, p, bo, pos_out, nrm_out, capacity);
+    } else if (vol_dtype == DFH_F32) {
         hipLaunchKernelGGL(surface_emit_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float *)tsdf, (const float *)tsdf_w, p, bo, pos_out, nrm_out, capacity);
     } else {
         hipLaunchKernelGGL(surface_emit_kernel<double>, dim3((unsigned)nb), dim3(256), 0, s, (const double *)tsdf, (const double *)tsdf_w, p, bo, pos_out, nrm_out, capacity);

@@ -929,6 +929,9 @@ __global__ __launch_bounds__(TPB) void fuse_volume_dqb_lds_kernel(float *__restr
 
 // The voxels the steady-state kernel could not decide (a float32 rounding tie of x1, a sample on a cell or volume boundary, s
 // at -tdist: ~1e-4 of them), through the reference's chain.  Fixed grid; the last block to finish clears the list's header.
+// (fixed grid: the list's length is known on the device only; one or two voxels per thread at the usual ~0.5 % of a 256^3 volume --
+// with 64 blocks a thread walked five of them one after the other: 12.6 us)
+constexpr int kRedoBlocks = 512;
 template <typename LiveT>
 __global__ __launch_bounds__(256) void dqb_redo_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const LiveT *__restrict__ live,
                                                         const double *__restrict__ node_pos, const double *__restrict__ node_dq,
@@ -1005,7 +1008,7 @@ static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const dou
             DFH_K3L(1024, kDqLdsStrideBig);
         } else if (tpb == 256) DFH_K3L(256, kDqLdsStride); else if (tpb == 512) DFH_K3L(512, kDqLdsStride); else DFH_K3L(1024, kDqLdsStride);
         // ... and right behind it the voxels it put on its redo list, through the exact chain
-        hipLaunchKernelGGL((dqb_redo_kernel<LiveT>), dim3(64), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq,
+        hipLaunchKernelGGL((dqb_redo_kernel<LiveT>), dim3(kRedoBlocks), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq,
                            node_w, knn_cache, p, redo_list);
 #undef DFH_K3L
     } else if (mode == 0) DFH_K3F(0); else if (mode == 1) DFH_K3F(1); else if (mode == 2) DFH_K3F(2); else DFH_K3F(3);

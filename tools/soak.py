@@ -24,8 +24,10 @@ depths = [[torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, in
 
 t0 = time.perf_counter()
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+solves = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 for f in range(frames):
-    sf.step(depths[f % 21], lws, gn_iters=10, huber=float(os.environ.get('HUBER', '0.5')), max_dist=float(os.environ.get('GATE', '2')))
+    sf.step(depths[f % 21], lws, gn_iters=10, huber=float(os.environ.get('HUBER', '0.5')), max_dist=float(os.environ.get('GATE', '2')),
+            data_views=int(os.environ['VIEWS']) if os.environ.get('VIEWS') else None)      # VIEWS=1: the data term on the first view only
     if f % 50 == 49:
         dq = sf.fs.solver.node_dq
         assert torch.isfinite(dq).all(), "non-finite warp field at frame %d" % f
@@ -36,7 +38,7 @@ for f in range(frames):
 sv = sf.fs.solver
 v0 = sv.vals.clone()
 x_ref = None
-for i in range(5000):
+for i in range(solves):
     sv.vals.copy_(v0)
     sv.solve_linear(1e-2, 1e-2)
     if i % 1000 == 999:

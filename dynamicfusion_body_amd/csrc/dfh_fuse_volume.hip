@@ -929,9 +929,9 @@ __global__ __launch_bounds__(TPB) void fuse_volume_dqb_lds_kernel(float *__restr
 
 // The voxels the steady-state kernel could not decide (a float32 rounding tie of x1, a sample on a cell or volume boundary, s
 // at -tdist: ~1e-4 of them), through the reference's chain.  Fixed grid; the last block to finish clears the list's header.
-// (fixed grid: the list's length is known on the device only; one or two voxels per thread at the usual ~0.5 % of a 256^3 volume --
-// with 64 blocks a thread walked five of them one after the other: 12.6 us)
-constexpr int kRedoBlocks = 512;
+// (fixed grid: the list's length is known on the device only.  64 blocks: 12.6 us at the usual ~0.5 % of a 256^3 volume; 512 blocks,
+// one voxel per thread, took 16.7 us -- the launch is the header's round trip and the last block's hand-shake, not the voxels)
+constexpr int kRedoBlocks = 64;
 template <typename LiveT>
 __global__ __launch_bounds__(256) void dqb_redo_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const LiveT *__restrict__ live,
                                                         const double *__restrict__ node_pos, const double *__restrict__ node_dq,

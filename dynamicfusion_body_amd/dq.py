@@ -69,3 +69,29 @@ def SE3TDQ(M):
     if q[0] < 0:
         q = -q
     return np.concatenate([q, 0.5 * qmul(np.array([0.0, t[0], t[1], t[2]]), q)])
+
+
+# ---- the reference's small helpers beside its DQ algebra (core/util.py) ------------------------------------------
+def huber_loss(x, c):
+    """Huber's rho of core/util.py:50-54: x^2 / 2 up to |x| = c, c (|x| - c / 2) beyond; scalars or arrays.  (The solver
+    applies it as IRLS weights on the data rows: dfh_gn_build_planned's huber_delta.)"""
+    a = np.abs(x)
+    return np.where(a <= c, 0.5 * np.square(x), c * (a - 0.5 * c)) if np.ndim(x) else (0.5 * x * x if a <= c else c * (a - 0.5 * c))
+
+
+def tukey_biweight_loss(x, c):
+    """core/util.py:56-60 as written there: x (1 - (x / c)^2)^2 inside |x| <= c, 0 outside (the biweight's influence
+    function rather than its rho; reproduced, not corrected); scalars or arrays."""
+    if np.ndim(x):
+        x = np.asarray(x, dtype=np.float64)
+        return np.where(np.abs(x) > c, 0.0, x * np.square(1.0 - np.square(x / c)))
+    return 0 if abs(x) > c else x * (1 - (x / c) ** 2) ** 2
+
+
+def inverse_rigid_matrix(A):
+    """Inverse of a 3 x 4 rigid transform [R | t] as a 3 x 4 matrix [R^-1 | -R^-1 t] (core/util.py:338-346)."""
+    A = np.asarray(A, dtype=np.float64)
+    if A.shape != (3, 4):
+        raise ValueError("a 3 x 4 matrix [R | t] is expected")
+    Rinv = np.linalg.inv(A[:, :3])
+    return np.concatenate([Rinv, -(Rinv @ A[:, 3])[:, None]], axis=1)

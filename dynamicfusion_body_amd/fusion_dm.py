@@ -66,6 +66,24 @@ class FusionDM:
         self._verbose = verbose
         self._write_warpfield = write_warpfield
 
+    def verbose_gpu(self):
+        """What the reference's device plug-in prints about its OpenCL devices (FusionDM_GPU.verbose_gpu, core/fusion_dm.py:576-598),
+        for the HIP devices this process sees: name, compute units, clock, memory, LDS and workgroup limits, the library's ABI."""
+        from . import _lib
+        print('\n' + '=' * 60 + '\nHIP devices (libdfusion_hip ABI %d)' % _lib.ABI_VERSION)
+        if not torch.cuda.is_available():
+            print('    none visible')
+        for i in range(torch.cuda.device_count()):
+            p = torch.cuda.get_device_properties(i)
+            print('=' * 60)
+            print('    Device %d - Name:  %s (%s)' % (i, p.name, getattr(p, "gcnArchName", "")))
+            print('    Device - Compute Units:  {0}'.format(p.multi_processor_count))
+            print('    Device - Max Clock Speed:  {0:.0f} Mhz'.format(getattr(p, "clock_rate", 0) / 1e3))
+            print('    Device - Local Memory:  {0:.0f} KB'.format(getattr(p, "shared_memory_per_block", 0) / 1024.0))
+            print('    Device - Global Memory: {0:.0f} GB'.format(p.total_memory / 1073741824.0))
+            print('    Device - Max Work Group Size: {0:.0f}'.format(getattr(p, "max_threads_per_block", 1024)))
+        print('\n')
+
     # ------------------------------------------------------------------ volumes
     def _new_volume_pair(self, res=None):
         require_gpu()

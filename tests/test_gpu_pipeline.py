@@ -110,7 +110,7 @@ def test_device_extraction_matches_torch_definition(dtype):
     offset, capacity truncation, empty result."""
     from dynamicfusion_body_amd.pipeline import extract_surface_samples_torch
     rng = np.random.default_rng(12)
-    for shape, x0 in (((40, 33, 37), 0), ((7, 64, 50), 13), ((9, 21, 44), 5), ((64, 64, 64), 0)):   # (z rows of 44, 64: the 16-byte-pack kernels)
+    for shape, x0 in (((40, 33, 37), 0), ((7, 64, 50), 13), ((9, 21, 44), 5), ((1, 40, 48), 3), ((64, 64, 64), 0)):   # (z rows of 44, 48, 64: the 16-byte-pack kernels; a one-plane slab)
         g = np.stack(np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij"), axis=-1)
         T = np.linalg.norm(g - (np.array(shape) / 2.0 + 0.3), axis=-1) - max(min(shape), 12) / 3.0 + 0.05 * rng.normal(size=shape)
         W = (rng.random(shape) < 0.8).astype(np.float64)

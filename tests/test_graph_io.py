@@ -113,3 +113,24 @@ def test_product_dq_helpers_against_the_reference(golden):
     # non-unit real part: the rotation is that of the normalised quaternion (core/util.py:86-89)
     d = g["warp_dq_non"][0]
     assert np.allclose(dq.DQTSE3(d)[:3, :3] @ dq.DQTSE3(d)[:3, :3].T, np.eye(3), atol=1e-12)
+
+
+def test_small_helpers_of_the_reference_util_module():
+    """huber_loss / tukey_biweight_loss / inverse_rigid_matrix (core/util.py:50-60,338-346) on the product side: the oracle's
+    scalar restatements on scalars, the same values elementwise on arrays, and M^-1 (M x) = x."""
+    from dynamicfusion_body_amd import dq as D
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.normal(size=40) * 2.0, [0.0, 1.5, -1.5]])
+    for c in (0.5, 1.5):
+        assert np.array_equal(D.huber_loss(xs, c), np.array([O.huber_loss(x, c) for x in xs]))
+        assert np.array_equal(D.tukey_biweight_loss(xs, c), np.array([O.tukey_biweight_loss(x, c) for x in xs], dtype=np.float64))
+        assert D.huber_loss(float(xs[0]), c) == O.huber_loss(float(xs[0]), c)
+        assert D.tukey_biweight_loss(float(xs[1]), c) == O.tukey_biweight_loss(float(xs[1]), c)
+    M = D.DQTSE3(D.twist_exp_dq(np.array([0.3, -0.2, 0.5, 0.7, -1.1, 0.4])))[:3]
+    Mi = D.inverse_rigid_matrix(M)
+    x = rng.normal(size=3)
+    y = M[:, :3] @ x + M[:, 3]
+    assert Mi.shape == (3, 4) and np.abs(Mi[:, :3] @ y + Mi[:, 3] - x).max() < 1e-12
+    with pytest.raises(ValueError):
+        D.inverse_rigid_matrix(np.eye(4))

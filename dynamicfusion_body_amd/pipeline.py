@@ -58,7 +58,7 @@ def extract_surface_samples_torch(T, Wt, band, x0=0, max_samples=None):
 
     def diff(axis_idx, n, take):
         lo, hi = (axis_idx - 1).clamp(min=0), (axis_idx + 1).clamp(max=n - 1)
-        return (take(hi) - take(lo)) / (hi - lo).to(torch.float64)
+        return (take(hi) - take(lo)) / (hi - lo).clamp(min=1).to(torch.float64)      # (a one-voxel-thick axis: 0 / 1, as the kernels)
     gx = diff(ix, X, lambda a: Tf[a, iy, iz])
     gy = diff(iy, Y, lambda a: Tf[ix, a, iz])
     gz = diff(iz, Z, lambda a: Tf[ix, iy, a])

@@ -979,7 +979,20 @@ static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const dou
     const long n_runs = (long)p.nx * p.Y * (p.Z / 64);
     const bool big = (size_t)p.N * kDqLdsStride * sizeof(double) > 64 * 1024;     // (64 KB: what a kernel may ask for without an attribute)
     const size_t lds = (size_t)p.N * (big ? kDqLdsStrideBig : kDqLdsStride) * sizeof(double);
-    if (mode == 3 && p.Z % 64 == 0 && n_runs < (1L << 25) && lds <= 144 * 1024 && !on(opt().k3_no_lds)) {
+    bool lds_path = mode == 3 && p.Z % 64 == 0 && n_runs < (1L << 25) && lds <= 144 * 1024 && !on(opt().k3_no_lds);
+    if (lds_path && big) {
+        // more than 64 KB of dynamic LDS has to be asked for, once per kernel (the attribute sticks to the function); a device that
+        // refuses takes the gather kernel below
+        static std::once_flag asked;
+        static hipError_t asked_rc = hipSuccess;
+        std::call_once(asked, [] {
+            asked_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fuse_volume_dqb_lds_kernel<LiveT, 1024, kDqLdsStrideBig>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            if (asked_rc != hipSuccess) (void)hipGetLastError();
+        });
+        lds_path = asked_rc == hipSuccess;
+    }
+    if (lds_path) {
         // persistent grid: as many workgroups as fit the chip with this much LDS (160 KB per CU)
         int dev = 0;
         DFH_HIP_CHECK(hipGetDevice(&dev));
@@ -996,17 +1009,8 @@ static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const dou
         if (wgs * wpb > n_runs) wgs = (n_runs + wpb - 1) / wpb;
 #define DFH_K3L(TPB, STRIDE) hipLaunchKernelGGL((fuse_volume_dqb_lds_kernel<LiveT, TPB, STRIDE>), dim3((unsigned)wgs), dim3(TPB), lds, s, (float *)tsdf, \
                                                 (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, knn_cache, w_cache, p, f, (int)n_runs, redo_list)
-        if (big) {
-            // more than 64 KB of dynamic LDS has to be asked for, once per kernel (the attribute sticks to the function)
-            static std::once_flag asked;
-            static hipError_t asked_rc = hipSuccess;
-            std::call_once(asked, [] {
-                asked_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fuse_volume_dqb_lds_kernel<LiveT, 1024, kDqLdsStrideBig>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            });
-            DFH_HIP_CHECK(asked_rc);
-            DFH_K3L(1024, kDqLdsStrideBig);
-        } else if (tpb == 256) DFH_K3L(256, kDqLdsStride); else if (tpb == 512) DFH_K3L(512, kDqLdsStride); else DFH_K3L(1024, kDqLdsStride);
+        if (big) DFH_K3L(1024, kDqLdsStrideBig);
+        else if (tpb == 256) DFH_K3L(256, kDqLdsStride); else if (tpb == 512) DFH_K3L(512, kDqLdsStride); else DFH_K3L(1024, kDqLdsStride);
         // ... and right behind it the voxels it put on its redo list, through the exact chain
         hipLaunchKernelGGL((dqb_redo_kernel<LiveT>), dim3(kRedoBlocks), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq,
                            node_w, knn_cache, p, redo_list);

@@ -113,7 +113,7 @@ int dfh_integrate_depth_multi(void *tsdf, void *tsdf_w, int vol_dtype, const int
 /* A live volume from scratch: the volumes are first set to (fresh_value, 0) -- the reference's np.zeros(...) + tdist and
  * np.zeros(...) in front of its fuseDepths loops, core/fusion_dm.py:100-101,152-153 -- and the n_views depth maps are then fused as
  * by dfh_integrate_depth_multi: the result is that of the two fills followed by that call, bit for bit (fresh_value is rounded to
- * the volume's type).  With the brick sweep the fill is part of the sweep: nothing is read and every voxel of the slab is written
+ * the volume's type).  With the column sweep the fill is part of the sweep: nothing is read and every voxel of the slab is written
  * once (a 256^3 live volume of three views: fills 38 + sweep 89 -> sweep 84 us); otherwise the slab is filled by a launch of its own first.
  * n_views == 0 only fills. */
 int dfh_integrate_depth_multi_fresh(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int tsdf_res, int x0, int x1,
@@ -251,7 +251,7 @@ int dfh_dq_blend_points(const double *points, int n_points, const int *nbr, int 
  * (:198-200) and map back to index space.  valid_out[s] = 0 when outside the image, no depth, or farther
  * than max_dist voxels from the warped sample (max_dist <= 0: no gate). */
 /* out[i] = in[order[i]] for the four per-sample arrays at once (samples are sorted by node tuple before the build:
- * few runs per 256-sample tile).  order: n_samples int64 indices, a permutation. */
+ * few runs per tile of dfh_gn_tile_samples() samples).  order: n_samples int64 indices, a permutation. */
 int dfh_permute_samples(const long *order, int n_samples, int knn, const double *pos, const double *nrm, const int *nbr,
                         const double *weights, double *pos_out, double *nrm_out, int *nbr_out, double *weights_out, void *stream);
 
@@ -292,9 +292,9 @@ int dfh_gn_build(const double *sample_pos, const double *sample_nrm, const int *
 
 /* The same normal equations without floating-point atomics in the data term (same bits every run), for
  * callers that prepare a plan once per frame (samples and their node tuples are static while the warp field
- * moves).  Samples sorted by node tuple; a "row" = a maximal run of equal tuples inside one 256-sample tile:
+ * moves).  Samples sorted by node tuple; a "row" = a maximal run of equal tuples inside one tile of dfh_gn_tile_samples() (128) samples:
  *   run_id[s]           row of sample s (n_rows rows);  partial: scratch of n_rows x dfh_gn_partial_doubles(knn)
- *                       + 2 x ceil(n_samples / 256) + n_rows doubles (the rows | {cost, count} per tile | one live flag per row)
+ *                       + 2 x ceil(n_samples / dfh_gn_tile_samples()) + n_rows doubles (the rows | {cost, count} per tile | one live flag per row)
  *   blk_ptr (n_blocks+1), blk_ent   for block b the entries row * knn^2 + sa * knn + sb (slots sa, sb of the
  *                                   row's tuple hold the block's row node and column node), any fixed order
  *   node_ptr (n_nodes+1), node_ent  for node a the entries row * knn + slot
@@ -340,8 +340,8 @@ int dfh_gn_tile_samples(void);
  * dfh_gn_sort_samples: the four per-sample arrays in the order of their node tuples (lexicographic, stable: equal tuples
  *   keep their input order), key_out[i] = the i-th sorted tuple as a knn-digit number in base n_nodes, order_out[i] =
  *   input index of the i-th sorted sample.
- * dfh_gn_plan_count:   rows = maximal runs of equal tuples inside 256-sample tiles of the SORTED nbr; tile_off
- *   (ceil(n_samples/256) + 1 ints) <- first row of every tile, *n_rows_out (device) <- number of rows.
+ * dfh_gn_plan_count:   rows = maximal runs of equal tuples inside tiles of dfh_gn_tile_samples() samples of the SORTED nbr; tile_off
+ *   (ceil(n_samples / dfh_gn_tile_samples()) + 1 ints) <- first row of every tile, *n_rows_out (device) <- number of rows.
  *   (*n_rows_out, like *uncovered_out below and dfh_surface_count's *total_out, is written by ONE plain store of the sequence's
  *   last writer: it may be device memory or pinned host memory, which the host can then watch instead of queueing a copy.)
  * dfh_gn_plan_build:   run_id (n_samples), row_first (n_rows: first sample of every row) and the CSR lists of

@@ -80,11 +80,11 @@ _SIGNATURES = {
                                       _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, _vp, _vp]),
     "dfh_gn_build_planned_assoc_views": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _c_double_p, _dbl,
                                                 _vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                                _dbl, _vp, _int, _int, _int, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp]),
+                                                _dbl, _vp, _int, _int, _int, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, _int, _vp]),
     "dfh_gn_iteration_views": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _c_double_p, _dbl,
                                       _vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _dbl, _vp, _int, _int, _int, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl,
-                                      _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _dbl, _int, _vp]),
+                                      _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _dbl, _int, _vp, _int, _vp]),
     "dfh_gn_pack_upper": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "dfh_gn_unpack_upper": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "dfh_gn_sort_workspace_bytes": (ctypes.c_size_t, [_int]),

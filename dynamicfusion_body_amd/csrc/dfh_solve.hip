@@ -1450,14 +1450,20 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
                                                         const int *__restrict__ node_ptr, const int *__restrict__ node_ent,
                                                         int n_nodes, double *__restrict__ vals, double *__restrict__ rhs,
                                                         double *__restrict__ cost_count, const double *__restrict__ cc, int n_cc,
-                                                        int cc_stride, bool accumulate, int only_part, const RegLists rl) {
+                                                        int cc_stride, bool accumulate, int only_part, const RegLists rl,
+                                                        const int2 *__restrict__ upper = nullptr, int n_upper = 0) {
+    // upper (optional): J^T J is symmetric and so is the way its blocks are summed -- block (b, a)'s list holds the rows of block
+    // (a, b)'s with the slots swapped, walked in the same order -- so only the n_upper blocks with column >= row are walked
+    // (upper[u] = {block, its mirror block or -1 on the diagonal}) and each wave stores its sums twice, the second time
+    // transposed: half the block waves, half the gather's reads.
     // cc: n_cc {cost, count} pairs, cc_stride doubles apart (per tile for the data term, per pair row for the regulariser)
     // only_part (debug timing): 0 = all, 1 = blocks, 2 = J^T r, 3 = cost
     // accumulate: add to what is there (a gather of its own for the regulariser rows) instead of storing
     const int nrw = (n_nodes + 3) / 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ double red[4][64];
-    const int nbw = (n_blocks + 3) / 4;
+    const int n_walk = upper ? n_upper : n_blocks;
+    const int nbw = (n_walk + 3) / 4;
     if (only_part) {
         const int part_of = (int)blockIdx.x < nbw ? 1 : ((int)blockIdx.x < nbw + nrw ? 2 : 3);
         if (part_of != only_part) return;
@@ -1466,12 +1472,18 @@ __global__ __launch_bounds__(256) void gn_gather_kernel(const double *__restrict
         __shared__ GatherLds L;
         // a workgroup's four blocks are a quarter of the block range apart: neighbouring blocks are the same node's row
         // and have long lists together, which one workgroup would walk alone
-        const int b = wv * nbw + (int)blockIdx.x;
-        const bool real = b < n_blocks;
+        const int u = wv * nbw + (int)blockIdx.x;
+        const bool real = u < n_walk;
+        int b = u, mir = -1;
+        if (upper && real) { const int2 um = upper[u]; b = um.x; mir = um.y; }
         const double acc = gather_block_both<K>(partial, live, blk_ptr, blk_ent, rl.partial, rl.blk_ptr, rl.blk_ent, b, real, lane, wv, L);
         if (real && lane < 36) {
             double *dst = vals + 36 * (size_t)b + lane;
             *dst = accumulate ? *dst + acc : acc;
+            if (mir >= 0) {
+                double *dm = vals + 36 * (size_t)mir + 6 * (lane % 6) + lane / 6;
+                *dm = accumulate ? *dm + acc : acc;
+            }
         }
     } else if ((int)blockIdx.x < nbw + nrw) {
         const int a = ((int)blockIdx.x - nbw) * 4 + wv;
@@ -2597,7 +2609,7 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
                          const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
                          const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
                          void *stream, const dfh::AssocArgs *assoc = nullptr, double *zero_ptr = nullptr, size_t zero_count = 0,
-                         bool *zeroed = nullptr) {
+                         bool *zeroed = nullptr, const int *blk_upper = nullptr, int n_upper = 0) {
     using namespace dfh;
     if (zeroed) *zeroed = false;
     const bool planned = blk_ptr != nullptr;
@@ -2675,11 +2687,13 @@ static int gn_build_impl(const double *sample_pos, const double *sample_nrm, con
         rl.n_rows = n_nodes * knn;
     }
     if (planned) {
-        dim3 grid((unsigned)((n_blocks + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
+        const int2 *upper = (blk_upper && n_upper > 0 && !on(opt().gn_gather_full)) ? reinterpret_cast<const int2 *>(blk_upper) : nullptr;
+        const int n_walk = upper ? n_upper : n_blocks;
+        dim3 grid((unsigned)((n_walk + 3) / 4 + (n_nodes + 3) / 4 + 1)), block(256);
 #define DFH_GATHER(KK)                                                                                              \
     case KK:                                                                                                        \
         hipLaunchKernelGGL(gn_gather_kernel<KK>, grid, block, 0, s, partial, tile_cost + 2 * (size_t)n_tiles, n_rows, blk_ptr, blk_ent, n_blocks, node_ptr,  \
-                           node_ent, n_nodes, vals, rhs, cost_count, tile_cost, n_tiles, 2, false, dbg_part, rl);   \
+                           node_ent, n_nodes, vals, rhs, cost_count, tile_cost, n_tiles, 2, false, dbg_part, rl, upper, n_upper);   \
         break
         switch (knn) {
             DFH_GATHER(1); DFH_GATHER(2); DFH_GATHER(3); DFH_GATHER(4); DFH_GATHER(5); DFH_GATHER(6); DFH_GATHER(7); DFH_GATHER(8);
@@ -2764,7 +2778,8 @@ static int gn_build_planned_assoc_impl(const char *what, const double *sample_po
                                const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
                                const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
                                const float *depth, const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
-                               const double lw_cam[12], double scale, const double center[3], double half, double max_dist, void *stream) {
+                               const double lw_cam[12], double scale, const double center[3], double half, double max_dist, void *stream,
+                               const int *blk_upper = nullptr, int n_upper = 0) {
     using namespace dfh;
     DFH_REQUIRE(blk_ptr, "%s: null blk_ptr", what);
     DFH_REQUIRE((depth || views) && K && Kinv && lw_cam && center && lw_dq && corr_out && valid_out, "%s: null pointer", what);
@@ -2777,7 +2792,8 @@ static int gn_build_planned_assoc_impl(const char *what, const double *sample_po
     aa.n_views = n_views;
     return gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
                          n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
-                         blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream, &aa);
+                         blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream, &aa,
+                         nullptr, 0, nullptr, blk_upper, n_upper);
 }
 
 int dfh_gn_build_planned_assoc(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
@@ -2804,14 +2820,16 @@ int dfh_gn_build_planned_assoc_views(const double *sample_pos, const double *sam
                                const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
                                const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
                                const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
-                               double scale, const double center[3], double half, double max_dist, void *stream) {
+                               double scale, const double center[3], double half, double max_dist, const int *blk_upper, int n_upper,
+                               void *stream) {
     using namespace dfh;
     DFH_REQUIRE(views && n_views >= 1 && n_views <= DFH_GN_MAX_VIEWS, "dfh_gn_build_planned_assoc_views: needs 1..%d packed views", DFH_GN_MAX_VIEWS);
+    DFH_REQUIRE(n_upper >= 0 && n_upper <= n_blocks && (n_upper == 0 || blk_upper), "dfh_gn_build_planned_assoc_views: bad upper-block list");
     return gn_build_planned_assoc_impl("dfh_gn_build_planned_assoc_views", sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples,
                                        knn, node_dq, node_pos, node_w, node_nbr, n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs,
                                        cost_count, run_id, n_rows, partial, blk_ptr, blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr,
                                        rblk_ent, rnode_ptr, rnode_ent, huber_delta, nullptr, views, n_views, H, W, K, Kinv, kIdentity34, scale,
-                                       center, half, max_dist, stream);
+                                       center, half, max_dist, stream, blk_upper, n_upper);
 }
 
 size_t dfh_pcg_workspace_bytes(int n_nodes, int iters) {
@@ -3048,7 +3066,7 @@ static int gn_iteration_impl(const char *what, const double *sample_pos, const d
                      const float *depth, const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
                      const double lw_cam[12], double scale, const double center[3], double half, double max_dist,
                      int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
-                     double step, void *stream) {
+                     double step, void *stream, const int *blk_upper = nullptr, int n_upper = 0) {
     using namespace dfh;
     DFH_REQUIRE(blk_ptr, "%s: null blk_ptr", what);
     DFH_REQUIRE((depth || views) && K && Kinv && lw_cam && center && lw_dq && corr_out && valid_out && node_dq, "%s: null pointer", what);
@@ -3068,7 +3086,7 @@ static int gn_iteration_impl(const char *what, const double *sample_pos, const d
     rc = gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
                        n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
                        blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream, &aa,
-                       on(opt().gn_iter_own_clear) ? nullptr : zbegin, zcount, &zeroed);
+                       on(opt().gn_iter_own_clear) ? nullptr : zbegin, zcount, &zeroed, blk_upper, n_upper);
     if (rc != DFH_OK) return rc;
     return pcg_solve_impl(row_ptr, col, vals, rhs, n_nodes, pcg_iters, lm_abs, lm_rel, x_out, pcg_workspace, pcg_workspace_bytes, node_dq,
                           step, stream, zeroed);
@@ -3102,9 +3120,10 @@ int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, c
                      const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
                      double scale, const double center[3], double half, double max_dist,
                      int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
-                     double step, int n_iters, void *stream) {
+                     double step, int n_iters, const int *blk_upper, int n_upper, void *stream) {
     using namespace dfh;
     DFH_REQUIRE(views && n_views >= 1 && n_views <= DFH_GN_MAX_VIEWS, "dfh_gn_iteration_views: needs 1..%d packed views", DFH_GN_MAX_VIEWS);
+    DFH_REQUIRE(n_upper >= 0 && n_upper <= n_blocks && (n_upper == 0 || blk_upper), "dfh_gn_iteration_views: bad upper-block list");
     DFH_REQUIRE(n_iters >= 0 && n_iters <= 1000, "dfh_gn_iteration_views: %d iterations", n_iters);
     // the frame's iterations are queued back to back from here: nothing between them depends on the host
     for (int it = 0; it < n_iters; ++it) {
@@ -3112,7 +3131,7 @@ int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, c
                                          node_pos, node_w, node_nbr, n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows,
                                          partial, blk_ptr, blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent,
                                          huber_delta, nullptr, views, n_views, H, W, K, Kinv, kIdentity34, scale, center, half, max_dist,
-                                         pcg_iters, lm_abs, lm_rel, x_out, pcg_workspace, pcg_workspace_bytes, step, stream);
+                                         pcg_iters, lm_abs, lm_rel, x_out, pcg_workspace, pcg_workspace_bytes, step, stream, blk_upper, n_upper);
         if (rc != DFH_OK) return rc;
     }
     return DFH_OK;

@@ -403,6 +403,17 @@ class WarpSolver:
         self.vals = self.system[:self.B * 36]
         self.rhs = self.system[self.B * 36:self.B * 36 + 6 * N]
         self.cost_count = self.system[self.B * 36 + 6 * N:]
+        # the pattern's symmetry for the gather (dfh_gn_iteration_views: blk_upper): per block with col >= row its index and its
+        # mirror block's (-1 on the diagonal); only those blocks' lists are walked, every sum is stored twice
+        upper_m = self.col >= rows
+        mkey_s = self.col.to(torch.int64) * N + rows.to(torch.int64)
+        mirror_s = torch.searchsorted(keys, mkey_s).clamp(max=self.B - 1)
+        self.blk_upper, self.n_upper = None, 0
+        if bool((keys[mirror_s] == mkey_s).all()):                  # (symmetric by construction; if ever not: every block is walked)
+            ids = torch.nonzero(upper_m).flatten()
+            mir = torch.where(self.col[ids] == rows[ids], torch.full_like(ids, -1), mirror_s[ids])
+            self.blk_upper = torch.stack([ids, mir], dim=1).to(torch.int32).contiguous()
+            self.n_upper = int(ids.numel())
         # what the multi-GPU all-reduce carries: J^T J is symmetric, only the blocks with col >= row travel (dfh_gn_pack_upper)
         self._tri = None
         if self.distributed and (_dist.world()[1] > 1 or self.force_collective) and not os.environ.get("DFH_ALLREDUCE_FULL"):
@@ -662,7 +673,8 @@ class WarpSolver:
                                              self.rnode_ptr.data_ptr(), self.rnode_ent.data_ptr())
                                             if self.partial_reg is not None else (0, 0, 0, 0, 0)),
                 float(huber), tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
-                _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), current_stream_ptr()),
+                _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist),
+                self.blk_upper.data_ptr() if self.blk_upper is not None else 0, self.n_upper, current_stream_ptr()),
                 "dfh_gn_build_planned_assoc_views")
             self._allreduce_system()
             return
@@ -723,7 +735,8 @@ class WarpSolver:
         tab, nv, H, W = self._views_table(depth if many else [depth], lw_cam if many else [lw_cam])
         _lib.check(self.lib.dfh_gn_iteration_views(
             *common, tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
-            _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), *tail, int(n_iters), current_stream_ptr()),
+            _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), *tail, int(n_iters),
+            self.blk_upper.data_ptr() if self.blk_upper is not None else 0, self.n_upper, current_stream_ptr()),
             "dfh_gn_iteration_views")
 
     def _allreduce_system(self):

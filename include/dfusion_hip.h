@@ -389,7 +389,11 @@ int dfh_gn_iteration(const double *sample_pos, const double *sample_nrm, const i
 
 /* dfh_gn_build_planned_assoc / dfh_gn_iteration with the association of dfh_gn_associate_views (float32 depth maps): the same
  * arguments with (views, n_views) in place of (depth, lw_cam).  dfh_gn_iteration_views queues `n_iters` whole iterations back to
- * back (a frame's ten iterations in one call: nothing between them depends on the host; the same bits as n_iters calls). */
+ * back (a frame's ten iterations in one call: nothing between them depends on the host; the same bits as n_iters calls).
+ * blk_upper (n_upper pairs of ints; NULL / 0: none): the symmetry of the block pattern -- for every block with column >= row
+ * {its index, the index of its mirror block (column, row), -1 on the diagonal}.  With it the gather walks only those blocks'
+ * lists and stores every sum twice, the second time transposed: J^T J is symmetric and block (b, a)'s list is block (a, b)'s with
+ * the slots swapped, so the result is the same bit for bit with half the block walks and half the reads. */
 int dfh_gn_build_planned_assoc_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
                                double *corr_out, unsigned char *valid_out, int n_samples, int knn, const double *node_dq,
                                const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
@@ -398,7 +402,8 @@ int dfh_gn_build_planned_assoc_views(const double *sample_pos, const double *sam
                                const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
                                const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
                                const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
-                               double scale, const double center[3], double half, double max_dist, void *stream);
+                               double scale, const double center[3], double half, double max_dist, const int *blk_upper, int n_upper,
+                               void *stream);
 int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
                      double *corr_out, unsigned char *valid_out, int n_samples, int knn, double *node_dq,
                      const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
@@ -409,7 +414,7 @@ int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, c
                      const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
                      double scale, const double center[3], double half, double max_dist,
                      int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
-                     double step, int n_iters, void *stream);
+                     double step, int n_iters, const int *blk_upper, int n_upper, void *stream);
 
 /* Multi-GPU solve: what travels in the per-iteration all-reduce.  `system` = {J^T J blocks (n_blocks x 36) | J^T r (6 n_nodes) |
  * cost, count} as the builds write it; J^T J is symmetric, so only the blocks with col >= row are packed (then J^T r and

@@ -223,7 +223,8 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
     pinned memory behind an event; the plan's lists are built by counting + per-list sorts.  The sequential loop
     (DFH_NO_SIDE_STREAM), the radix-sort plan (DFH_PLAN_RADIX), the stage-timed loop (a synchronisation after every stage) and the
     loop that reads its counts through device scalars instead of host-visible words (HostScalar off) and the loop whose GN
-    iterations are two calls (build, solve) instead of dfh_gn_iteration (DFH_GN_NO_FUSED_ITER) must give the same warp
+    iterations are two calls (build, solve) instead of dfh_gn_iteration (DFH_GN_NO_FUSED_ITER), and the loop whose gather walks the
+    lists of ALL blocks instead of those with column >= row (option gn_gather_full) must give the same warp
     field and the same canonical volume, bit for bit: a race between the streams, or a count read too early, would show here."""
     from dynamicfusion_body_amd.pipeline import SlabFrame
     from dynamicfusion_body_amd.device import HostScalar
@@ -244,7 +245,8 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setattr(HostScalar, "enabled", "NO_HOST_SCALARS" not in env)
         from dynamicfusion_body_amd import _lib
-        _lib.set_option("plan_radix", 1 if "DFH_PLAN_RADIX" in env else None)        # (a switch of the library; the others are Python's)
+        _lib.set_option("plan_radix", 1 if "DFH_PLAN_RADIX" in env else None)        # (switches of the library; the others are Python's)
+        _lib.set_option("gn_gather_full", 1 if "GN_GATHER_FULL" in env else None)    # every block's list walked (default: column >= row, sums stored twice)
         for k in env:
             if k.startswith("DFH_"):
                 monkeypatch.setenv(k, "1")
@@ -258,7 +260,7 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
     ref = run((), False)
     assert HostScalar.enabled
     for env, timed in ((("DFH_NO_SIDE_STREAM",), False), (("DFH_PLAN_RADIX",), False), (("NO_HOST_SCALARS",), False),
-                       (("DFH_GN_NO_FUSED_ITER",), False), ((), True), ((), False)):
+                       (("DFH_GN_NO_FUSED_ITER",), False), (("GN_GATHER_FULL",), False), ((), True), ((), False)):
         got = run(env, timed)
         assert got[0] == ref[0], (env, timed)
         for a, b in zip(got[1:], ref[1:]):

@@ -197,8 +197,9 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
             "bound": "not HBM (SURVEY 8(d)): rows kernel = fp64 issue on the CUs + the matrix pipe (v_mfma_f64_16x16x4, 64 cycles each), "
                      "gather = latency of the longest lists, PCG = one cross-XCD hand-off per iteration; counters (256^3 / 512 nodes, "
                      "profiles/r2_gn_experiments.txt sections 2-4, 13): rows kernel VALU issue 33 % of resident wave cycles, waiting 53 %, "
-                     "MFMA pipe busy 3.57 M cycles per launch, LDS bank conflicts 14 % of LDS cycles; gather moves 46 MB for 22 MB of live "
-                     "sub-blocks; PCG iteration 3.0 us of which ~1.8 us hand-off",
+                     "MFMA pipe busy 3.57 M cycles per launch, LDS bank conflicts 14 % of LDS cycles; gather walks the blocks with column >= row "
+                     "only and stores their sums twice (round 3: 70 -> 50 MB per launch in the frame); PCG iteration 3.0 us of which ~1.8 us "
+                     "hand-off; round 3's experiments on the rows kernel: profiles/r3_gn_experiments.txt",
             "workload": "%d^3 canonical volume, %d-node warp field, DQB warp + projective association + %d GN "
                         "iterations per solve (fp64), %s" % (R, N, iters, "samples sharded by axis-0 slab" if mode == "sharded" else
                                                            "all samples on every rank")}

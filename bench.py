@@ -186,7 +186,7 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
     return {**oracle, "gn_iters_per_s": n_it / dt, "ms_per_gn_iter": dt / n_it * 1e3, "gn_iters_per_solve": iters,
             "solves_timed": args.gn_solves, "active_samples": A, "nodes": N, "knn": k, "blocks_6x6": B,
             "pcg_iters": sv.pcg_iters, "scaling": "strong" if world > 1 else "n/a", "launch": launch,
-            "solve_mode": mode if world > 1 else "single GPU",
+            "solve_mode": mode if world > 1 else "single GPU", "pcg_path": pcg_path_name(N),
             "solve_mode_note": None if world == 1 else "sharded = slab samples + one all-reduce of the upper block triangle per iteration; "
                                "replicated = every rank solves the whole system (no per-iteration collective); chosen by "
                                "dynamicfusion_body_amd.dist.solve_mode, a latency model whose collective term is an estimate "
@@ -203,6 +203,14 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
             "workload": "%d^3 canonical volume, %d-node warp field, DQB warp + projective association + %d GN "
                         "iterations per solve (fp64), %s" % (R, N, iters, "samples sharded by axis-0 slab" if mode == "sharded" else
                                                            "all samples on every rank")}
+
+
+def pcg_path_name(n_nodes):
+    """Which PCG the solves of this process take (dfh_pcg_path): runs compare bit for bit only on the same path -- ranks that share
+    one GPU (a rehearsal) take the two-launch kernels, one rank per GPU the persistent single-reduction kernel."""
+    from dynamicfusion_body_amd import _lib
+    code = _lib.load().dfh_pcg_path(int(n_nodes))
+    return {1: "persistent single-reduction kernel", 2: "two launches per iteration (ranks share a GPU, or forced)"}.get(code, "error %d" % code)
 
 
 def frame_leg(args, torch, dist, scene, rank, world, barrier):
@@ -284,13 +292,14 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
         frame(f, timed=True)
     cost, cnt = sf.fs.solver.cost()
     tot = torch.tensor([float(info["samples"])], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if world > 1 and sf.solve_mode == "sharded":          # (replicated: every rank already holds the all-gathered sample set)
         dist.all_reduce(tot)
     return {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "frames_timed": nframes - nwarm, "scaling": "strong" if world > 1 else "n/a",
             "stage_ms_with_syncs": {kk: vv / (nframes - nwarm) for kk, vv in stages.items()},
             "gn_iters_per_frame": iters, "nodes": N, "samples": int(tot.item()), "mesh_vertices": info["vertices"],
             "mesh_faces": info["faces"], "final_cost": cost,
             "solve_mode": "single GPU" if world == 1 else sf.solve_mode,
+            "pcg_path": pcg_path_name(N),
             "exchange": "none" if world == 1 else ("per frame: all-gather of the live volume (%.0f MB) + face-plane halo" % (R ** 3 * 4 / 1e6)) +
                         ("; per GN iteration: one all-reduce of the normal equations' upper block triangle" if sf.solve_mode == "sharded" else
                          " + all-gather of the slabs' samples (96 B each); no collective inside the GN iterations (every rank solves the whole system)"),

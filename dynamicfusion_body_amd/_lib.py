@@ -98,6 +98,7 @@ _SIGNATURES = {
     "dfh_pcg_solve": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp]),
     "dfh_pcg_solve_update": (_int, [_vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _vp, _dbl, _vp]),
     "dfh_pcg_set_mode": (_int, [_int]),
+    "dfh_pcg_path": (_int, [_int]),
     "dfh_pcg_status": (_int, [_vp, ctypes.POINTER(ctypes.c_long)]),
     "dfh_pcg_status_peek": (_int, [_vp, ctypes.POINTER(ctypes.c_long)]),
     "dfh_apply_twist": (_int, [_vp, _vp, _int, _dbl, _vp]),

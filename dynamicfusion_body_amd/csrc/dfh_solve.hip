@@ -2309,12 +2309,32 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
         gamma_prev = gamma;
         alpha_prev = alpha;
     }
-    if (lead) x[6 * a + lane] = xi;
-    if (update_dq && !__any(xi != xi)) {
-        const double xs = update_step * xi;
-        const double t0 = __shfl(xs, 0, 64), t1 = __shfl(xs, 1, 64), t2 = __shfl(xs, 2, 64);
-        const double t3 = __shfl(xs, 3, 64), t4 = __shfl(xs, 4, 64), t5 = __shfl(xs, 5, 64);
-        if (row && lane == 0) apply_twist_one(update_dq + 8 * (size_t)a, t0, t1, t2, t3, t4, t5);
+    if (!update_dq) {
+        if (lead) x[6 * a + lane] = xi;
+        return;
+    }
+    // The twist update is ALL OR NOTHING (round 4).  A time-out that falls into the last reduction leaves some workgroups with
+    // finished rows and others with NaN; a wave applying its own row's step (round 3) then left node_dq half updated.  Now every
+    // workgroup publishes its rows' x and takes a ticket (flag[2], zeroed with the scalars); the workgroup that draws the last
+    // ticket knows that every other one is done, looks at the abort flag and at every row's x, and applies all N twists or none:
+    // after a timed-out solve node_dq is what it was before the solve.
+    if (lead) st_agent(x + 6 * a + lane, xi);
+    __shared__ unsigned s_ticket;
+    __syncthreads();                                                // (this workgroup's x stores are issued)
+    if (threadIdx.x == 0)
+        s_ticket = __hip_atomic_fetch_add(abort_flag + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // release: after the x stores
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    bool bad = ab.raised();
+    for (int r = (int)threadIdx.x; r < 6 * N; r += (int)blockDim.x) {
+        const double v = ld_agent(x + r);
+        bad = bad || !(fabs(v) < __builtin_huge_val());
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) return;
+    for (int r = (int)threadIdx.x; r < N; r += (int)blockDim.x) {
+        const double *xr = x + 6 * (size_t)r;
+        apply_twist_one(update_dq + 8 * (size_t)r, update_step * ld_agent(xr), update_step * ld_agent(xr + 1), update_step * ld_agent(xr + 2),
+                        update_step * ld_agent(xr + 3), update_step * ld_agent(xr + 4), update_step * ld_agent(xr + 5));
     }
 }
 
@@ -2890,8 +2910,7 @@ int dfh_pcg_status(void *stream, long *aborted_solves_out) {
     if (aborted_solves_out) *aborted_solves_out = (long)n;
     if (n)
         return fail(DFH_E_TIMEOUT, "persistent PCG: %llu solve(s) timed out in a grid barrier (workgroups not co-resident?); x = NaN; "
-                                   "node_dq is unchanged unless the time-out fell into the LAST reduction (rows whose workgroup had "
-                                   "already passed it applied their step): restore the warp field from before the solve", n);
+                                   "a timed-out solve leaves node_dq as it was before that solve (the twist update is all or nothing)", n);
     return DFH_OK;
 }
 
@@ -2915,6 +2934,50 @@ static void pcg_zero_range(void *workspace, int n_nodes, int iters, double **beg
     *count = N6 + n_scal + 12 * N6;
 }
 
+// Launch shape of a solve with n_nodes rows on the current device, and whether it takes the persistent kernel.
+static int pcg_shape(int n_nodes, int *dev_out, int *wpb_out, int *nblk_out, bool *persistent_out) {
+    using namespace dfh;
+    int dev = 0;
+    DFH_HIP_CHECK(hipGetDevice(&dev));
+    DeviceInfo &di = device_info(dev);              // per DEVICE: a process may drive several
+    if (di.n_cu == 0) DFH_HIP_CHECK(hipDeviceGetAttribute(&di.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int n_cu = di.n_cu;
+    // Workgroups of 8 waves (one row each) as long as they fit one per CU, of 16 beyond.  Measured at 2 048 rows (tools/kbench_pcg.py):
+    // 256 workgroups x 8 waves 55 us per 10-iteration solve (slope 4.3 us, prologue 14.5), 128 x 16 waves 90 us (6.4 / 27.3).
+    int wpb = (n_nodes + 7) / 8 <= n_cu ? 8 : 16;
+    { const long v = opt().pcg_wpb; if (v == 4 || v == 8 || v == 16) wpb = (int)v; }
+    const int nblk = (n_nodes + wpb - 1) / wpb;
+    // Persistent path only when its grid barrier cannot starve: (1) the occupancy query says a workgroup of this size
+    // fits on a CU, (2) the grid has at most one workgroup per CU (other kernels of this process may hold CUs for a while: they
+    // end, the waiting workgroups then start; what must NOT run beside it is a second persistent solve that also wants most of
+    // the chip -- two of them could wait for each other until the spin bound makes both leave and report DFH_E_TIMEOUT),
+    // (3) the caller has not declared co-residency unsafe (dfh_pcg_set_mode(2): several processes time-sharing one GPU),
+    // (4) the abort counter exists (it cannot be allocated while the stream is being captured: pcg_solve_impl).  Otherwise:
+    // two launches per iteration, no spinning.
+    bool persistent = nblk <= n_cu && nblk <= kMaxPcgBlocks && dfh::g_pcg_mode != 2 && !on(opt().pcg_multilaunch);
+    if (persistent) {
+        int &occ = wpb <= 8 ? di.pcg_occ512 : di.pcg_occ1024;
+        if (occ < 0) {
+            int nb = 0;
+            const hipError_t e = wpb <= 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcg_cg1_kernel<512>, 64 * 8, 0)
+                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcg_cg1_kernel<1024>, 64 * 16, 0);
+            occ = e == hipSuccess ? nb : 0;
+        }
+        persistent = occ >= 1;
+    }
+    *dev_out = dev; *wpb_out = wpb; *nblk_out = nblk; *persistent_out = persistent;
+    return DFH_OK;
+}
+
+int dfh_pcg_path(int n_nodes) {
+    DFH_REQUIRE(n_nodes >= 1, "dfh_pcg_path: bad node count");
+    int dev = 0, wpb = 0, nblk = 0;
+    bool persistent = false;
+    const int rc = pcg_shape(n_nodes, &dev, &wpb, &nblk, &persistent);
+    if (rc != DFH_OK) return rc;
+    return persistent ? 1 : 2;
+}
+
 static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, const double *rhs, int n_nodes, int iters,
                           double lm_abs, double lm_rel, double *x_out, void *workspace, size_t workspace_bytes, double *update_dq,
                           double update_step, void *stream, bool precleared = false) {
@@ -2936,36 +2999,11 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
     double *ring = scal + n_scal;                 // persistent kernel only; zero bits = "not yet published"
     PcgParams p{n_nodes, lm_abs, lm_rel};
     dim3 grid((n_nodes + 255) / 256), block(256);
-    // One persistent launch when every row can have its own co-resident wave (N <= 16 waves x #CUs / 2)
-    int dev = 0;
-    DFH_HIP_CHECK(hipGetDevice(&dev));
-    DeviceInfo &di = device_info(dev);              // per DEVICE: a process may drive several
-    if (di.n_cu == 0) DFH_HIP_CHECK(hipDeviceGetAttribute(&di.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    const int n_cu = di.n_cu;
-    // Workgroups of 8 waves (one row each) as long as they fit one per CU, of 16 beyond.  Measured at 2 048 rows (tools/kbench_pcg.py):
-    // 256 workgroups x 8 waves 55 us per 10-iteration solve (slope 4.3 us, prologue 14.5), 128 x 16 waves 90 us (6.4 / 27.3).
-    int wpb = (n_nodes + 7) / 8 <= n_cu ? 8 : 16;
-    { const long v = opt().pcg_wpb; if (v == 4 || v == 8 || v == 16) wpb = (int)v; }
-    const int nblk = (n_nodes + wpb - 1) / wpb;
-    // Persistent path only when its grid barrier cannot starve: (1) the occupancy query says a workgroup of this size
-    // fits on a CU, (2) the grid has at most one workgroup per CU (other kernels of this process may hold CUs for a while: they
-    // end, the waiting workgroups then start; what must NOT run beside it is a second persistent solve that also wants most of
-    // the chip -- two of them could wait for each other until the spin bound makes both leave and report DFH_E_TIMEOUT),
-    // (3) the caller has not declared co-residency unsafe (dfh_pcg_set_mode(2): several processes time-sharing one GPU),
-    // (4) the abort counter exists (it cannot be allocated while the stream is being captured).  Otherwise: two launches
-    // per iteration, no spinning.
-    bool persistent = nblk <= n_cu && nblk <= kMaxPcgBlocks && dfh::g_pcg_mode != 2 && !on(opt().pcg_multilaunch);
+    // One persistent launch when every row can have its own co-resident wave (pcg_shape: the decision, also behind dfh_pcg_path)
+    int dev = 0, wpb = 8, nblk = 1;
+    bool persistent = false;
+    { const int rc = pcg_shape(n_nodes, &dev, &wpb, &nblk, &persistent); if (rc != DFH_OK) return rc; }
     unsigned long long *abort_count = nullptr;
-    if (persistent) {
-        int &occ = wpb <= 8 ? di.pcg_occ512 : di.pcg_occ1024;
-        if (occ < 0) {
-            int nb = 0;
-            const hipError_t e = wpb <= 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcg_cg1_kernel<512>, 64 * 8, 0)
-                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcg_cg1_kernel<1024>, 64 * 16, 0);
-            occ = e == hipSuccess ? nb : 0;
-        }
-        persistent = occ >= 1;
-    }
     if (persistent) {
         if (dev >= 0 && dev < 64 && g_abort_count[dev]) {
             abort_count = g_abort_count[dev];

@@ -232,8 +232,9 @@ class WarpSolver:
             _lib.check(self.lib.dfh_pcg_set_mode(2), "dfh_pcg_set_mode")
 
     def check_status(self, completed_only=False):
-        """Raise DfhError if a persistent PCG solve since the last check timed out in its grid barrier (x = NaN, node_dq
-        left as it was).  Synchronises; called where the host synchronises anyway (cost()).  completed_only: look only at
+        """Raise DfhError if a persistent PCG solve since the last check timed out in its grid barrier (x = NaN; the twist
+        update is all or nothing, so node_dq is what it was before the timed-out solve -- later iterations of the same call
+        start from that field).  Synchronises; called where the host synchronises anyway (cost()).  completed_only: look only at
         the solves that have already completed and do not touch the device when none of them timed out (the end of
         SlabFrame.step, right after the sample count's read-back).  After a time-out this process takes the multi-launch
         PCG path."""

@@ -431,12 +431,16 @@ int dfh_gn_unpack_upper(double *system, const int *row_of, const int *col, const
  * one workgroup per CU.  That cannot be known when several PROCESSES time-share one GPU: such callers declare it with
  * dfh_pcg_set_mode(2) and every solve then takes the two-launches-per-iteration path (0 = auto, the default).
  * A barrier of the persistent kernel that does not complete within its spin bound (seconds) makes every workgroup
- * leave: x_out = NaN, node_dq untouched (unless the time-out fell into the very last reduction of dfh_pcg_solve_update: the
- * workgroups that had passed it have applied their rows' steps -- a caller that wants to go on restores node_dq from
- * before the solve), and a per-device counter is bumped.  dfh_pcg_status() synchronises `stream`,
+ * leave: x_out = NaN, node_dq untouched (the twist update of dfh_pcg_solve_update / dfh_gn_iteration* is all or nothing: the
+ * workgroup that finishes last applies every row's step, and only if no barrier timed out and every x is finite -- after a
+ * timed-out solve node_dq is what it was before that solve), and a per-device counter is bumped.  dfh_pcg_status() synchronises `stream`,
  * reads and clears that counter: DFH_OK, or DFH_E_TIMEOUT when a solve since the last call timed out
  * (*aborted_solves_out = how many; may be NULL).  Call it wherever the host synchronises anyway. */
 int dfh_pcg_set_mode(int mode);
+/* Which path a solve with n_nodes rows takes on the current device right now: 1 = the persistent single-reduction kernel,
+ * 2 = two launches per iteration (the textbook recurrence; same iterates in exact arithmetic, not the same bits), < 0 = error.
+ * Callers that compare runs bit for bit (N ranks against one GPU) compare runs of the same path. */
+int dfh_pcg_path(int n_nodes);
 int dfh_pcg_status(void *stream, long *aborted_solves_out);
 /* The same answer for the solves that have COMPLETED, without touching the device when none of them timed out (the kernel
  * also sets a word of pinned host memory): for callers that have just synchronised for a reason of their own (a count

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "dfh_graph_unsupported": (_int, [_vp, _int, _vp, _int, _vp, _vp, _int, _vp, _vp]),
     "dfh_dq_blend_points": (_int, [_vp, _int, _vp, _int, _vp, _vp, _vp, _int, _vp, _vp]),
     "dfh_sample_knn": (_int, [_vp, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
+    "dfh_dqb_skip_layout": (_int, [_c_int_p, _int, _int, _c_int_p, _int, _int, ctypes.POINTER(ctypes.c_size_t)]),
     "dfh_dqb_build_candidates": (_int, [_c_int_p, _int, _int, _vp, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "dfh_sample_knn_bricks": (_int, [_vp, _int, _vp, _vp, _int, _int, _c_int_p, _int, _int, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
     "dfh_gn_associate": (_int, [_vp, _vp, _vp, _int, _int, _vp, _c_double_p, _vp, _int, _int, _int, _c_double_p,

@@ -8,6 +8,8 @@
 // once to the volume dtype.
 #include "dfh_dq.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -548,12 +550,61 @@ __device__ __forceinline__ bool near_f32_tie(double v) {
     return tie | !(fabs(v) > 0x1p-10) | !(fabs(v) < 0x1p+100);
 }
 
-// the reference's chain for one voxel from scratch (weights from the node positions), written to float32 volumes
+// The running average of the float32 paths (core/fusion.py:186-190): ONE expression for every float32 path -- the fast finish,
+// the exact chain of a guarded voxel, the constant-live stream -- so that which of them takes a voxel never shows in its bits.
+// wi_f: the integration weight rounded to float32 (what the stored neighbourhoods keep).
+__device__ __forceinline__ void dqb_update_f32(float t_old, float w_old, float wi_f, double m, double wmax, float &t_new, float &w_new) {
+    const double wi = (double)wi_f;
+    double wt = (double)w_old;
+    if (wt == 0.0) wt = wi;                                                                         // fusion.py:186-187
+    const double den = wi + wt;
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+    t_new = (float)(__builtin_fma((double)t_old, wt, m * wi) * r);                                  // :189
+    w_new = (float)fmin(den, wmax);                                                                 // :190
+}
+
+// interpolate_exact with one rule on top, for float32 volumes only: eight EQUAL corners give that value (exact in real
+// arithmetic; the reference's c (1 - d) + c d may land one ulp of the DOUBLE beside it, far inside the float32 bar).  It makes
+// the sample of a position whose corners all hold the truncation value independent of the position -- what the constant-live
+// skip below relies on -- in the exact chain as in the fast one (whose FMA lerps have the property anyway).
+template <typename LiveT>
+__device__ __forceinline__ bool interpolate_exact_eq(const LiveT *__restrict__ vol, int RX, int RY, int RZ,
+                                                     double px, double py, double pz, double &out) {
+    const double mn = fmin(fmin(px, py), pz);
+    if (!(mn >= 0.0) || !(px <= (double)(RX - 1)) || !(py <= (double)(RY - 1)) || !(pz <= (double)(RZ - 1))) return false;
+    const double fx = floor(px), fy = floor(py), fz = floor(pz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const int x1 = (int)ceil(px), y1 = (int)ceil(py), z1 = (int)ceil(pz);
+    const double xd = px - fx, yd = py - fy, zd = pz - fz;
+    const size_t sx = (size_t)RY * RZ, sy = (size_t)RZ;
+    const double c000 = (double)vol[x0 * sx + y0 * sy + z0], c100 = (double)vol[x1 * sx + y0 * sy + z0];
+    const double c001 = (double)vol[x0 * sx + y1 * sy + z0], c101 = (double)vol[x1 * sx + y1 * sy + z0];
+    const double c010 = (double)vol[x0 * sx + y0 * sy + z1], c110 = (double)vol[x1 * sx + y0 * sy + z1];
+    const double c011 = (double)vol[x0 * sx + y1 * sy + z1], c111 = (double)vol[x1 * sx + y1 * sy + z1];
+    if (c000 == c100 && c000 == c001 && c000 == c101 && c000 == c010 && c000 == c110 && c000 == c011 && c000 == c111) {
+        out = c000;
+        return true;
+    }
+    const double c00 = c000 * (1.0 - xd) + c100 * xd;
+    const double c01 = c001 * (1.0 - xd) + c101 * xd;
+    const double c10 = c010 * (1.0 - xd) + c110 * xd;
+    const double c11 = c011 * (1.0 - xd) + c111 * xd;
+    const double c0 = c00 * (1.0 - yd) + c10 * yd;
+    const double c1 = c01 * (1.0 - yd) + c11 * yd;
+    out = c0 * (1.0 - zd) + c1 * zd;
+    return true;
+}
+
+// the reference's chain for one voxel from scratch (weights from the node positions): its decisions and its sample; the running
+// average is dqb_update_f32 with the stored float32 integration weight (wi_f < 0: none stored -- the weights did not normalise --
+// the one computed here, rounded)
 template <typename LiveT>
 __device__ __forceinline__ void dqb_exact_voxel(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const LiveT *__restrict__ live,
                                                 const double *__restrict__ node_pos, const double *__restrict__ node_dq,
                                                 const double *__restrict__ node_w, const int (&bi)[4], const DqbParams &p,
-                                                double px, double py, double pz, size_t off) {
+                                                double px, double py, double pz, size_t off, float wi_f) {
     double bd[4], wg[4], wi;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -564,14 +615,13 @@ __device__ __forceinline__ void dqb_exact_voxel(float *__restrict__ tsdf, float 
     dqb_weights<4>(node_w, bd, bi, 4, wg, wi);
     const D3 q = dqb_blend_warp<4>(node_dq, wg, bi, 4, p.lw.q, px, py, pz);
     double s;
-    if (!interpolate_exact(live, p.LX, p.LY, p.LZ, q.x, q.y, q.z, s)) return;
+    if (!interpolate_exact_eq(live, p.LX, p.LY, p.LZ, q.x, q.y, q.z, s)) return;
     if (!(s > -1.0 * p.tdist)) return;
-    double wt = (double)tsdf_w[off];
-    if (wt == 0.0) wt = wi;
     const double m = s < p.tdist ? s : p.tdist;
-    tsdf[off] = (float)(((double)tsdf[off] * wt + m * wi) / (wi + wt));
-    const double nw = wi + wt;
-    tsdf_w[off] = (float)(nw < p.wmax ? nw : p.wmax);
+    float tn, wn;
+    dqb_update_f32(tsdf[off], tsdf_w[off], wi_f >= 0.0f ? wi_f : (float)wi, m, p.wmax, tn, wn);
+    tsdf[off] = tn;
+    tsdf_w[off] = wn;
 }
 
 #ifndef DFH_K3_STUB                  // experiment builds (tools/build_variant.sh ... -DDFH_K3_STUB=bits): parts of the steady-state kernel
@@ -586,6 +636,8 @@ struct DqGlobal {
 // doubles per node in LDS: 80-byte rows spread the 16-byte reads of different nodes over the banks (graphs up to 819 nodes: 64 KB,
 // two workgroups per CU); plain 64-byte rows let graphs up to 2 304 nodes (144 KB, one workgroup per CU) use the table too
 constexpr int kDqLdsStride = 10, kDqLdsStrideBig = 8;
+// sub-lists of the constant-live skip (below): one hot counter serialises ~4 ns per returning atomic at the memory side
+constexpr int kSkipLists = 64;
 template <int STRIDE>
 struct DqLds {
     const double *q;                        // (the caller indexes its __shared__ array directly: the address space survives inlining)
@@ -747,22 +799,16 @@ __device__ __forceinline__ void dqb_stage_finish(float *__restrict__ tsdf, float
             return;
         } else {
             asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));              // keep the exact chain's arithmetic inside its branch
-            dqb_exact_voxel(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, p, px, py, pz, off);
+            dqb_exact_voxel(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, p, px, py, pz, off, wi_f);
         }
         return;
     }
     if (!ok) return;
-    const double wi = (double)wi_f;
-    double wt = (double)w_old;
-    if (wt == 0.0) wt = wi;                                                                         // fusion.py:186-187
-    const double m = fmin(sv, p.tdist);
-    const double den = wi + wt;
-    double r = __builtin_amdgcn_rcp(den);
-    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
-    if ((DFH_K3_STUB & 2) && den != 12345.678) return;
-    tsdf[off] = (float)(__builtin_fma((double)t_old, wt, m * wi) * r);                              // :189
-    tsdf_w[off] = (float)fmin(den, p.wmax);                                                         // :190
+    float tn, wn;
+    dqb_update_f32(t_old, w_old, wi_f, fmin(sv, p.tdist), p.wmax, tn, wn);
+    if ((DFH_K3_STUB & 2) && wn != 12345.678f) return;
+    tsdf[off] = tn;
+    tsdf_w[off] = wn;
 }
 
 template <typename LiveT, typename DqSrc>
@@ -871,7 +917,8 @@ struct DqbRunInputs {
     float wi, t, w;
 };
 
-template <typename LiveT, int TPB, int STRIDE>
+// LIST: only the bricks on the skip's sub-lists are taken (the constant-live skip below leaves the bricks near the live surface).
+template <typename LiveT, int TPB, int STRIDE, bool LIST = false>
 __global__ __launch_bounds__(TPB) void fuse_volume_dqb_lds_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
                                                                    const LiveT *__restrict__ live,
                                                                    const double *__restrict__ node_pos,
@@ -879,7 +926,9 @@ __global__ __launch_bounds__(TPB) void fuse_volume_dqb_lds_kernel(float *__restr
                                                                    const double *__restrict__ node_w,
                                                                    const unsigned short *__restrict__ knn_cache,
                                                                    const double *__restrict__ w_cache, const DqbParams p,
-                                                                   const RigidFastParams f, int n_runs, const DqbRedoList redo_list) {
+                                                                   const RigidFastParams f, int n_runs, const DqbRedoList redo_list,
+                                                                   const unsigned *__restrict__ list_count = nullptr,
+                                                                   const unsigned *__restrict__ list = nullptr, unsigned sub_cap = 0) {
     extern __shared__ double sdq[];                                           // N rows of STRIDE doubles
     for (int i = threadIdx.x; i < p.N * 8; i += TPB) sdq[(i >> 3) * STRIDE + (i & 7)] = node_dq[i];
     __syncthreads();
@@ -909,6 +958,53 @@ __global__ __launch_bounds__(TPB) void fuse_volume_dqb_lds_kernel(float *__restr
         bi[0] = min((int)(idx.x & 0xffffu), p.N - 1); bi[1] = min((int)(idx.x >> 16), p.N - 1);   // a stale or foreign workspace must not fault
         bi[2] = min((int)(idx.y & 0xffffu), p.N - 1); bi[3] = min((int)(idx.y >> 16), p.N - 1);
     };
+    if (LIST) {
+        // The bricks dqb_bound_kernel left to this kernel, on kSkipLists sub-lists in brick order (z fastest).  A pass takes ONE
+        // row (of a brick's 16) of FOUR consecutive entries: lanes 16 g .. 16 g + 15 the 16 voxels of entry 4 q + g -- mostly
+        // neighbours along z, i.e. up to 64 contiguous voxels (four rows of one brick per pass, 64-byte pieces four rows apart,
+        // measured 11.5 us per pass against 9.2: the texture addresser pays per cache line).  Wave w serves sub-list
+        // w % kSkipLists and takes the items w / kSkipLists, + n_waves / kSkipLists, ...: the same number of passes per wave, +-1.
+        const int l = wave % kSkipLists, first = wave / kSkipLists, step = max(n_waves / kSkipLists, 1);
+        if (wave >= step * kSkipLists) return;                                 // (a grid that is not a multiple of the list count)
+        const unsigned *__restrict__ mine = list + (size_t)l * sub_cap;
+        const int n_entries = (int)min(list_count[16 * l], sub_cap);
+        const int n_items = 16 * ((n_entries + 3) >> 2);                       // item = (four consecutive entries, one of a brick's 16 rows)
+        const unsigned last_brick = (unsigned)(p.nbx * p.nby * p.nbz - 1);
+        const int g = lane >> 4;
+        auto entry_of = [&](int it) { const int e = 4 * (it >> 4) + g; return e < n_entries ? min(mine[e], last_brick) : 0xffffffffu; };
+        unsigned entry = first < n_items ? entry_of(first) : 0xffffffffu;      // (the next item's entries are asked for a whole item ahead)
+        for (int it = first; it < n_items; it += step) {
+            const unsigned brick = entry;
+            if (it + step < n_items) entry = entry_of(it + step);
+            const int rr = it & 15;
+            const bool have = brick != 0xffffffffu;
+            const unsigned bq = have ? brick : 0u;
+            const int bz = (int)(bq % (unsigned)p.nbz), bxy = (int)(bq / (unsigned)p.nbz);
+            const int by = bxy % p.nby, bx = bxy / p.nby;
+            const int xl = bx * kBX + (rr >> 2), y = by * kBY + (rr & 3);
+            const bool valid = have && xl < p.nx && y < p.Y;
+            const size_t off = ((size_t)xl * p.Y + y) * p.Z + (size_t)(bz * kBZ + (lane & 15));
+            const double px = (double)(p.x0 + xl), py = (double)y, pz = (double)(bz * kBZ + (lane & 15));
+            DqbRunInputs in;
+            in.idx = make_uint2(0u, 0u); in.w0 = 1.0; in.w1 = in.w2 = 0.0; in.wi = 1.0f; in.t = in.w = 0.0f;
+            if (valid) {
+                in.idx = *reinterpret_cast<const uint2 *>(knn_cache + off * 4);
+                in.w0 = w_cache[off]; in.w1 = w_cache[nvox + off]; in.w2 = w_cache[2 * nvox + off];
+                in.wi = wi_cache[off];
+                in.t = tsdf[off]; in.w = tsdf_w[off];
+            }
+            int bi[4];
+            nodes_of(in.idx, bi);
+            DqbNorm e;
+            e.w0 = in.w0; e.w1 = in.w1; e.w2 = in.w2; e.wi = in.wi;
+            DqbWarped wp = dqb_stage_warp(DqLds<STRIDE>{sdq}, bi, e, p, f, px, py, pz);
+            if (!valid) { wp.ok = false; wp.redo = false; wp.fx = wp.fy = wp.fz = 0.0; }
+            LiveT c[8];
+            dqb_stage_gather(live, p, wp, c);
+            dqb_stage_finish<LiveT, true>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, e.wi, p, wp, c, px, py, pz, off, in.t, in.w, redo_list);
+        }
+        return;
+    }
     if (wave >= n_runs) return;
     for (int r = wave; r < n_runs; r += n_waves) {                            // consecutive waves take consecutive runs
         DqbRunInputs in;
@@ -936,7 +1032,7 @@ template <typename LiveT>
 __global__ __launch_bounds__(256) void dqb_redo_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const LiveT *__restrict__ live,
                                                         const double *__restrict__ node_pos, const double *__restrict__ node_dq,
                                                         const double *__restrict__ node_w, const unsigned short *__restrict__ knn_cache,
-                                                        const DqbParams p, const DqbRedoList redo_list) {
+                                                        const float *__restrict__ wi_cache, const DqbParams p, const DqbRedoList redo_list) {
     const unsigned n = redo_list.count[0];
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const size_t off = redo_list.offs[i];
@@ -947,13 +1043,378 @@ __global__ __launch_bounds__(256) void dqb_redo_kernel(float *__restrict__ tsdf,
         int bi[4];
         bi[0] = min((int)(v.x & 0xffffu), p.N - 1); bi[1] = min((int)(v.x >> 16), p.N - 1);
         bi[2] = min((int)(v.y & 0xffffu), p.N - 1); bi[3] = min((int)(v.y >> 16), p.N - 1);
-        dqb_exact_voxel(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, p, (double)(p.x0 + xl), (double)y, (double)z, off);
+        dqb_exact_voxel(tsdf, tsdf_w, live, node_pos, node_dq, node_w, bi, p, (double)(p.x0 + xl), (double)y, (double)z, off, wi_cache[off]);
     }
     __syncthreads();                                                          // (this block's reads of count[0] are done)
     if (threadIdx.x == 0 && atomicAdd(redo_list.count + 1, 1u) == gridDim.x - 1) {
         redo_list.count[0] = 0u;
         redo_list.count[1] = 0u;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Constant-live skip (round 4; profiles/r3_k3_experiments.txt section 6 left it open for want of a bound).
+// The live volume holds the truncation value everywhere except within tdist of the live surface; a voxel all of whose possible
+// sample corners hold exactly tdist takes s = tdist WHATEVER its warped position: the update needs T, w and the stored
+// integration weight (12-20 B per voxel moved instead of 64, a dozen instructions instead of ~220) -- no indices, no blend
+// weights, no node rows, no gathers.  What it takes is a PROVEN bound on |warp(p) - p|.
+//
+// Bound.  b = sum_j w_j dq_j with w_j >= 0, sum 1 (the stored weights are normalised; the exact chain's are a positive multiple
+// and the 8-norm normalisation removes any common factor).  With r, d its real and dual parts the reference's warp (dq_blend +
+// dqb_warp, core/fusion.py:527-551, core/util.py:68-72) is x1 = (r p r* + 2 vec(d r*)) / (|r|^2 + |d|^2), so
+//     x1 - p = N(b, p) / (|r|^2 + |d|^2),   N(b, p) = (r p r* - |r|^2 p) + 2 vec(d r*) - |d|^2 p,
+// a quadratic form in b.  (The last term is the 8-norm's: a unit dual quaternion with translation t has |d| = |t| / 2 and the
+// reference's normalisation SCALES the point by 1 / (1 + |t|^2 / 4); in the frame loop it moves voxels far from the surface by up
+// to 15 voxels -- tools/k3_skip_probe.py.)  With G its symmetric bilinear form, G(a, a, p) = N(a, p),
+//     G(a, b, p) = (a_r p b_r* + b_r p a_r*) / 2 - (a_r . b_r + a_d . b_d) p + vec(a_d b_r* + b_d a_r*),
+// a convex combination gives N(b, p) = sum_jk w_j w_k G(dq_j, dq_k, p), hence |N(b, p)| <= max_jk |G(dq_j, dq_k, p)|, and likewise
+// |r|^2 + |d|^2 >= |r|^2 >= min_jk r_j . r_k -- the maxima over the pairs of nodes that can blend in.  Over a brick with centre c
+// and half diagonal rho_b:  G(a, b, c + p') - G(a, b, c) = (v_a + v_b) x p' + [(da p' db* + db p' da*) / 2 - (da . db) p'] - (a_d . b_d) p'
+// (r = 1 + delta, v = its vector part), of norm <= (|v_a| + |v_b| + 2 |da| |db| + |a_d . b_d|) rho_b.  So
+//     D = max_jk [ |G_jk(c)| + (|v_j| + |v_k| + 2 |delta_j| |delta_k| + |d_j . d_k|) rho_b ] / min_jk r_j . r_k
+// bounds |x1 - p| for every voxel of the brick (cross-checked against the oracle's dq_blend + dqb_warp on random blends,
+// tests/test_k3_skip_bound.py; on the device against every voxel, tests/test_gpu_fuse_volume.py::test_dqb_skip_bound_holds_for_every_voxel;
+// on the bench scene the largest displacement / bound is 0.98).  On top:
+// the float32 rounding of x1 (core/util.py:69), the paths' own error and 1e-3 voxel of slack.  m_lw must be the identity (the
+// frame loop's case); otherwise no skip.  The sample's corners floor / ceil lie within D + 1 of p on every axis.
+// The nodes that can blend into a brick: the union of its voxels' stored k nearest nodes (`used`, built with the stored
+// neighbourhoods; static while the graph stays) -- 6-12 nodes where the candidate lists hold 23.
+//
+// Masks.  U: one bit per 4x4x4 cell of the LIVE volume, set iff its 64 voxels all equal tdist (cells cut by a face: clear).  S: one
+// bit per cell of the canonical slab, set for the four cells of a brick iff every live cell within reach = ceil((D + 1) / 4) cells
+// (Chebyshev) of them exists and is set in U -- then every corner of every voxel of the brick holds tdist, the position is inside
+// the live volume, s = tdist exactly (eight equal corners: the FMA lerps return the value, interpolate_exact_eq makes the exact
+// chain do the same), s > -tdist holds and the update is dqb_update_f32(T, w, wi, tdist).  Such bricks are taken by
+// dqb_stream_kernel (16-byte packs, no warp); the LDS kernel takes the other bricks, four of a brick's 16-voxel rows per pass.  Bits: identical to the kernels without the skip (test_dqb_constant_live_skip), because every path ends in
+// dqb_update_f32.
+struct DqbSkip {
+    unsigned long long *U;          // word (cx * CY + cy) * WZ + (cz >> 6), bit cz & 63
+    unsigned long long *S;          // one BYTE per K3 brick: 1 = its voxels take the constant-live stream
+    unsigned char *mb;              // per K3 brick (4 x 4 x 16 = four cells along z): cells to look around, 1 or 2; 255 = no bound
+    float *db;                      // per K3 brick: D (diagnostics and tests)
+    unsigned short *used;           // per K3 brick: kSkipUsed node ids, ascending, 0xffff = none; [0] = 0xfffe: more than fit
+    unsigned *sub_count;            // kSkipLists counters, 64 B apart (index 16 l): bricks on sub-list l
+    unsigned *sub_list;             // kSkipLists sub-lists of sub_cap entries: the warp kernel's bricks; brick b goes on list b % kSkipLists
+    unsigned sub_cap;
+    int CX, CY, CZ, WZ;             // cells of the live volume, 64-bit words per cell row
+    int SCX, SCY;                   // cell rows of the slab
+};
+constexpr int kSkipMaxWords = 8;    // LZ <= 2048
+constexpr int kSkipUsed = 16;
+
+template <typename LiveT>
+__global__ __launch_bounds__(1024) void dqb_live_mask_kernel(const LiveT *__restrict__ live, int LX, int LY, int LZ, double tdist,
+                                                              const DqbSkip k, int cx_lo) {
+    __shared__ unsigned long long part[16][kSkipMaxWords];
+    const int cell_row = cx_lo * k.CY + blockIdx.x;                            // (only the cell planes within reach of the slab)
+    const int cx = cell_row / k.CY, cy = cell_row - cx * k.CY;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = 4 * cx + (wave >> 2), y = 4 * cy + (wave & 3);
+    const bool row_ok = x < LX && y < LY;                                      // (a cell cut by the volume's face stays clear)
+    for (int wz = 0; wz < k.WZ; ++wz) {
+        const int cz = wz * 64 + lane;
+        bool f = false;
+        if (row_ok && cz < k.CZ) {
+            const VPack<LiveT, 4> v = *reinterpret_cast<const VPack<LiveT, 4> *>(live + ((size_t)x * LY + y) * LZ + 4 * (size_t)cz);
+            f = (double)v.v[0] == tdist && (double)v.v[1] == tdist && (double)v.v[2] == tdist && (double)v.v[3] == tdist;
+        }
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) part[wave][wz] = b;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + kSkipLists) k.sub_count[16 * (threadIdx.x - 64)] = 0u;   // (filled by dqb_bound_kernel, behind this launch)
+    if ((int)threadIdx.x < k.WZ) {
+        unsigned long long u = part[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) u &= part[w][threadIdx.x];
+        k.U[(size_t)cell_row * k.WZ + threadIdx.x] = u;
+    }
+}
+
+// The nodes a brick's voxels blend (union of their stored k nearest nodes), ascending: one block per brick, a voxel per thread.
+// Every stored index is on the brick's candidate list (sorted by node id), so a binary search finds its slot.
+__global__ __launch_bounds__(256) void dqb_used_nodes_kernel(const unsigned short *__restrict__ knn_cache, const int *__restrict__ cand,
+                                                              const DqbParams p, const DqbSkip k) {
+    __shared__ int slist[kCap];
+    __shared__ unsigned char flag[kCap];
+    __shared__ int wave_cnt[4];
+    const long brick = blockIdx.x;
+    const int bz = (int)(brick % p.nbz);
+    const int by = (int)((brick / p.nbz) % p.nby);
+    const int bx = (int)(brick / ((long)p.nbz * p.nby));
+    const int lz = threadIdx.x & (kBZ - 1), ly = (threadIdx.x >> 4) & (kBY - 1), lx = threadIdx.x >> 6;
+    const int xl = bx * kBX + lx, y = by * kBY + ly, z = bz * kBZ + lz;
+    const bool inb = xl < p.nx && y < p.Y && z < p.Z;
+    const int *c = cand + brick * (kCap + 1);
+    const int cnt = c[0];
+    unsigned short *out = k.used + brick * kSkipUsed;
+    if (cnt < 0) {                                                             // overflowed list: any node may blend in -> no bound
+        if (threadIdx.x < kSkipUsed) out[threadIdx.x] = threadIdx.x == 0 ? (unsigned short)0xfffe : (unsigned short)0xffff;
+        return;
+    }
+    if ((int)threadIdx.x < cnt) slist[threadIdx.x] = c[1 + threadIdx.x];
+    flag[threadIdx.x] = 0;
+    __syncthreads();
+    if (inb) {
+        const size_t off = ((size_t)xl * p.Y + y) * p.Z + z;
+        const uint2 v = *reinterpret_cast<const uint2 *>(knn_cache + off * 4);
+        const int id[4] = {(int)(v.x & 0xffffu), (int)(v.x >> 16), (int)(v.y & 0xffffu), (int)(v.y >> 16)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int lo = 0, hi = cnt - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (slist[mid] < id[j]) lo = mid + 1; else hi = mid;
+            }
+            if (slist[lo] == id[j]) flag[lo] = 1;
+        }
+    }
+    __syncthreads();
+    const bool f = (int)threadIdx.x < cnt && flag[threadIdx.x] != 0;
+    const unsigned long long m = __ballot(f);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wave_cnt[wave] = __builtin_popcountll(m);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_cnt[w];
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (total > kSkipUsed) {
+        if (threadIdx.x < kSkipUsed) out[threadIdx.x] = threadIdx.x == 0 ? (unsigned short)0xfffe : (unsigned short)0xffff;
+        return;
+    }
+    if ((int)threadIdx.x >= total && threadIdx.x < kSkipUsed) out[threadIdx.x] = (unsigned short)0xffff;
+    if (f) out[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned short)slist[threadIdx.x];
+}
+
+// bit i of the result = bit i + s of the cell row (cur = this word, nxt = the next one along z); s in 1..63
+__device__ __forceinline__ unsigned long long row_shr(unsigned long long cur, unsigned long long nxt, int s) { return (cur >> s) | (nxt << (64 - s)); }
+__device__ __forceinline__ unsigned long long row_shl(unsigned long long cur, unsigned long long prv, int s) { return (cur << s) | (prv >> (64 - s)); }
+__device__ __forceinline__ unsigned long long wave_and_u64(unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo &= (unsigned)__shfl_xor((int)lo, o, 64);
+        hi &= (unsigned)__shfl_xor((int)hi, o, 64);
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// How far around a brick the live volume is constant: rs[brick] = 2 / 1 / 0 = every live cell within two / one cell(s)
+// (Chebyshev) of the brick's four cells exists and is set in U / not even that.  One wave per slab cell row, a lane per
+// neighbouring cell row (5 x 5), the words eroded along z and AND-ed over the wave.  (Written into mb; dqb_bound_kernel reads it
+// there and replaces it by the reach the bound asks for.)
+__global__ __launch_bounds__(256) void dqb_reach_kernel(const DqbParams p, const DqbSkip k) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= k.SCX * k.SCY) return;
+    const int lane = threadIdx.x & 63;
+    const int scx = t / k.SCY, cy = t - scx * k.SCY;
+    const int cx = p.x0 / 4 + scx;
+    const int dx = lane / 5 - 2, dy = lane % 5 - 2;
+    const bool nb = lane < 25;
+    const int ax = cx + dx, ay = cy + dy;
+    const bool inside = nb && ax >= 0 && ax < k.CX && ay >= 0 && ay < k.CY;   // outside the live volume: never constant
+    const unsigned long long *urow = k.U + ((size_t)(inside ? ax : 0) * k.CY + (inside ? ay : 0)) * k.WZ;
+    unsigned char *rs = k.mb + ((long)scx * p.nby + cy) * p.nbz;
+    for (int wz = 0; wz < k.WZ; ++wz) {
+        unsigned long long e1 = ~0ull, e2 = ~0ull;
+        if (nb) {
+            const unsigned long long cur = inside ? urow[wz] : 0ull, prv = inside && wz > 0 ? urow[wz - 1] : 0ull,
+                                     nxt = inside && wz + 1 < k.WZ ? urow[wz + 1] : 0ull;
+            const unsigned long long a1 = cur & row_shr(cur, nxt, 1) & row_shl(cur, prv, 1);
+            e2 = a1 & row_shr(cur, nxt, 2) & row_shl(cur, prv, 2);
+            if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) e1 = a1;
+        }
+        e1 = wave_and_u64(e1);
+        e2 = wave_and_u64(e2);
+        if (lane < 16) {
+            const int bz = wz * 16 + lane;
+            const unsigned long long grp = 0xfull << (4 * lane);
+            if (bz < p.nbz) rs[bz] = (e2 & grp) == grp ? 2 : ((e1 & grp) == grp ? 1 : 0);
+        }
+    }
+}
+
+// Per brick: the bound D, the reach it asks for and the verdict (Sb = 1: its voxels take the constant-live stream; 0: the warp
+// kernel, which finds it on one of kSkipLists sub-lists: one list behind ONE counter cost 100 us for 26 k bricks -- same-address
+// returning atomics serialise at the memory side -- and flags read by statically assigned waves left the launch as long as
+// without the skip, 215 us: the live surface's shell falls on few of them).  16 lanes per brick: lane j keeps node used[j]'s dual
+// quaternion (LDS); the pairs (j <= k) are dealt densely over the lanes.  all_bounds: compute D also where the live volume
+// rules the skip out anyway (tests).
+__global__ __launch_bounds__(256) void dqb_bound_kernel(const double *__restrict__ node_dq, const DqbParams p, const DqbSkip k, int all_bounds) {
+    // float32 from here on: the pair loop is the kernel (28 pairs of ~130 operations per brick), and what it produces is a BOUND.
+    // Its own rounding: products of size <= |c| |q|^2 ~ 500 carry 2^-24 relative each, ~40 of them add up along a component:
+    // < 2.4e-6 |c| voxel; the node values rounded to float32: another 1e-7 |c|.  4e-6 |c| + 2e-3 voxel are added below for both.
+    __shared__ float sq[16][kSkipUsed * 15 + 1];                               // per node: dq (8), a = r (0, c) (4), |v|, |r - 1|; 15 floats, 241 per brick
+    const long nbricks = (long)p.nbx * p.nby * p.nbz;
+    const long brick_raw = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool real = brick_raw < nbricks;
+    const long brick = real ? brick_raw : 0;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int bz = (int)(brick % p.nbz);
+    const int by = (int)((brick / p.nbz) % p.nby);
+    const int bx = (int)(brick / ((long)p.nbz * p.nby));
+    const double cxd = (double)(p.x0 + bx * kBX) + 0.5 * (kBX - 1), cyd = (double)(by * kBY) + 0.5 * (kBY - 1),
+                 czd = (double)(bz * kBZ) + 0.5 * (kBZ - 1);
+    const float cx = (float)cxd, cy = (float)cyd, cz = (float)czd;             // (half-integers below 2^24: exact)
+    const int rs = real ? (int)k.mb[brick] : 0;                                // dqb_reach_kernel's answer (this kernel overwrites it)
+    const bool want = real && (rs > 0 || all_bounds);                          // (uniform over the brick's 16 lanes)
+    const unsigned short id = want ? k.used[brick * kSkipUsed + sub] : (unsigned short)0xffff;
+    const bool have = id < 0xfffe && (int)id < p.N;
+    bool bad = false;
+    float me[8] = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (have) {
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) me[c8] = (float)node_dq[8 * (size_t)id + c8];
+    }
+    float *mine = &sq[grp][sub * 15];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        mine[c8] = me[c8];
+        bad = bad | !(fabsf(me[c8]) < 1e6f);                                   // (NaN / inf land here)
+    }
+    mine[8] = -(me[1] * cx + me[2] * cy + me[3] * cz);                         // a = r (0, c)
+    mine[9] = me[0] * cx + me[2] * cz - me[3] * cy;
+    mine[10] = me[0] * cy + me[3] * cx - me[1] * cz;
+    mine[11] = me[0] * cz + me[1] * cy - me[2] * cx;
+    const float vv = (me[1] * me[1] + me[2] * me[2]) + me[3] * me[3];
+    mine[12] = sqrtf(vv);
+    mine[13] = sqrtf((me[0] - 1.0f) * (me[0] - 1.0f) + vv);
+    const int n = __builtin_popcount((unsigned)(__ballot(have) >> (16 * (grp & 3))) & 0xffffu);       // ids are packed to the front
+    const bool overflow = (__shfl((int)id, (int)(threadIdx.x & 48), 64) & 0xffff) == 0xfffe;   // the group's lane 0
+    __syncthreads();
+    float num = 0.0f, n2min = __builtin_huge_valf();
+    const int npairs = n * (n + 1) / 2;
+    for (int q = sub; q < npairs; q += 16) {
+        int j = 0, rem = q;
+        while (rem >= n - j) { rem -= n - j; ++j; }
+        const int kk = j + rem;
+        const float *a = &sq[grp][j * 15], *b = &sq[grp][kk * 15];
+        const float aw = a[0], ax = a[1], ay = a[2], az = a[3], a0 = a[4], a1 = a[5], a2 = a[6], a3 = a[7];
+        const float bw = b[0], bx_ = b[1], by_ = b[2], bz_ = b[3], b0 = b[4], b1 = b[5], b2 = b[6], b3 = b[7];
+        const float q1w = a[8], q1x = a[9], q1y = a[10], q1z = a[11], q2w = b[8], q2x = b[9], q2y = b[10], q2z = b[11];
+        // vec(q b*) for b* = (bw, -bx, -by, -bz): x: -qw bx + qx bw - qy bz + qz by, ...
+        const float s1x = -q1w * bx_ + q1x * bw - q1y * bz_ + q1z * by_, s1y = -q1w * by_ + q1y * bw - q1z * bx_ + q1x * bz_, s1z = -q1w * bz_ + q1z * bw - q1x * by_ + q1y * bx_;
+        const float s2x = -q2w * ax + q2x * aw - q2y * az + q2z * ay, s2y = -q2w * ay + q2y * aw - q2z * ax + q2x * az, s2z = -q2w * az + q2z * aw - q2x * ay + q2y * ax;
+        // vec(a_d b_r*) + vec(b_d a_r*)
+        const float t1x = -a0 * bx_ + a1 * bw - a2 * bz_ + a3 * by_, t1y = -a0 * by_ + a2 * bw - a3 * bx_ + a1 * bz_, t1z = -a0 * bz_ + a3 * bw - a1 * by_ + a2 * bx_;
+        const float t2x = -b0 * ax + b1 * aw - b2 * az + b3 * ay, t2y = -b0 * ay + b2 * aw - b3 * ax + b1 * az, t2z = -b0 * az + b3 * aw - b1 * ay + b2 * ax;
+        const float rr = (aw * bw + ax * bx_) + (ay * by_ + az * bz_), dd = (a0 * b0 + a1 * b1) + (a2 * b2 + a3 * b3);
+        const float gx = 0.5f * (s1x + s2x) - (rr + dd) * cx + (t1x + t2x);
+        const float gy = 0.5f * (s1y + s2y) - (rr + dd) * cy + (t1y + t2y);
+        const float gz = 0.5f * (s1z + s2z) - (rr + dd) * cz + (t1z + t2z);
+        const float lam = a[12] + b[12] + 2.0f * a[13] * b[13] + fabsf(dd);
+        num = fmaxf(num, sqrtf(gx * gx + gy * gy + gz * gz) + lam * (float)DFH_BRICK_RADIUS);
+        n2min = fminf(n2min, rr);
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        num = fmaxf(num, __shfl_xor(num, o, 16));
+        n2min = fminf(n2min, __shfl_xor(n2min, o, 16));
+        bad = bad | (__shfl_xor(bad ? 1 : 0, o, 16) != 0);
+    }
+    float D = __builtin_huge_valf();
+    int m = 255;
+    if (want && !overflow && n >= 1 && !bad && n2min > 0.25f && num < 1e6f) {
+        const double cn = sqrt((cxd * cxd + cyd * cyd) + czd * czd) + DFH_BRICK_RADIUS;
+        double d = (double)num / ((double)n2min * (1.0 - 1e-5)) * (1.0 + 1e-5);
+        d = d + (cn + d) * 0x1p-23 + cn * 4e-6 + 2e-3;                         // + float32 rounding of x1 + this kernel's and the paths' own error + slack
+        D = (float)(d * (1.0 + 0x1p-22));                                      // (rounded up: the stored value is never below d)
+        const double need = d + 1.0;                                           // the corners: floor / ceil of the position
+        m = need <= 4.0 ? 1 : (need <= 8.0 ? 2 : 255);
+    }
+    const bool safe = m <= rs;                                                 // (uniform over the 16 lanes)
+    if (sub == 0 && real) {
+        k.db[brick] = want ? D : -1.0f;                                        // -1: not computed (the live volume ruled the skip out)
+        k.mb[brick] = (unsigned char)m;
+        reinterpret_cast<unsigned char *>(k.S)[brick] = safe ? 1 : 0;
+    }
+    // the warp kernel's bricks of this block, in brick order (z fastest: neighbours along z stay neighbours), onto sub-list
+    // blockIdx % kSkipLists behind ONE atomic
+    __shared__ unsigned char s_unsafe[16];
+    __shared__ unsigned s_base;
+    if (sub == 0) s_unsafe[grp] = real && !safe ? 1 : 0;
+    __syncthreads();
+    // (not blockIdx % kSkipLists: with 64 columns per x plane that is "the columns at y = l", a plane, and the sphere's planes
+    // hold anything from none to most of the shell -- 135 us instead of 100)
+    const unsigned l = (blockIdx.x ^ (blockIdx.x >> 6) ^ (blockIdx.x >> 12) ^ (blockIdx.x >> 18)) % kSkipLists;
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) tot += s_unsafe[g];
+        s_base = tot ? atomicAdd(k.sub_count + 16 * l, tot) : 0u;
+    }
+    __syncthreads();
+    if (sub == 0 && real && !safe) {
+        unsigned before = 0;
+        for (int g = 0; g < grp; ++g) before += s_unsafe[g];
+        k.sub_list[(size_t)l * k.sub_cap + s_base + before] = (unsigned)brick;
+    }
+}
+
+// the bricks with Sb = 1: T, w, wi in 16-byte packs, s = tdist; a pack nothing changes in (T already at tdist, w saturated: most
+// of the free space) is not written back
+__global__ __launch_bounds__(256) void dqb_stream_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const float *__restrict__ wi_cache,
+                                                          const DqbParams p, const DqbSkip k, const DqbRedoList redo_list, unsigned npacks, int sat_ok) {
+    const unsigned pack = blockIdx.x * 256u + threadIdx.x;
+    if (pack >= npacks) return;
+    const unsigned zp = (unsigned)p.Z >> 2;
+    const unsigned row = pack / zp, cz = pack - row * zp;
+    const unsigned xl = row / (unsigned)p.Y, y = row - xl * (unsigned)p.Y;
+    if (!reinterpret_cast<const unsigned char *>(k.S)[((size_t)(xl >> 2) * p.nby + (y >> 2)) * p.nbz + (cz >> 2)]) return;
+    const size_t off = (size_t)pack * 4;
+    const float4 t0 = *reinterpret_cast<const float4 *>(tsdf + off);
+    const float4 w0 = *reinterpret_cast<const float4 *>(tsdf_w + off);
+    // T already at tdist and w at wmax (the free space after a few frames): the update changes nothing whatever wi >= 0 is,
+    // PROVIDED tdist is a power of two (the frame loop's 4 voxels; sat_ok): then tdist wi and tdist wt are exact, their sum is
+    // tdist (wi + wt) exactly (two float32 values of similar size add exactly in fp64), times the reciprocal, good to an ulp of
+    // the double, rounds to the float32 tdist; and wt = wmax gives min(wi + wmax, wmax) = wmax.  No wi load, no store.
+    const float td = (float)p.tdist, wm = (float)p.wmax;
+    if (sat_ok && t0.x == td && t0.y == td && t0.z == td && t0.w == td && w0.x == wm && w0.y == wm && w0.z == wm && w0.w == wm) return;
+    const float4 wi = *reinterpret_cast<const float4 *>(wi_cache + off);
+    float4 t = t0, w = w0;
+    float *tv = &t.x, *wv = &w.x;
+    const float *wiv = &wi.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (wiv[j] >= 0.0f) {
+            dqb_update_f32(tv[j], wv[j], wiv[j], p.tdist, p.wmax, tv[j], wv[j]);
+        } else {                                   // no stored weight (the blend weights did not normalise): the exact chain's turn
+            redo_list.offs[atomicAdd(redo_list.count, 1u)] = (unsigned)(off + j);
+        }
+    }
+    if (t.x != t0.x || t.y != t0.y || t.z != t0.z || t.w != t0.w) *reinterpret_cast<float4 *>(tsdf + off) = t;
+    if (w.x != w0.x || w.y != w0.y || w.z != w0.z || w.w != w0.w) *reinterpret_cast<float4 *>(tsdf_w + off) = w;
+}
+
+// Regions of the skip inside a level-2 workspace: behind the fast path's 28 B per voxel and the redo list's 4 B + header, in the
+// 8 B per voxel the fp64-weight layout leaves unused.  Returns false when they do not fit (tiny slabs of a large live volume).
+static bool skip_layout(const DqbParams &p, double *w_cache, DqbSkip &k, size_t *used = nullptr) {
+    const size_t nv = (size_t)p.nx * p.Y * p.Z;
+    k.CX = (p.LX + 3) / 4; k.CY = (p.LY + 3) / 4; k.CZ = p.LZ / 4; k.WZ = (k.CZ + 63) / 64;
+    k.SCX = p.nx / 4; k.SCY = (p.Y + 3) / 4;
+    const long nbricks = (long)p.nbx * p.nby * p.nbz;
+    char *base = reinterpret_cast<char *>(w_cache);
+    size_t at = (nv * 32 + 16 + 63) & ~(size_t)63;
+    auto take = [&](size_t bytes) { char *q = base ? base + at : nullptr; at = (at + bytes + 63) & ~(size_t)63; return q; };
+    k.used = reinterpret_cast<unsigned short *>(take((size_t)nbricks * kSkipUsed * 2));        // (static while the graph stays: first)
+    k.U = reinterpret_cast<unsigned long long *>(take((size_t)k.CX * k.CY * k.WZ * 8));
+    k.S = reinterpret_cast<unsigned long long *>(take((size_t)nbricks));                        // (one byte per brick)
+    k.mb = reinterpret_cast<unsigned char *>(take((size_t)nbricks));
+    // blocks of 16 bricks, dealt by a hash of the block index: a bijection on every aligned group of kSkipLists blocks (the low
+    // six bits are xor-ed with bits that are constant inside the group), so no list gets more than this
+    k.sub_cap = (unsigned)((((nbricks + 15) / 16 + kSkipLists - 1) / kSkipLists) * 16);
+    k.sub_count = reinterpret_cast<unsigned *>(take((size_t)kSkipLists * 64));
+    k.sub_list = reinterpret_cast<unsigned *>(take((size_t)kSkipLists * k.sub_cap * 4));
+    k.db = reinterpret_cast<float *>(take((size_t)nbricks * 4));
+    if (used) *used = at;
+    return at <= nv * 40;
+}
+
+// sizes for which the skip's tables exist at all (what the store pass and the steady state both ask)
+static bool skip_sizes_ok(const DqbParams &p) {
+    const size_t nv = (size_t)p.nx * p.Y * p.Z;
+    return p.x0 % 4 == 0 && p.nx % 4 == 0 && p.LZ % 4 == 0 && p.LZ <= 64 * 4 * kSkipMaxWords && p.Z % 64 == 0 && p.Z <= 2048 &&
+           nv / 4 < (1ull << 32);
 }
 
 template <typename LiveT>
@@ -986,8 +1447,11 @@ static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const dou
         static std::once_flag asked;
         static hipError_t asked_rc = hipSuccess;
         std::call_once(asked, [] {
-            asked_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fuse_volume_dqb_lds_kernel<LiveT, 1024, kDqLdsStrideBig>),
+            asked_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fuse_volume_dqb_lds_kernel<LiveT, 1024, kDqLdsStrideBig, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            if (asked_rc == hipSuccess)
+                asked_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fuse_volume_dqb_lds_kernel<LiveT, 1024, kDqLdsStrideBig, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             if (asked_rc != hipSuccess) (void)hipGetLastError();
         });
         lds_path = asked_rc == hipSuccess;
@@ -1007,16 +1471,56 @@ static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const dou
         long wgs = per_cu * di.n_cu;
         const int wpb = tpb / 64;
         if (wgs * wpb > n_runs) wgs = (n_runs + wpb - 1) / wpb;
-#define DFH_K3L(TPB, STRIDE) hipLaunchKernelGGL((fuse_volume_dqb_lds_kernel<LiveT, TPB, STRIDE>), dim3((unsigned)wgs), dim3(TPB), lds, s, (float *)tsdf, \
-                                                (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, knn_cache, w_cache, p, f, (int)n_runs, redo_list)
+        // constant-live skip (above): steady state, m_lw the identity, slab and live volume cut into whole 4-cells, tdist a float32
+        DqbSkip sk = {};
+        const size_t nv = (size_t)p.nx * p.Y * p.Z;
+        // k3_skip: 0 off, 1 on, 2 on + every brick's bound computed (tests), unset: on for grids beyond 256^3 -- measured on the
+        // bench scenes (tools/k3_skip_probe.py): 512^3 / 2 048 nodes 1.91-1.96 -> 1.20-1.25 ms (72 % of the bricks skip), 256^3 /
+        // 512 nodes 235 -> 232-250 us (61 % skip; the pre-passes and the warp kernel's poorer coalescing on 16-voxel rows eat it)
+        const bool skip_wanted = opt().k3_skip > 0 || (opt().k3_skip < 0 && (long)p.X * p.Y * p.Z > (1L << 24));
+        bool skip = skip_wanted && p.tdist > 0.0 && (double)(float)p.tdist == p.tdist && skip_sizes_ok(p) &&
+                    (uintptr_t)live % (4 * sizeof(LiveT)) == 0 && (uintptr_t)tsdf % 16 == 0 && (uintptr_t)tsdf_w % 16 == 0 &&
+                    p.lw.q[0] == 1.0 && p.lw.q[1] == 0.0 && p.lw.q[2] == 0.0 && p.lw.q[3] == 0.0 && p.lw.q[4] == 0.0 && p.lw.q[5] == 0.0 &&
+                    p.lw.q[6] == 0.0 && p.lw.q[7] == 0.0;
+        if (skip) skip = skip_layout(p, w_cache, sk);
+        const float *wi_cache = reinterpret_cast<const float *>(w_cache + 3 * nv);
+        if (skip) {
+            const long nbr = (long)p.nbx * p.nby * p.nbz;
+            int ex = 0;
+            // (the stream's "nothing changes" shortcut: exact only for a power-of-two tdist -- see dqb_stream_kernel)
+            const int sat_ok = frexp(p.tdist, &ex) == 0.5 && p.wmax > 0.0 && (double)(float)p.wmax == p.wmax ? 1 : 0;
+            const int cx_lo = std::max(0, p.x0 / 4 - 2), cx_hi = std::min(sk.CX, (p.x0 + p.nx) / 4 + 2);       // reach <= 2 cells
+            if (cx_hi > cx_lo)
+                hipLaunchKernelGGL((dqb_live_mask_kernel<LiveT>), dim3((unsigned)((cx_hi - cx_lo) * sk.CY)), dim3(1024), 0, s, (const LiveT *)live, p.LX,
+                                   p.LY, p.LZ, p.tdist, sk, cx_lo);
+            hipLaunchKernelGGL(dqb_reach_kernel, dim3((unsigned)((sk.SCX * sk.SCY + 3) / 4)), dim3(256), 0, s, p, sk);
+            hipLaunchKernelGGL(dqb_bound_kernel, dim3((unsigned)((nbr + 15) / 16)), dim3(256), 0, s, node_dq, p, sk, opt().k3_skip == 2 ? 1 : 0);
+            hipLaunchKernelGGL(dqb_stream_kernel, dim3((unsigned)((nv / 4 + 255) / 256)), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, wi_cache, p, sk,
+                               redo_list, (unsigned)(nv / 4), sat_ok);
+        }
+#define DFH_K3L(TPB, STRIDE)                                                                                                                          \
+        do {                                                                                                                                          \
+            if (skip) hipLaunchKernelGGL((fuse_volume_dqb_lds_kernel<LiveT, TPB, STRIDE, true>), dim3((unsigned)wgs), dim3(TPB), lds, s, (float *)tsdf,  \
+                                         (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, knn_cache, w_cache, p, f, (int)n_runs,        \
+                                         redo_list, (const unsigned *)sk.sub_count, (const unsigned *)sk.sub_list, sk.sub_cap);                       \
+            else hipLaunchKernelGGL((fuse_volume_dqb_lds_kernel<LiveT, TPB, STRIDE, false>), dim3((unsigned)wgs), dim3(TPB), lds, s, (float *)tsdf,     \
+                                    (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq, node_w, knn_cache, w_cache, p, f, (int)n_runs, redo_list, \
+                                    (const unsigned *)nullptr, (const unsigned *)nullptr, 0u);                                                       \
+        } while (0)
         if (big) DFH_K3L(1024, kDqLdsStrideBig);
         else if (tpb == 256) DFH_K3L(256, kDqLdsStride); else if (tpb == 512) DFH_K3L(512, kDqLdsStride); else DFH_K3L(1024, kDqLdsStride);
         // ... and right behind it the voxels it put on its redo list, through the exact chain
         hipLaunchKernelGGL((dqb_redo_kernel<LiveT>), dim3(kRedoBlocks), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, (const LiveT *)live, node_pos, node_dq,
-                           node_w, knn_cache, p, redo_list);
+                           node_w, knn_cache, reinterpret_cast<const float *>(w_cache + 3 * ((size_t)p.nx * p.Y * p.Z)), p, redo_list);
 #undef DFH_K3L
     } else if (mode == 0) DFH_K3F(0); else if (mode == 1) DFH_K3F(1); else if (mode == 2) DFH_K3F(2); else DFH_K3F(3);
 #undef DFH_K3F
+    if (mode == 1 && w_cache && skip_sizes_ok(p)) {
+        // the store pass also leaves, per brick, the nodes its voxels blend: what the constant-live skip's bound runs over
+        DqbSkip sk = {};
+        if (skip_layout(p, w_cache, sk))
+            hipLaunchKernelGGL(dqb_used_nodes_kernel, dim3((unsigned)nbricks), dim3(256), 0, s, (const unsigned short *)knn_cache, (const int *)cand, p, sk);
+    }
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }
@@ -1239,6 +1743,30 @@ extern "C" int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, cons
     }
     if (live_dtype == DFH_F32) return launch_dqb<double, float>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
     return launch_dqb<double, double>(tsdf, tsdf_w, live, node_pos, node_dq, node_w, cand, knn_cache, w_cache, mode, p, s);
+}
+
+extern "C" int dfh_dqb_skip_layout(const int res[3], int x0, int x1, const int live_res[3], int knn, int n_nodes, size_t out[13]) {
+    using namespace dfh;
+    DFH_REQUIRE(res && live_res && out, "dfh_dqb_skip_layout: null pointer");
+    DFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0 && 0 <= x0 && x0 < x1 && x1 <= res[0], "dfh_dqb_skip_layout: bad grid / slab");
+    DFH_REQUIRE(knn == 4, "dfh_dqb_skip_layout: the skip belongs to the knn = 4 float32 path");
+    DqbParams p = {};
+    p.X = res[0]; p.Y = res[1]; p.Z = res[2];
+    p.LX = live_res[0]; p.LY = live_res[1]; p.LZ = live_res[2];
+    p.x0 = x0; p.nx = x1 - x0; p.N = n_nodes; p.k = knn;
+    brick_counts(res, x0, x1, p.nbx, p.nby, p.nbz);
+    const size_t cached1 = dfh_dqb_workspace_bytes_cached(res, x0, x1, knn, n_nodes, 1);
+    const size_t cached2 = dfh_dqb_workspace_bytes_cached(res, x0, x1, knn, n_nodes, 2);
+    DFH_REQUIRE(cached2 > cached1, "dfh_dqb_skip_layout: no level-2 workspace for these sizes");
+    DqbSkip k = {};
+    size_t used = 0;
+    const bool fits = skip_layout(p, reinterpret_cast<double *>(cached1), k, &used);        // (pointer arithmetic on offsets only)
+    out[0] = reinterpret_cast<size_t>(k.U); out[1] = reinterpret_cast<size_t>(k.S); out[2] = reinterpret_cast<size_t>(k.mb);
+    out[3] = reinterpret_cast<size_t>(k.db); out[4] = 0; out[5] = 0;
+    out[6] = (size_t)k.CX; out[7] = (size_t)k.CY; out[8] = (size_t)k.WZ; out[9] = (size_t)k.SCX; out[10] = (size_t)k.SCY;
+    out[11] = fits && skip_sizes_ok(p) ? 1 : 0;
+    out[12] = reinterpret_cast<size_t>(k.used);
+    return DFH_OK;
 }
 
 extern "C" int dfh_dqb_build_candidates(const int res[3], int x0, int x1, const double *node_pos, int n_nodes, int knn,

@@ -230,6 +230,33 @@ def dqb_workspace(res, x_range=None, device=None, knn=None, n_nodes=None, level=
     return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.int32, device=device or "cuda")
 
 
+def dqb_skip_tables(workspace, res, live_res, n_nodes, x_range=None, knn=4):
+    """Views of the constant-live skip's per-call tables inside a level-2 dqb_workspace (dfh_dqb_skip_layout), as left by the last
+    steady-state fuse_volume_dqb call through it: {"U": live-cell mask words, "S": uint8 per brick (1 = its voxels took the constant-live stream), "reach": uint8 per
+    brick, "bound": float32 per brick (voxels; -1 = not computed: the live volume ruled the skip out; option k3_skip = 2 computes all), "used": int16 (bricks, 16) node ids, "n_listed": 16-voxel rows left to the warp kernel, "n_runs": all such rows, "ok": sizes admit the skip}.  For tests and
+    measurement code."""
+    import ctypes
+    lib = _lib.load()
+    if x_range is None:
+        x_range = (0, res[0])
+    out = (ctypes.c_size_t * 13)()
+    _lib.check(lib.dfh_dqb_skip_layout(_lib.iarr(res), int(x_range[0]), int(x_range[1]), _lib.iarr(live_res), int(knn), int(n_nodes), out),
+               "dfh_dqb_skip_layout")
+    raw = workspace.view(torch.uint8)
+    nx = int(x_range[1]) - int(x_range[0])
+    nb = (-(-nx // 4)) * (-(-int(res[1]) // 4)) * (-(-int(res[2]) // 16))
+    CX, CY, WZ, SCX, SCY = (int(out[i]) for i in (6, 7, 8, 9, 10))
+    n_runs = nx * int(res[1]) * (int(res[2]) // 16)                      # 16-voxel rows
+
+    def region(i, nbytes, dtype):
+        return raw[int(out[i]):int(out[i]) + nbytes].view(dtype)
+    tabs = {"ok": bool(out[11]), "U": region(0, CX * CY * WZ * 8, torch.int64).view(CX, CY, WZ), "S": region(1, nb, torch.uint8),
+            "reach": region(2, nb, torch.uint8), "bound": region(3, nb * 4, torch.float32), "used": region(12, nb * 32, torch.int16).view(nb, 16)}
+    tabs["n_runs"] = n_runs
+    tabs["n_listed"] = int((tabs["S"] == 0).sum()) * 16                 # rows left to the warp kernel (whole bricks)
+    return tabs
+
+
 def dqb_build_candidates(workspace, res, node_pos, knn, x_range=None):
     """Fill the per-brick candidate node lists of a dqb_workspace (what fuse_volume_dqb does itself on a call with
     rebuild_candidates=True); needed up front only by solve.sample_knn(..., bricks=...)."""

@@ -161,7 +161,11 @@ int dfh_fuse_volume_rigid(void *tsdf, void *tsdf_w, int vol_dtype, const int res
  * the blend weights exp(..) and wi (level 2: + 8*(knn+1) bytes): the call with rebuild_candidates != 0 stores
  * them, later calls skip the node search and the sqrt/divide/exp chain -- same results, bit for bit, since
  * these values depend on (node_pos, node_w, knn, grid, slab) and not on node_dq.  The level in use is
- * inferred from workspace_bytes. */
+ * inferred from workspace_bytes.
+ * float32 volumes, knn = 4, level-2 workspace, lw_dq the identity, steady state (round 4): voxels that provably sample only
+ * live voxels holding exactly tdist -- a per-brick bound on |warp(i) - i| from the brick's candidate nodes' DQs, a per-cell
+ * "all 64 live voxels == tdist" mask -- skip the warp: s = tdist whatever the position; same bits (dfh_dqb_skip_layout;
+ * option k3_skip = 0 switches it off). */
 size_t dfh_dqb_workspace_bytes(const int res[3], int x0, int x1);
 size_t dfh_dqb_workspace_bytes_cached(const int res[3], int x0, int x1, int knn, int n_nodes, int level);
 int dfh_fuse_volume_dqb(void *tsdf, void *tsdf_w, int vol_dtype, const int res[3], int x0, int x1,
@@ -218,6 +222,15 @@ int dfh_closest_correspondences(const double *warped_pos, const double *warped_n
  * graph is unchanged.  nbr_out: n_samples x knn int32; weights_out: n_samples x knn. */
 int dfh_sample_knn(const double *sample_pos, int n_samples, const double *node_pos, const double *node_w, int n_nodes,
                    int knn, int *nbr_out, double *weights_out, void *stream);
+/* Where the constant-live skip of dfh_fuse_volume_dqb (float32 volumes, knn = 4, stored neighbourhoods, m_lw = identity; round 4)
+ * keeps its per-call tables inside a level-2 workspace, as byte offsets from the workspace's start: out[0] live-cell mask U,
+ * [1] slab-cell mask S, [2] per-brick reach (uint8: 1 / 2 cells, 255 = no bound), [3] per-brick displacement bound (float32,
+ * voxels; -1 = not computed), [1] is one byte per brick (1 = constant-live stream, 0 = warp kernel), [4], [5] unused; [6..8] live cells
+ * along x, y and 64-bit words per cell row, [9..10] slab cell rows; [11] 1 when these sizes admit the skip at all; [12] per brick
+ * the 16 node ids (uint16, ascending, 0xffff = none, first = 0xfffe: too many) its voxels blend.  For tests and measurement code:
+ * the proof obligation "no voxel moves further than its brick's bound" is checked against [3] (tests/test_gpu_fuse_volume.py).
+ * No reference counterpart. */
+int dfh_dqb_skip_layout(const int res[3], int x0, int x1, const int live_res[3], int knn, int n_nodes, size_t out[13]);
 /* The same through the per-brick candidate lists of a dfh_fuse_volume_dqb workspace (built for the same node_pos, knn,
  * grid and slab by dfh_dqb_build_candidates or by a dfh_fuse_volume_dqb call with rebuild_candidates != 0): a point
  * scans the list of the brick of its nearest voxel centre (the lists carry the head-room that makes this exact for

@@ -331,3 +331,94 @@ def test_dqb_float32_paths_give_the_same_bits(field):
     assert float(((ex[0] - ref[0]).abs() / (1 + ref[0].abs())).max()) <= f32_tol(1)
     assert float(((ex[1] - ref[1]).abs() / (1 + ref[1].abs())).max()) <= f32_tol(1)
     assert int(((ref[0] != T0) | (ref[1] != W0)).sum()) > 10000
+
+
+# ------------------------------------------------------------------------------ K3: the constant-live skip (round 4)
+def _skip_scene(res, N, tdist, field, seed=3):
+    from dynamicfusion_body_amd.dq import twist_exp_dq
+    rng = np.random.default_rng(seed)
+    gx, gy, gz = (torch.arange(r, device="cuda", dtype=torch.float32) for r in res)
+    c = [r / 2 for r in res]
+    d = torch.sqrt((gx[:, None, None] - c[0]) ** 2 + (gy[None, :, None] - c[1]) ** 2 + (gz[None, None, :] - c[2]) ** 2)
+    rad = 0.3 * min(res)
+    # a live volume as K1 leaves it: the truncation value away from the surface (in front of it and where nothing was seen)
+    live = torch.clamp(d - rad + 0.7, -tdist, tdist).contiguous()
+    T0 = torch.clamp(d - rad, -tdist, tdist).contiguous()
+    W0 = (torch.rand(res, device="cuda") < 0.7).float() * 2.0                  # (zeros: the first-touch rule)
+    W0[: res[0] // 3] = 9.0                                                    # saturated, T at tdist far out: the stream's "nothing changes" shortcut
+    node_pos, node_w = scene.fibonacci_nodes(N, min(res))
+    node_pos = node_pos * (np.array(res) / min(res))
+    amp = {"gentle": (.002, .15), "wild": (.05, 3.0), "identity": (0.0, 0.0)}[field]
+    dqs = twist_exp_dq(rng.normal(size=(N, 6)) * np.array([amp[0]] * 3 + [amp[1]] * 3))
+    return live, T0, W0, node_pos, node_w, dqs
+
+
+@pytest.mark.parametrize("res,tdist,field,live_dtype", [((128, 128, 128), 4.0, "gentle", torch.float32), ((64, 62, 128), 3.0, "gentle", torch.float64),
+                                                        ((64, 64, 64), 4.0, "wild", torch.float32), ((64, 64, 64), 2.0, "identity", torch.float32)])
+def test_dqb_constant_live_skip_gives_the_same_bits(res, tdist, field, live_dtype):
+    """Steady state of the float32 / knn = 4 path with m_lw = identity: bricks that provably sample only live voxels holding
+    exactly tdist skip the warp (dqb_stream_kernel), the others go through the LDS kernel from the skip's sub-lists.  Same bits as
+    with the skip off -- whole grid and a slab that starts inside the grid, float32 and float64 live volumes, a ragged y extent
+    (cells cut by the volume's face never count as constant), tdist a power of two (the saturated shortcut) and not; a gentle
+    field skips a share of the bricks (the sphere's shell is thick against these small grids), a wild one (translations of voxels: bounds beyond 7) none or few, and the identity
+    field sends every remaining voxel through the redo list."""
+    from dynamicfusion_body_amd import _lib
+    N, k = 150, 4
+    live, T0, W0, node_pos, node_w, dqs = _skip_scene(res, N, tdist, field)
+    live = live.to(live_dtype)
+    ident = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+    for a, b in ((0, res[0]), (res[0] // 4, res[0] // 4 * 3)):
+        outs = {}
+        for skip in (1, 0):
+            ws = kernels.dqb_workspace(res, (a, b), knn=k, n_nodes=N, level=2)
+            T, W = T0[a:b].clone(), W0[a:b].clone()
+            _lib.set_option("k3_skip", skip)
+            kernels.fuse_volume_dqb(T, W, live, node_pos, dqs, node_w, k, ident, tdist, 9.0, res=res, x_range=(a, b), workspace=ws, rebuild_candidates=True)
+            Tm, Wm = T.clone(), W.clone()
+            for _ in range(2):                                                  # steady state, twice (w reaches wmax on the way)
+                kernels.fuse_volume_dqb(T, W, live, node_pos, dqs, node_w, k, ident, tdist, 9.0, res=res, x_range=(a, b), workspace=ws,
+                                        rebuild_candidates=False)
+            torch.cuda.synchronize()
+            outs[skip] = (T, W, Tm, Wm)
+            if skip:
+                tabs = kernels.dqb_skip_tables(ws, res, res, N, x_range=(a, b))
+                assert tabs["ok"]
+                share = float(tabs["S"].float().mean())
+        assert torch.equal(outs[1][2], outs[0][2]) and torch.equal(outs[1][3], outs[0][3])          # (the store pass: no skip yet)
+        assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1]), (res, field, (a, b))
+        assert not torch.equal(outs[1][0], outs[1][2])                                               # the steady-state calls did something
+        if field == "gentle":
+            assert share > 0.05, share
+        if field == "wild":
+            assert share < 0.2, share
+
+
+def test_dqb_skip_bound_holds_for_every_voxel():
+    """The proof obligation of the skip, checked on the device: for every brick whose bound is finite no voxel's warped position
+    (the reference's chain, dfh_warp_points, with the voxel's k nearest nodes) lies further from the voxel than the brick's bound.
+    Unit and non-unit node DQs (the 8-norm's scale term), rotations up to a few degrees, translations up to voxels."""
+    from dynamicfusion_body_amd import _lib
+    from dynamicfusion_body_amd.solve import sample_knn, warp_points
+    from dynamicfusion_body_amd.dq import twist_exp_dq
+    R, N, k, tdist = 64, 120, 4, 4.0
+    rng = np.random.default_rng(17)
+    live, T0, W0, node_pos, node_w, _ = _skip_scene((R, R, R), N, tdist, "gentle")
+    ident = np.array([1.0, 0, 0, 0, 0, 0, 0, 0])
+    g = torch.stack(torch.meshgrid(*[torch.arange(R, device="cuda", dtype=torch.float64)] * 3, indexing="ij"), dim=-1).reshape(-1, 3).contiguous()
+    nbr, _ = sample_knn(g, node_pos, node_w, k)
+    for rot, trans, scale in ((.003, .3, 1.0), (.03, 1.5, 1.0), (.01, .5, 1.03)):
+        dqs = twist_exp_dq(rng.normal(size=(N, 6)) * np.array([rot] * 3 + [trans] * 3)) * scale
+        ws = kernels.dqb_workspace((R, R, R), knn=k, n_nodes=N, level=2)
+        T, W = T0.clone(), W0.clone()
+        _lib.set_option("k3_skip", 2)                                           # every brick's bound, also where the live volume rules the skip out
+        for rebuild in (True, False):
+            kernels.fuse_volume_dqb(T, W, live, node_pos, dqs, node_w, k, ident, tdist, 9.0, workspace=ws, rebuild_candidates=rebuild)
+        torch.cuda.synchronize()
+        bound = kernels.dqb_skip_tables(ws, (R, R, R), (R, R, R), N)["bound"].double().view(R // 4, R // 4, R // 16)
+        wp, _ = warp_points(g, None, ident, nbr=nbr, node_dq=dqs, node_pos=node_pos, node_w=node_w)
+        disp = (wp - g).norm(dim=1).view(R // 4, 4, R // 4, 4, R // 16, 16).amax(dim=(1, 3, 5))
+        finite = torch.isfinite(bound)
+        assert float(finite.float().mean()) > 0.9
+        assert bool((bound >= 0).all())
+        assert bool((disp[finite] <= bound[finite]).all()), float((disp[finite] / bound[finite]).max())
+        assert float((disp[finite] / bound[finite]).max()) > 0.3               # ... and it is not vacuous

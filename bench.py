@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--leg-timeout", type=int, default=300, help="N > 1: seconds the secondary legs (gn, frame) may take before "
                                                                    "rank 0 prints the line without them and every rank leaves (0 = off)")
     ap.add_argument("--no-frame", action="store_true", help="skip the end-to-end per-frame leg")
+    ap.add_argument("--no-frame-512", action="store_true", help="skip the config-5-size frame leg (512^3, 8 views, 2 048 nodes; 1 GPU only)")
     ap.add_argument("--gn-nodes", type=int, default=512)
     ap.add_argument("--gn-mode", default="auto", choices=("auto", "sharded", "replicated"), help="N > 1: how the warp solve runs")
     ap.add_argument("--gn-solves", type=int, default=5, help="timed solves of 10 GN iterations each")
@@ -205,6 +206,11 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
                                                            "all samples on every rank")}
 
 
+def kernels_mod():
+    from dynamicfusion_body_amd import kernels
+    return kernels
+
+
 def pcg_path_name(n_nodes):
     """Which PCG the solves of this process take (dfh_pcg_path): runs compare bit for bit only on the same path -- ranks that share
     one GPU (a rehearsal) take the two-launch kernels, one rank per GPU the persistent single-reduction kernel."""
@@ -213,7 +219,47 @@ def pcg_path_name(n_nodes):
     return {1: "persistent single-reduction kernel", 2: "two launches per iteration (ranks share a GPU, or forced)"}.get(code, "error %d" % code)
 
 
-def frame_leg(args, torch, dist, scene, rank, world, barrier):
+def k23_of(torch, kernels, sf, tvox):
+    """K2 (FusionDM.updateTSDF, core/fusion_dm.py:300-316) and K3 (Fusion.updateTSDF, core/fusion.py:153-198) on the state a frame
+    loop has reached: the canonical slab, the live volume of its last frame, the solved warp field, K3's stored neighbourhoods
+    (steady state, what every frame after the first runs).  HIP-event time per call; SURVEY 8(d)'s algorithmic bytes = 20 B per
+    voxel (T and w read and written, each live sample counted once)."""
+    from dynamicfusion_body_amd import _lib
+    R = sf.R
+    nv = float(sf.T.numel())
+    sv = sf.fs.solver
+    T, Wt = sf.T.clone(), sf.Wt.clone()
+    alg = 20.0 * nv
+    out = {}
+    lw_rigid = np.array([0.9999995, 0.0005, -0.0007, 0.0004, 0.0, 0.05, -0.03, 0.02])        # a small rigid motion (unit to 1e-7: the reference's _lw)
+    ms = time_launches(torch, lambda: kernels.fuse_volume_rigid(T, Wt, sf.live, lw_rigid, tvox, res=(R, R, R), x_range=(sf.a, sf.b)), 10)
+    out["k2_rigid"] = {"kernel_ms": ms, "algorithmic_bytes": alg, "algorithmic_GBps": alg / (ms * 1e-3) / 1e9,
+                       "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mvox_per_s": nv / ms / 1e3}
+
+    def k3():
+        kernels.fuse_volume_dqb(T, Wt, sf.live, sv.node_pos, sv.node_dq, sv.node_w, sf.knn, sf.ident_lw, tvox, res=(R, R, R),
+                                x_range=(sf.a, sf.b), workspace=sf.ws_dqb, rebuild_candidates=False)
+    ms = time_launches(torch, k3, 10)
+    tabs = kernels.dqb_skip_tables(sf.ws_dqb, (R, R, R), (R, R, R), int(sv.N), x_range=(sf.a, sf.b))
+    skipped = float(tabs["S"].float().mean()) if tabs["ok"] else 0.0
+    skip_on = _lib.get_option("k3_skip") > 0 or (_lib.get_option("k3_skip") < 0 and R ** 3 > (1 << 24))
+    out["k3_dqb"] = {"kernel_ms": ms, "algorithmic_bytes": alg, "algorithmic_GBps": alg / (ms * 1e-3) / 1e9,
+                     "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mvox_per_s": nv / ms / 1e3, "nodes": int(sv.N),
+                     "constant_live_skip": bool(skip_on and tabs["ok"]),
+                     "bricks_skipping_the_warp": skipped if (skip_on and tabs["ok"]) else None,
+                     "what": "steady state (stored neighbourhoods, float32 volumes, identity m_lw): every launch of the call -- "
+                             "live-cell mask, reach, per-brick bound, constant-live stream, warp kernel, redo list"}
+    _lib.set_option("k3_skip", 0 if skip_on else 1)                                          # the other setting, for the record
+    try:
+        ms2 = time_launches(torch, k3, 10)
+        out["k3_dqb"]["kernel_ms_skip_%s" % ("off" if skip_on else "on")] = ms2
+    finally:
+        _lib.set_option("k3_skip", None)
+    del T, Wt
+    return out
+
+
+def frame_leg(args, torch, dist, scene, rank, world, barrier, nframes=8, with_k23=False):
     """One non-rigid frame at config-3 scale, the loop of the reference's test.py:116-131 with this build's
     device path (pipeline.SlabFrame): live depth -> live TSDF slab (K1) -> all-gather of the live volume
     (N > 1) -> 10 GN iterations against the live depth (one all-reduce each) -> canonical slab <- live through
@@ -241,7 +287,6 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
     sf.refresh_samples()
     lws = [scene.view_extrinsic(a) for a in angles]
     lw_cam = lws
-    nframes = 8
     depths = []
     for f in range(nframes):                      # the sphere drifts and breathes a little every frame; three views per frame
         off = np.array([0.10, -0.07, 0.05]) * (f + 1) * scale
@@ -294,7 +339,9 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier):
     tot = torch.tensor([float(info["samples"])], dtype=torch.float64, device="cuda")
     if world > 1 and sf.solve_mode == "sharded":          # (replicated: every rank already holds the all-gathered sample set)
         dist.all_reduce(tot)
-    return {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "frames_timed": nframes - nwarm, "scaling": "strong" if world > 1 else "n/a",
+    k23 = k23_of(torch, kernels_mod(), sf, tdist / scale) if (with_k23 and world == 1) else None
+    return {**({"k23": k23} if k23 is not None else {}),
+            "ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "frames_timed": nframes - nwarm, "scaling": "strong" if world > 1 else "n/a",
             "stage_ms_with_syncs": {kk: vv / (nframes - nwarm) for kk, vv in stages.items()},
             "gn_iters_per_frame": iters, "nodes": N, "samples": int(tot.item()), "mesh_vertices": info["vertices"],
             "mesh_faces": info["faces"], "final_cost": cost,
@@ -668,11 +715,13 @@ def main():
                                # parity spot check: same update mask as the GPU volume after the same views
                                "mask_match": bool(np.array_equal(Wo > 0, (Wt > 0).cpu().numpy()))}
     del T, Wt
+    k1_512_failed = False
     if world == 1 and not args.no_k1_512:
         try:
             out["k1_512"] = k1_512_leg(torch, kernels, scene)
         except Exception as e:
             out["k1_512"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            k1_512_failed = True
 
     # The headline (K1) is measured; the secondary legs below run collectives.  If a rank fails inside one of them its peers would
     # wait in a collective for ever, so every rank runs a watchdog thread: it ends the rank when the legs' time limit passes OR when
@@ -719,7 +768,7 @@ def main():
 
     if distributed and args.leg_timeout > 0:
         threading.Thread(target=watch, daemon=True).start()
-    failed = False
+    failed = k1_512_failed
     if not args.no_gn:
         try:
             out["gn"] = gn_leg(args, torch, dist, scene, rank, world, barrier)
@@ -728,10 +777,30 @@ def main():
             failed = True
         if not args.no_frame and not (failed and distributed):
             try:
-                out["frame"] = frame_leg(args, torch, dist, scene, rank, world, barrier)
+                out["frame"] = frame_leg(args, torch, dist, scene, rank, world, barrier, with_k23=True)
+                k23 = out["frame"].pop("k23", None)
+                if k23 is not None:
+                    out["k23"] = {"workload": "TSDF -> TSDF fusion of the frame loop's live volume into its canonical volume: K2 = "
+                                              "FusionDM.updateTSDF (rigid), K3 = Fusion.updateTSDF (DQB warp field), float32 volumes, HIP events "
+                                              "around 10 calls; bytes = SURVEY 8(d): 20 B per voxel; PMC traffic: profiles/ (DESIGN.md section 5)",
+                                  "%d^3_%d_nodes" % (args.res, args.gn_nodes): k23}
             except Exception as e:                    # the composed leg must never cost the headline line
                 out["frame"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
                 failed = True
+            if world == 1 and not args.no_frame_512 and args.res == 256 and not failed:
+                # BASELINE config 5 on ONE GPU: 512^3, 8 views of 1280x720, 2 048 nodes (the 8-GPU run is the driver's)
+                try:
+                    import copy
+                    a5 = copy.copy(args)
+                    a5.res, a5.gn_nodes = 512, 2048
+                    f5 = frame_leg(a5, torch, dist, scene, rank, world, barrier, nframes=5, with_k23=True)
+                    k23 = f5.pop("k23", None)
+                    if k23 is not None and "k23" in out:
+                        out["k23"]["512^3_2048_nodes"] = k23
+                    out["frame_512"] = f5
+                except Exception as e:
+                    out["frame_512"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                    failed = True
     if distributed and failed:
         # this rank's collectives no longer match its peers': do not enter another one.  Tell the peers (their watchdogs look at
         # the store), give rank 0 a moment to print its line before a launcher that kills the job at the first non-zero exit

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DFH_LIB_PATH") or os.path.join(_PKG, "libdfusion_hip.
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dfusion_hip.h")
 
 F32, F64 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -77,6 +77,8 @@ _SIGNATURES = {
                                 _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _dbl, _vp]),
     "dfh_gn_views_bytes": (ctypes.c_size_t, [_int]),
     "dfh_gn_pack_views": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_void_p), _c_double_p, _vp]),
+    "dfh_gn_views_bytes_cells": (ctypes.c_size_t, [_int, _int, _int]),
+    "dfh_gn_pack_views_cells": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_void_p), _int, _int, _c_double_p, _vp]),
     "dfh_gn_associate_views": (_int, [_vp, _vp, _vp, _int, _int, _vp, _c_double_p, _vp, _int, _int, _int, _int, _c_double_p,
                                       _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _vp, _vp, _vp]),
     "dfh_gn_build_planned_assoc_views": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _c_double_p, _dbl,

@@ -586,11 +586,19 @@ class WarpSolver:
         lw = np.ascontiguousarray(np.stack([np.asarray(m, dtype=np.float64).reshape(12) for m in lw_cams]))
         key = (tuple(int(d.data_ptr()) for d in depths), lw.tobytes(), current_stream_ptr())
         if getattr(self, "_views_key", None) != key:
-            nbytes = self.lib.dfh_gn_views_bytes(n)
-            buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
             ptrs = (ctypes.c_void_p * n)(*[int(d.data_ptr()) for d in depths])
-            _lib.check(self.lib.dfh_gn_pack_views(buf.data_ptr(), n, ptrs, lw.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                                  current_stream_ptr()), "dfh_gn_pack_views")
+            Hh, Ww = (int(v) for v in depths[0].shape)
+            if depths[0].dtype == torch.float32:
+                # with the per-view depth-cell tables: the fused build drops, per tile, the views that cannot hold a correspondence
+                nbytes = self.lib.dfh_gn_views_bytes_cells(n, Hh, Ww)
+                buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+                _lib.check(self.lib.dfh_gn_pack_views_cells(buf.data_ptr(), n, ptrs, Hh, Ww, lw.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                            current_stream_ptr()), "dfh_gn_pack_views_cells")
+            else:
+                nbytes = self.lib.dfh_gn_views_bytes(n)
+                buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+                _lib.check(self.lib.dfh_gn_pack_views(buf.data_ptr(), n, ptrs, lw.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                      current_stream_ptr()), "dfh_gn_pack_views")
             self._views_key, self._views_buf, self._views_keep = key, buf, list(depths)
         H, W = depths[0].shape
         return self._views_buf, n, int(H), int(W)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DFH_ABI_VERSION 3
+#define DFH_ABI_VERSION 4
 
 #define DFH_F32 0
 #define DFH_F64 1
@@ -286,6 +286,14 @@ int dfh_gn_associate(const double *sample_pos, const int *nbr, const double *wei
 #define DFH_GN_MAX_VIEWS 16
 size_t dfh_gn_views_bytes(int n_views);
 int dfh_gn_pack_views(void *views_out, int n_views, const void *const *depth, const double *lw_cam, void *stream);
+/* The same table with, behind it, per view a table of 16 x 16-pixel cells {smallest, largest valid z = -depth} of FLOAT32 depth
+ * maps (views_out: dfh_gn_views_bytes_cells(n_views, H, W) bytes).  With it the fused builds (dfh_gn_build_planned_assoc_views,
+ * dfh_gn_iteration_views) drop, per 128-sample tile, the views none of its samples can be valid in -- the tile's warped samples'
+ * box projects outside the image, or onto pixels whose valid depths all lie further than max_dist from the box's depth range
+ * (exact for rigid extrinsics and a pinhole K: |c - x'| >= |z - l2| / scale) -- before projecting a single sample into them:
+ * same corr / valid, same bits (option gn_no_view_cull = 1 keeps every view).  Round 4; no reference counterpart. */
+size_t dfh_gn_views_bytes_cells(int n_views, int H, int W);
+int dfh_gn_pack_views_cells(void *views_out, int n_views, const void *const *depth, int H, int W, const double *lw_cam, void *stream);
 int dfh_gn_associate_views(const double *sample_pos, const int *nbr, const double *weights, int n_samples, int knn,
                            const double *node_dq, const double lw_dq[8], const void *views, int n_views, int depth_dtype, int H, int W,
                            const double K[9], const double Kinv[9], double scale, const double center[3], double half,

@@ -306,3 +306,51 @@ def test_multi_view_association_and_gn_loop_vs_oracle():
     assert max(abs(a - b) for a, b in zip(gpu_counts, or_counts)) <= 3
     assert np.abs(sv.node_dq.cpu().numpy() - dq_or).max() <= 1e-5
     assert gpu_costs[-1] / gpu_counts[-1] < gpu_costs[0] / gpu_counts[0]
+
+
+def test_view_culling_per_tile_changes_nothing():
+    """Config 5's data term: eight orbit views, 45 degrees apart.  The fused build drops, per 128-sample tile, the views none
+    of the tile's samples can be valid in (csrc/dfh_solve.hip: tile_view_mask -- the tile's box projects outside the image, or
+    onto pixels whose valid depths lie further than the gate from the box's depth range) before projecting a sample into them.
+    Asserted: corr / valid, the normal equations and the cost are bit for bit those of the build that tries every view
+    (option gn_no_view_cull) and corr / valid those of the stand-alone association kernel; five of the eight views win somewhere (the three behind the back wall see the wall, not the sphere)."""
+    from dynamicfusion_body_amd import _lib
+    R, N = 128, 256
+    angles = tuple(45.0 * v for v in range(8))
+    K, Kinv, (H, W), scale, center, tdist, T, Wt = canonical(R, "C2", angles=angles)
+    fs = FrameSolver(K, scale, center, R / 2, knn=4, pcg_iters=10, distributed=False)
+    node_pos, node_w = scene.fibonacci_nodes(N, R)
+    ident = np.tile(IDENT, (N, 1))
+    fs.set_graph(node_pos, ident, node_w)
+    S = fs.set_canonical(T, Wt, band=4.0)
+    assert S > 50000
+    off = np.array([0.5, -0.35, 0.25]) * scale
+    lws = [scene.view_extrinsic(a) for a in angles]
+    lives = [scene.render_depth(K, lw, H, W, dtype=np.float32, sphere_offset=off, sphere_r=scene.SPHERE_R * 1.01) for lw in lws]
+    depths = [torch.from_numpy(d).cuda() for d in lives]
+    sv = fs.solver
+    rng = np.random.default_rng(23)
+    dq0 = G.apply_twists(ident, rng.normal(scale=[2e-3] * 3 + [0.15] * 3, size=(N, 6)))
+    sv.node_dq.copy_(torch.from_numpy(dq0).cuda())
+    max_dist = 2.0
+    sv.associate_depth(depths, K, Kinv, lws, scale, center, R / 2, fs.lw, max_dist)            # every view, sample by sample
+    ref_c, ref_v = sv.corr.clone(), sv.valid.clone()
+    assert int(ref_v.sum()) > 20000
+    outs = []
+    for opt in (None, 1):
+        _lib.set_option("gn_no_view_cull", opt)
+        sv.corr.zero_(); sv.valid.zero_()
+        sv.build_associated(depths, K, Kinv, lws, scale, center, R / 2, fs.lw, 5.0, max_dist, 0.5)
+        c, n = sv.cost()
+        assert torch.equal(sv.corr, ref_c) and torch.equal(sv.valid, ref_v), opt
+        outs.append((sv.vals.clone(), sv.rhs.clone(), c, n))
+    _lib.set_option("gn_no_view_cull", None)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2:] == outs[1][2:]
+    # every one of the eight views is the closest valid one for some samples (the culling never removes a winner)
+    pos, nrm, nbr, node_nbr = host_arrays(sv)
+    from oracle import oracle_np as O
+    sel = rng.choice(len(pos), size=4000, replace=False)
+    warped = O.warp(pos[sel], dq0[nbr[sel]], node_pos[nbr[sel]], node_w[nbr[sel]], m_lw=IDENT)
+    co, vo, view = G.associate_depth_views(warped, K, Kinv, lws, lives, scale, center, R / 2, max_dist)
+    # (the views behind the back wall see the wall, not the sphere: they win nowhere -- and are dropped for every tile)
+    assert np.array_equal(ref_v.cpu().numpy()[sel].astype(bool), vo) and len(set(view[vo])) >= 5

@@ -2465,6 +2465,29 @@ __device__ __forceinline__ void apply_twist_one(double *__restrict__ d, double o
     d[4] = nd.w; d[5] = nd.x; d[6] = nd.y; d[7] = nd.z;
 }
 
+// dq <- exp(factor * log(dq)): the node's rigid motion scaled towards the identity (factor in [0, 1]) along its own screw.
+// log of a dual quaternion (q | qe) with q = |q| (cos(t/2), sin(t/2) n): omega = t n, v = 2 vec(qe q*) / |q|^2 -- the inverse of
+// apply_twist_one's exp for a unit q; a non-unit q (the solve never renormalises) comes back unit.
+__global__ __launch_bounds__(256) void relax_twist_kernel(double *__restrict__ node_dq, int N, double factor) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= N) return;
+    double *d = node_dq + 8 * (size_t)a;
+    const double w = d[0], x = d[1], y = d[2], z = d[3];
+    const double n2 = (w * w + x * x) + (y * y + z * z);
+    if (!(n2 > 1e-300) || !(n2 < 1e300)) return;                               // (zero / non-finite: left alone)
+    const double vn = sqrt(x * x + y * y + z * z);
+    const double th = 2.0 * atan2(vn, w);                                      // rotation angle, (-2 pi, 2 pi]
+    const double k = vn > 1e-12 ? th / vn : 2.0 / sqrt(n2);                    // omega = k (x, y, z)
+    // (0, v) = 2 qe q* / |q|^2
+    const double e0 = d[4], e1 = d[5], e2 = d[6], e3 = d[7];
+    const double inv = 2.0 / n2;
+    const double vx = inv * (-e0 * x + e1 * w - e2 * z + e3 * y);
+    const double vy = inv * (-e0 * y + e2 * w - e3 * x + e1 * z);
+    const double vz = inv * (-e0 * z + e3 * w - e1 * y + e2 * x);
+    d[0] = 1.0; d[1] = d[2] = d[3] = d[4] = d[5] = d[6] = d[7] = 0.0;
+    apply_twist_one(d, factor * k * x, factor * k * y, factor * k * z, factor * vx, factor * vy, factor * vz);
+}
+
 __global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ node_dq, const double *__restrict__ xi, int N,
                                                            double step) {
     const int a = blockIdx.x * 256 + threadIdx.x;
@@ -3403,6 +3426,16 @@ int dfh_gn_unpack_upper(double *system, const int *row_of, const int *col, const
     const long n = (long)n_blocks * 36 + 6L * n_nodes + 2;
     hipLaunchKernelGGL(gn_unpack_upper_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, system, row_of, col, src,
                        n_blocks, 6 * n_nodes + 2, packed, n_upper);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_relax_twists(double *node_dq, int n_nodes, double factor, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_nodes >= 0 && factor >= 0.0 && factor <= 1.0, "dfh_relax_twists: %d nodes, factor %g (0..1)", n_nodes, factor);
+    if (n_nodes == 0 || factor == 1.0) return DFH_OK;
+    DFH_REQUIRE(node_dq, "dfh_relax_twists: null pointer");
+    hipLaunchKernelGGL(relax_twist_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, (hipStream_t)stream, node_dq, n_nodes, factor);
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }

@@ -116,6 +116,8 @@ class SlabFrame:
     slab <- live volume through the warp field (K3) -> this slab's samples for the next frame.
     With one rank it is the single-GPU frame."""
 
+    RELAX = 0.8          # default of step(relax=...): see there
+
     def __init__(self, K, scale, center, res, tdist_vox, node_pos, node_w, knn=4, pcg_iters=10, band=4.0, volume_dtype=torch.float32,
                  distributed=True, solve_mode="auto"):
         """solve_mode (several ranks): "sharded" = every rank builds the normal equations of its own slab's samples, one
@@ -242,10 +244,13 @@ class SlabFrame:
         return n_new
 
     def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5, stage_ms=None,
-             update_graph=False, on_updated=None, data_views=None):
-        """Defaults (regulariser weight, LM damping, association gate and Huber threshold in voxels) are the ones under which the loop tracks
-        a +-0.5 voxel oscillation of the bench scene for hundreds of frames without drift (tools/soak.py); with a 4-voxel
-        gate and weak damping, nodes without data support wander and the TSDF update then corrupts the canonical volume.
+             update_graph=False, on_updated=None, data_views=None, relax=None):
+        """Defaults (regulariser weight, LM damping, association gate and Huber threshold in voxels, the per-frame decay of the warp
+        field `relax` = 0.8) are the ones under which the loop follows a +-0.6 voxel oscillation of the bench scene with a BOUNDED
+        warp field: max node translation 0.85 voxel at frame 400, 1.01 at frame 1 200, sample count constant (tools/soak.py;
+        tests/test_gpu_pipeline.py::test_soak_300_frames runs 300 of them).  Without the decay (relax = 1, round 3) nothing
+        pulls a node back: 2.3 voxels at frame 400 and growing, the |T| < band shell thickens and the sample count doubles.  With
+        a 4-voxel gate and weak damping, nodes without data support wander and the TSDF update corrupts the canonical volume.
         stage_ms: optional dict; when given, the device is synchronised after every stage and the stage's wall
         time (ms) is added under its name (for breakdowns only: the syncs cost throughput).
         on_updated: optional callable, called once the launches of this frame's TSDF update are queued and `self.updated` is
@@ -302,6 +307,13 @@ class SlabFrame:
         kernels.fuse_volume_dqb(self.T, self.Wt, live_full, sv.node_pos, sv.node_dq, sv.node_w, self.knn, self.ident_lw, self.tvox,
                                 res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_dqb, rebuild_candidates=self._first)
         self._first = False
+        # the warp field decays towards the identity once the TSDF update has used it (dfh_relax_twists: every node's motion
+        # scaled by `relax` along its own screw).  Fusion.updateTSDF writes most of the motion into the canonical volume every
+        # frame, and without a term that pulls a node back the field random-walks over hundreds of frames
+        # (tools/soak.py; tests/test_gpu_pipeline.py::test_soak_300_frames).  relax = 1 keeps round 3's behaviour.
+        rx = self.RELAX if relax is None else float(relax)
+        if rx != 1.0:
+            _lib.check(_lib.load().dfh_relax_twists(sv.node_dq.data_ptr(), int(sv.N), rx, current_stream_ptr()), "dfh_relax_twists")
         if self.updated is None:
             self.updated = torch.cuda.Event()
         self.updated.record()                  # the canonical slab of this frame is final from here on (a consumer on another

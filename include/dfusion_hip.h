@@ -470,6 +470,13 @@ int dfh_pcg_status_peek(void *stream, long *aborted_solves_out);
 
 /* node_dq[a] <- exp(step * xi[a]) (x) node_dq[a]; exp = rotation exp(omega), translation v. */
 int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step, void *stream);
+/* node_dq[a] <- exp(factor * log(node_dq[a])), 0 <= factor <= 1: every node's rigid motion scaled towards the identity along its
+ * own screw (a unit dual quaternion comes back; zero / non-finite entries are left alone).  The composed frame loop calls it once
+ * per frame after the TSDF update (pipeline.SlabFrame.step(relax=...)): Fusion.updateTSDF moves the canonical surface most of
+ * the way to the live one every frame (core/fusion.py:180-190: the live sample weighs wi ~ tens against a canonical weight that
+ * starts at the view count), so what the field carried is largely in the volume afterwards -- without this decay nothing ever
+ * pulls a node back and the field random-walks.  No reference counterpart. */
+int dfh_relax_twists(double *node_dq, int n_nodes, double factor, void *stream);
 
 /* ---- surface samples for the solve (stand-in for marching cubes, core/fusion.py:554-568) -----------
  * Every band voxel (w > 0, |T| < band; T in voxel units as fuseDepths stores it) whose TSDF gradient

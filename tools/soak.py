@@ -27,8 +27,14 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 solves = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 for f in range(frames):
     sf.step(depths[f % 21], lws, gn_iters=10, huber=float(os.environ.get('HUBER', '0.5')), max_dist=float(os.environ.get('GATE', '2')),
-            data_views=int(os.environ['VIEWS']) if os.environ.get('VIEWS') else None)      # VIEWS=1: the data term on the first view only
+            data_views=int(os.environ['VIEWS']) if os.environ.get('VIEWS') else None,      # VIEWS=1: the data term on the first view only
+            relax=float(os.environ['RELAX']) if os.environ.get('RELAX') else None)
+    c_, n_ = sf.fs.solver.cost()                      # (data + regulariser objective at the frame's last build, valid samples)
+    hist = globals().setdefault("hist", [])
+    hist.append((c_ / max(n_, 1), n_))
     if f % 50 == 49:
+        h = np.array(hist[-50:])
+        print("   last 50 frames: objective per valid sample %.4f (mean), valid samples %.0f (mean)" % (h[:, 0].mean(), h[:, 1].mean()), flush=True)
         dq = sf.fs.solver.node_dq
         assert torch.isfinite(dq).all(), "non-finite warp field at frame %d" % f
         d = dq.cpu().numpy()
@@ -41,7 +47,7 @@ for f in range(frames):
               "that do not; max rotation %.4f, samples %d" % (f + 1, time.perf_counter() - t0, tr[sup].max(), sup.sum(), np.median(tr[sup]),
                                                              np.percentile(tr[sup], 99), tr[~sup].max() if (~sup).any() else 0.0, (~sup).sum(),
                                                              rot.max(), sv_.S), flush=True)
-        assert tr[sup].max() < 3.0, "the warp field drifts: max translation %.2f voxel at frame %d (scene moves +-0.6)" % (tr[sup].max(), f + 1)
+        assert tr.max() < 3.0, "the warp field drifts: max translation %.2f voxel over all nodes at frame %d (scene moves +-0.6)" % (tr.max(), f + 1)
 sv = sf.fs.solver
 v0 = sv.vals.clone()
 x_ref = None

@@ -106,6 +106,8 @@ _SIGNATURES = {
     "dfh_pcg_status_peek": (_int, [_vp, ctypes.POINTER(ctypes.c_long)]),
     "dfh_apply_twist": (_int, [_vp, _vp, _int, _dbl, _vp]),
     "dfh_relax_twists": (_int, [_vp, _int, _dbl, _vp]),
+    "dfh_gn_global_step_bytes": (ctypes.c_size_t, []),
+    "dfh_gn_global_step": (_int, [_vp, _int, _vp, _int, _dbl, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "dfh_surface_workspace_bytes": (ctypes.c_size_t, [_c_int_p]),
     "dfh_surface_count": (_int, [_vp, _vp, _int, _c_int_p, _dbl, _vp, ctypes.c_size_t, _vp, _vp]),
     "dfh_surface_emit": (_int, [_vp, _vp, _int, _c_int_p, _int, _dbl, _vp, _vp, _vp, ctypes.c_long, _vp]),

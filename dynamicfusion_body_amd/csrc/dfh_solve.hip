@@ -2488,6 +2488,71 @@ __global__ __launch_bounds__(256) void relax_twist_kernel(double *__restrict__ n
     apply_twist_one(d, factor * k * x, factor * k * y, factor * k * z, factor * vx, factor * vy, factor * vz);
 }
 
+// ---- the rigid mode of the normal equations (round 4) ------------------------------------------------------------
+// Ten block-Jacobi PCG iterations barely move the smoothest mode of the system -- all nodes moving together -- which the
+// regulariser does not penalise and the preconditioner does not see: of a pure 0.6-voxel translation the shipped ten GN
+// iterations recover 28 % along the normals, the exactly solved loop 70 % (tests/golden/solve_recovery.json).  The coarse
+// correction: restrict the system to ONE twist shared by all nodes, x_a = xi for every a -- A_g = sum of all 6x6 blocks,
+// g_g = sum of all J^T r -- solve (A_g + lm diag A_g) xi = -g_g and apply xi to every node.  kGlobalWgs workgroups add their
+// share of the blocks (wave w of the grid: blocks w, w + n_waves, ...; lane e < 36 one matrix entry, lanes 36..41 the J^T r
+// entries of nodes w, w + n_waves, ...), publish 42 partial sums, and the workgroup that draws the last ticket adds the
+// partials in index order (same bits every run), solves by Cholesky and applies the twist.
+constexpr int kGlobalWgs = 64;
+__global__ __launch_bounds__(256) void gn_global_step_kernel(const double *__restrict__ vals, int n_blocks, const double *__restrict__ rhs, int N,
+                                                              double lm_rel, double *__restrict__ node_dq, double *__restrict__ xi_out,
+                                                              double *__restrict__ scratch /* kGlobalWgs x 42 partials | ticket */) {
+    __shared__ double part[4][42];
+    __shared__ double sA[36], sg[6], sxi[6];
+    __shared__ unsigned s_ticket;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+    double acc = 0.0;
+    if (lane < 36) {
+        for (int b = wave; b < n_blocks; b += n_waves) acc += vals[36 * (size_t)b + lane];
+    } else if (lane < 42) {
+        for (int a = wave; a < N; a += n_waves) acc += rhs[6 * (size_t)a + (lane - 36)];
+    }
+    if (lane < 42) part[wv][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 42)
+        __hip_atomic_store(scratch + 42 * (size_t)blockIdx.x + threadIdx.x,
+                           ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    unsigned *ticket = reinterpret_cast<unsigned *>(scratch + 42 * (size_t)gridDim.x);
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    if (threadIdx.x < 42) {
+        double v = 0.0;
+        for (unsigned w = 0; w < gridDim.x; ++w) v += __hip_atomic_load(scratch + 42 * (size_t)w + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < 36) sA[threadIdx.x] = v; else sg[threadIdx.x - 36] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double D[36];
+#pragma unroll
+        for (int e = 0; e < 36; ++e) D[e] = 0.5 * (sA[e] + sA[6 * (e % 6) + e / 6]);        // (symmetric up to summation order: symmetrised)
+#pragma unroll
+        for (int d = 0; d < 6; ++d) D[7 * d] = D[7 * d] + lm_rel * D[7 * d];
+        double row[6];
+        inv6_row(D, (int)threadIdx.x, row);
+        double x = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x -= row[j] * sg[j];
+        const bool ok = fabs(x) < 1e6;                                                       // (NaN / a singular system: no step)
+        sxi[threadIdx.x] = ok ? x : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && xi_out) xi_out[threadIdx.x] = sxi[threadIdx.x];
+    if (threadIdx.x == 0) *ticket = 0u;                                                      // (ready for the next call)
+    bool all_ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) all_ok = all_ok && sxi[j] == sxi[j];
+    if (!all_ok) return;
+    for (int a = threadIdx.x; a < N; a += 256) apply_twist_one(node_dq + 8 * (size_t)a, sxi[0], sxi[1], sxi[2], sxi[3], sxi[4], sxi[5]);
+}
+
 __global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ node_dq, const double *__restrict__ xi, int N,
                                                            double step) {
     const int a = blockIdx.x * 256 + threadIdx.x;
@@ -3426,6 +3491,20 @@ int dfh_gn_unpack_upper(double *system, const int *row_of, const int *col, const
     const long n = (long)n_blocks * 36 + 6L * n_nodes + 2;
     hipLaunchKernelGGL(gn_unpack_upper_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, system, row_of, col, src,
                        n_blocks, 6 * n_nodes + 2, packed, n_upper);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+size_t dfh_gn_global_step_bytes(void) { return sizeof(double) * (42 * (size_t)dfh::kGlobalWgs + 2); }
+
+int dfh_gn_global_step(const double *vals, int n_blocks, const double *rhs, int n_nodes, double lm_rel, double *node_dq, double *xi_out,
+                       void *scratch, size_t scratch_bytes, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(vals && rhs && node_dq && scratch, "dfh_gn_global_step: null pointer");
+    DFH_REQUIRE(n_blocks >= 1 && n_nodes >= 1 && lm_rel >= 0.0, "dfh_gn_global_step: bad sizes / damping");
+    DFH_REQUIRE(scratch_bytes >= dfh_gn_global_step_bytes(), "dfh_gn_global_step: scratch too small (need %zu bytes, zeroed once)", dfh_gn_global_step_bytes());
+    hipLaunchKernelGGL(gn_global_step_kernel, dim3(kGlobalWgs), dim3(256), 0, (hipStream_t)stream, vals, n_blocks, rhs, n_nodes, lm_rel, node_dq,
+                       xi_out, static_cast<double *>(scratch));
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }

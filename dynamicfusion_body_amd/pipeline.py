@@ -101,6 +101,14 @@ class FrameSolver:
         self.solver.iterate_associated(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, rw, max_dist, huber,
                                        lm_abs, lm_rel, n_iters=n_iters)
 
+    def global_iteration(self, depth, lw_cam, rw=5.0, max_dist=2.0, huber=0.0, lm_rel=0.1, n_iters=1):
+        """associate -> build (+ all-reduce) -> the rigid mode alone (WarpSolver.global_step: one twist for all nodes), n_iters
+        times; asynchronous.  Cheap (a build and one small launch each) and worth several node iterations where the live frame
+        has moved as a whole: ten truncated PCG iterations hardly touch that mode."""
+        for _ in range(int(n_iters)):
+            self.solver.build_associated(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, rw, max_dist, huber)
+            self.solver.global_step(lm_rel)
+
     def solve(self, depth, lw_cam, rw=5.0, iters=10, **kw):
         costs = []
         for _ in range(iters):
@@ -117,6 +125,7 @@ class SlabFrame:
     With one rank it is the single-GPU frame."""
 
     RELAX = 0.8          # default of step(relax=...): see there
+    GLOBAL_ITERS = 2     # default of step(global_iters=...): rigid-mode steps in front of the node iterations
 
     def __init__(self, K, scale, center, res, tdist_vox, node_pos, node_w, knn=4, pcg_iters=10, band=4.0, volume_dtype=torch.float32,
                  distributed=True, solve_mode="auto"):
@@ -244,7 +253,7 @@ class SlabFrame:
         return n_new
 
     def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5, stage_ms=None,
-             update_graph=False, on_updated=None, data_views=None, relax=None):
+             update_graph=False, on_updated=None, data_views=None, relax=None, global_iters=None, global_lm=0.1):
         """Defaults (regulariser weight, LM damping, association gate and Huber threshold in voxels, the per-frame decay of the warp
         field `relax` = 0.8) are the ones under which the loop follows a +-0.6 voxel oscillation of the bench scene with a BOUNDED
         warp field: max node translation 0.85 voxel at frame 400, 1.01 at frame 1 200, sample count constant (tools/soak.py;
@@ -300,6 +309,10 @@ class SlabFrame:
         mark("live_tsdf")
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
         mark("allgather")
+        # the rigid mode first (FrameSolver.global_iteration), then the node iterations
+        ng = self.GLOBAL_ITERS if global_iters is None else int(global_iters)
+        if ng > 0:
+            self.fs.global_iteration(solve_depth, solve_lw, rw=rw, max_dist=max_dist, huber=huber, lm_rel=global_lm, n_iters=ng)
         # (one host call for the frame's iterations: nothing between them depends on the host)
         self.fs.gn_iteration(solve_depth, solve_lw, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist, huber=huber, n_iters=gn_iters)
         mark("solve")

@@ -777,6 +777,16 @@ class WarpSolver:
                                           self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, current_stream_ptr()),
                    "dfh_pcg_solve")
 
+    def global_step(self, lm_rel=0.1):
+        """The rigid mode of the last build, solved on its own and applied to every node (dfh_gn_global_step): one twist shared
+        by all nodes.  Asynchronous; the twist is left in self.global_xi (6 doubles on the device)."""
+        if getattr(self, "_global_ws", None) is None:
+            self._global_ws = torch.zeros((self.lib.dfh_gn_global_step_bytes() + 7) // 8, dtype=torch.float64, device="cuda")
+            self.global_xi = torch.zeros(6, dtype=torch.float64, device="cuda")
+        _lib.check(self.lib.dfh_gn_global_step(self.vals.data_ptr(), self.B, self.rhs.data_ptr(), self.N, float(lm_rel), self.node_dq.data_ptr(),
+                                               self.global_xi.data_ptr(), self._global_ws.data_ptr(), self._global_ws.numel() * 8,
+                                               current_stream_ptr()), "dfh_gn_global_step")
+
     def apply(self, step=1.0):
         _lib.check(self.lib.dfh_apply_twist(self.node_dq.data_ptr(), self.dx.data_ptr(), self.N, float(step),
                                             current_stream_ptr()), "dfh_apply_twist")

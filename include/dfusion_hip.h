@@ -477,6 +477,17 @@ int dfh_apply_twist(double *node_dq, const double *xi, int n_nodes, double step,
  * starts at the view count), so what the field carried is largely in the volume afterwards -- without this decay nothing ever
  * pulls a node back and the field random-walks.  No reference counterpart. */
 int dfh_relax_twists(double *node_dq, int n_nodes, double factor, void *stream);
+/* The rigid mode of a built system (dfh_gn_build*: vals, rhs), solved on its own: all nodes share ONE twist xi --
+ * (sum of all 6x6 blocks + lm_rel diag) xi = -(sum of all J^T r) -- which is applied to every node,
+ * node_dq[a] <- exp(xi) (x) node_dq[a], and written to xi_out (6 doubles, may be NULL).  Block-Jacobi PCG truncated at ten
+ * iterations hardly moves this mode (the regulariser does not penalise it, the preconditioner does not see it); the frame loop
+ * takes two such steps, each behind a build, before its node iterations (pipeline.SlabFrame.step(global_iters=...)).  The
+ * reference fits a global rigid motion first too (Fusion.solve, precompute_lw: core/fusion.py:356-365).  scratch: device
+ * memory of dfh_gn_global_step_bytes() bytes, ZEROED by the caller once (the kernel leaves it ready for the next call); sums
+ * are added in a fixed order: the same bits every run.  Restated in oracle/gn_np.global_step. */
+size_t dfh_gn_global_step_bytes(void);
+int dfh_gn_global_step(const double *vals, int n_blocks, const double *rhs, int n_nodes, double lm_rel, double *node_dq, double *xi_out,
+                       void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---- surface samples for the solve (stand-in for marching cubes, core/fusion.py:554-568) -----------
  * Every band voxel (w > 0, |T| < band; T in voxel units as fuseDepths stores it) whose TSDF gradient

@@ -357,6 +357,17 @@ def pcg_cg1(N, keys, blocks, Jtr, iters, lm_abs=0.0, lm_rel=0.0):
     return x
 
 
+def global_step(dqs, blocks, Jtr, lm_rel):
+    """The rigid mode of the normal equations solved on its own (dfh_gn_global_step, csrc/dfh_solve.hip): all nodes share ONE
+    twist xi -- (sum of all 6x6 blocks, symmetrised, + lm_rel diag) xi = -(sum of all J^T r) -- applied to every node.
+    Returns (new dqs, xi)."""
+    A = blocks.sum(axis=0)
+    A = 0.5 * (A + A.T)
+    A = A + lm_rel * np.diag(np.diag(A))
+    xi = -np.linalg.solve(A, Jtr.sum(axis=0))
+    return apply_twists(dqs, np.tile(xi, (len(dqs), 1))), xi
+
+
 def huber_scale(r, delta):
     """(sqrt of the IRLS weight per row, Huber objective sum rho(r)) -- dfh_gn_build_planned's huber_delta."""
     a = np.abs(r)
@@ -366,14 +377,16 @@ def huber_scale(r, delta):
 
 
 def gn_loop_truncated(dqs, pos, nrm, nbr, node_nbr, node_pos, node_w, lw, associate, iters, rw, lm_abs, lm_rel, huber, pcg_iters,
-                      exact=False):
+                      exact=False, global_iters=0, global_lm=0.1):
     """The shipped GN loop (pipeline.FrameSolver.gn_iteration x iters) on the CPU: per iteration associate ->
     Huber-weighted normal equations -> `pcg_iters` iterations of pcg_cg1 (exact=True: sparse direct solve) -> twist
-    update.  associate(warped_points) -> (corr, valid).  Returns (costs at every build, valid counts, final dqs)."""
+    update.  associate(warped_points) -> (corr, valid).  global_iters: that many rigid-mode steps first (associate -> the same
+    normal equations -> global_step), as pipeline.SlabFrame.step takes them.  Returns (costs at every build of the node
+    iterations, valid counts, final dqs)."""
     N = len(dqs)
     dqs = np.asarray(dqs, dtype=np.float64).copy()
     costs, counts = [], []
-    for _ in range(iters):
+    for it_ in range(global_iters + iters):
         warped = O.warp(pos, dqs[nbr], node_pos[nbr], node_w[nbr], m_lw=lw)
         corr, valid = associate(warped)
         sel = np.flatnonzero(valid)
@@ -384,6 +397,9 @@ def gn_loop_truncated(dqs, pos, nrm, nbr, node_nbr, node_pos, node_w, lw, associ
             r, J = r * sc, J * sc[:, None, None]
         rho, nb, Ji, Jj = reg_residual_jacobian(dqs, np.arange(N), node_nbr, node_pos, node_w, rw)
         keys, blocks, Jtr, _ = assemble_blocks(N, r, J, nbr[sel], rho, nb, Ji, Jj)
+        if it_ < global_iters:
+            dqs, _ = global_step(dqs, blocks, Jtr, global_lm)
+            continue
         costs.append(obj + 0.5 * float(np.sum(rho * rho)))
         counts.append(int(len(sel)))
         if exact:

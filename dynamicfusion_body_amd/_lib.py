@@ -186,6 +186,12 @@ def get_option(name):
     return int(load().dfh_get_option(name.encode()))
 
 
+def opt_on(name):
+    """True when a development switch is set (> 0).  The Python layer's own A/B switches (py_*) live in the library's option
+    table too: DFH_OPTIONS="py_no_side_stream=1" or set_option(); no call path reads the environment."""
+    return load().dfh_get_option(name.encode()) > 0
+
+
 _darr_cache = {}
 
 

@@ -32,14 +32,20 @@ class HostScalar:
     the word until the kernel's store lands -- a few microseconds after the kernel ends, where a queued device-to-host copy
     behind an event took ~30 us during which the device had nothing to do (profiles/r2_gn_experiments.txt section 6).
     Only for scalars written by ONE plain store of the launch sequence's last writer (no atomics across PCIe).
-    DFH_NO_HOST_SCALARS=1 goes back to a device scalar and .item()."""
+    Option py_no_host_scalars (read once, at the first HostScalar) goes back to a device scalar and .item()."""
     _pool = {}
-    enabled = not os.environ.get("DFH_NO_HOST_SCALARS")
+    enabled = True           # (set False by tests, or once at import by the option py_no_host_scalars -- see below the class)
+
+    _option_read = False
 
     def __init__(self, dtype=torch.int32, n=1):
         """n > 1: that many words (each written once by the launch sequence); get() then returns a tuple."""
         self._dtype, self._n = dtype, int(n)
         self._np = None
+        if not HostScalar._option_read:                # (once per process: the library's option table, not the environment)
+            HostScalar._option_read = True
+            if _lib.opt_on("py_no_host_scalars"):
+                HostScalar.enabled = False
         if HostScalar.enabled:
             free = HostScalar._pool.setdefault((dtype, self._n), [])
             self._t = free.pop() if free else torch.empty(self._n, dtype=dtype).pin_memory()

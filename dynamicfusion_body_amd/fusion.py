@@ -448,7 +448,12 @@ class Fusion:
             self._T = torch.empty((R, R, R), dtype=self._vol_dtype, device="cuda")
             self._Wt = torch.empty_like(self._T)
             self._tsdf_host = None
-            ds = [to_device(d if _is_tensor(d) else np.asarray(d), dtype=torch.float32) for d in depths]
+            # (the dtype rule of fuseDepths: float32 on the device unless a float64 map is not float32-exact -- then every map
+            # travels as float64, so that no visibility mask can flip; integrate_depth_views wants one dtype per call)
+            def exact32(d):
+                return (d.dtype == torch.float32) if _is_tensor(d) else f32_exact(np.asarray(d))
+            ddt = torch.float32 if all(exact32(d) for d in depths) else torch.float64
+            ds = [to_device(d if _is_tensor(d) else np.asarray(d), dtype=ddt) for d in depths]
             kernels.integrate_depth_views(self._T, self._Wt, ds, self._K, self._Kinv, [np.asarray(m, dtype=np.float64) for m in lws],
                                           scale, center, self._tdist, fresh=float(self._tdist))
         else:

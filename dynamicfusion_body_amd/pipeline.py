@@ -6,8 +6,6 @@ solve -> updateTSDF) with projective association in place of marching cubes + KD
 `extract_surface_samples` runs the HIP band-compaction kernels of csrc/dfh_extract.hip (the
 first "next" row of SURVEY.md §8(f)); `extract_surface_samples_torch` is the same computation on
 torch ops, kept for CPU-side tests of the sample definition."""
-import os
-
 import numpy as np
 import torch
 
@@ -295,7 +293,7 @@ class SlabFrame:
         # The solver's per-frame plan depends on the samples only and the live volume on the depth maps only: the live-volume
         # sweep (bandwidth-bound) runs on a side stream beside the plan's launches (bound by latency and atomics, with two
         # read-backs in between); the streams join before the first GN iteration.  With stage timing the order is sequential.
-        if stage_ms is None and not os.environ.get("DFH_NO_SIDE_STREAM"):
+        if stage_ms is None and not _lib.opt_on("py_no_side_stream"):
             if self._side is None:
                 self._side = torch.cuda.Stream()
             main = torch.cuda.current_stream()

@@ -8,7 +8,6 @@ hyper-parameters (`regularization_weight`, its /8 relaxation while the cost redu
 torch is used for allocation and for the once-per-frame index bookkeeping (sorting samples by
 node tuple, unique node pairs); every per-iteration step is a HIP kernel behind the C ABI.
 """
-import os
 
 import ctypes
 
@@ -277,7 +276,7 @@ class WarpSolver:
         if sort and pos.shape[0] > 0:
             # group samples with the same ordered node tuple: few runs per 256-sample tile.  The tuple is packed
             # into one int64 (base-N digits, lexicographic order preserved) so that a 1-D radix sort does it.
-            if float(self.N) ** self.knn < 2.0 ** 62 and not os.environ.get("DFH_PLAN_TORCH"):
+            if float(self.N) ** self.knn < 2.0 ** 62 and not _lib.opt_on("py_plan_torch"):
                 pos, nrm, nbr, weights = self._sort_samples_device(pos, nrm, nbr, weights)      # pack + sort + permute behind one call
             else:
                 key = self._pack_tuples(nbr)
@@ -417,7 +416,7 @@ class WarpSolver:
             self.n_upper = int(ids.numel())
         # what the multi-GPU all-reduce carries: J^T J is symmetric, only the blocks with col >= row travel (dfh_gn_pack_upper)
         self._tri = None
-        if self.distributed and (_dist.world()[1] > 1 or self.force_collective) and not os.environ.get("DFH_ALLREDUCE_FULL"):
+        if self.distributed and (_dist.world()[1] > 1 or self.force_collective) and not _lib.opt_on("py_allreduce_full"):
             upper = self.col >= rows
             up_rank = (torch.cumsum(upper.to(torch.int64), 0) - 1)
             mkey = self.col.to(torch.int64) * N + rows.to(torch.int64)
@@ -439,7 +438,7 @@ class WarpSolver:
         The data plan is built on the device (dfh_gn_plan_count / dfh_gn_plan_build: run scan, block look-up, two radix
         sorts); `keys` must be the pattern row_ptr / col describe.  Returns whether every node pair of every row is a
         block of the pattern (always True when reg=True: that call follows a pattern build)."""
-        if self.S == 0 or self._tuple_key is None or os.environ.get("DFH_PLAN_TORCH"):
+        if self.S == 0 or self._tuple_key is None or _lib.opt_on("py_plan_torch"):
             return self._build_plan_torch(keys, reg)
         N, k, S, dev = self.N, self.knn, self.S, "cuda"
         tile = int(self.lib.dfh_gn_tile_samples())
@@ -636,7 +635,7 @@ class WarpSolver:
         # not, so exactly one rank adds them before the all-reduce
         reg_here = (not self.distributed) or _dist.world()[0] == 0
         nn = 0 if (self.node_nbr is None or rw == 0.0 or not reg_here) else self.node_nbr.data_ptr()
-        if os.environ.get("DFH_GN_ATOMIC"):          # the atomics-based build (no plan needed), kept for A/B comparison
+        if _lib.opt_on("py_gn_atomic"):          # the atomics-based build (no plan needed), kept for A/B comparison
             _lib.check(self.lib.dfh_gn_build(self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(),
                                              self.corr.data_ptr(), self.valid.data_ptr(), self.S, self.knn,
                                              self.node_dq.data_ptr(), self.node_pos.data_ptr(), self.node_w.data_ptr(), nn, self.N,
@@ -664,7 +663,7 @@ class WarpSolver:
         depth, lw_cam, many = self._one_or_many(depth, lw_cam)
         d0 = depth[0] if many else depth
         fused = (isinstance(d0, torch.Tensor) and d0.is_cuda and d0.dim() == 2 and d0.is_contiguous() and
-                 d0.dtype == torch.float32 and self.S > 0 and not os.environ.get("DFH_GN_ATOMIC") and not os.environ.get("DFH_GN_NO_FUSED_ASSOC"))
+                 d0.dtype == torch.float32 and self.S > 0 and not _lib.opt_on("py_gn_atomic") and not _lib.opt_on("py_gn_no_fused_assoc"))
         if not fused:
             self.associate_depth(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, max_dist)
             return self.build(lw_dq, rw, huber)
@@ -707,15 +706,15 @@ class WarpSolver:
         """n_iters GN iterations: build_associated + solve_update each.  On one GPU (no all-reduce between the halves) they
         are ONE call, dfh_gn_iteration_views (the views' table holds one or several depth maps): the iterations are queued
         back to back without returning to Python, and in each the clearing of the solve's workspace rides in the data-row
-        launch -- the same bits as separate calls.  DFH_GN_ITER_PER_CALL=1: one dfh_gn_iteration call per iteration (single
+        launch -- the same bits as separate calls.  option py_gn_iter_per_call: one dfh_gn_iteration call per iteration (single
         view), as before round 3."""
         if self._pattern is None:
             self._build_pattern()
         depth, lw_cam, many = self._one_or_many(depth, lw_cam)
         d0 = depth[0] if many else depth
         one_call = (isinstance(d0, torch.Tensor) and d0.is_cuda and d0.dim() == 2 and d0.is_contiguous() and
-                    d0.dtype == torch.float32 and self.S > 0 and not os.environ.get("DFH_GN_ATOMIC") and
-                    not os.environ.get("DFH_GN_NO_FUSED_ASSOC") and not os.environ.get("DFH_GN_NO_FUSED_ITER") and
+                    d0.dtype == torch.float32 and self.S > 0 and not _lib.opt_on("py_gn_atomic") and
+                    not _lib.opt_on("py_gn_no_fused_assoc") and not _lib.opt_on("py_gn_no_fused_iter") and
                     not (self.distributed and (_dist.world()[1] > 1 or self.force_collective)))
         if not one_call:
             for _ in range(int(n_iters)):
@@ -733,7 +732,7 @@ class WarpSolver:
                                               if self.partial_reg is not None else (0, 0, 0, 0, 0)),
                   float(huber))
         tail = (self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(), self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, 1.0)
-        if not many and os.environ.get("DFH_GN_ITER_PER_CALL"):
+        if not many and _lib.opt_on("py_gn_iter_per_call"):
             H, W = depth.shape
             for _ in range(int(n_iters)):
                 _lib.check(self.lib.dfh_gn_iteration(

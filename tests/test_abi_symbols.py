@@ -50,6 +50,9 @@ def test_no_oracle_in_product():
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert not re.search(r"import\s+c?KDTree|scipy\.spatial", txt), f
+    # the Python layer's A/B switches are options of the library too (py_*): its call paths read no environment variable
+    for f in ("solve.py", "pipeline.py", "device.py", "kernels.py", "fusion.py", "fusion_dm.py", "graph.py", "mesh.py"):
+        assert "os.environ" not in open(os.path.join(pkg, f)).read(), f
     n_getenv = 0
     csrc = os.path.join(pkg, "csrc")
     for f in os.listdir(csrc):

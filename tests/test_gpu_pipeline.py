@@ -241,15 +241,14 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
         frames.append([torch.from_numpy(scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0, sphere_offset=off)).cuda() for lw in lws])
 
     def run(env, timed, data_views=None):
-        for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX", "DFH_GN_NO_FUSED_ITER", "DFH_GN_ITER_PER_CALL"):
-            monkeypatch.delenv(k, raising=False)
         monkeypatch.setattr(HostScalar, "enabled", "NO_HOST_SCALARS" not in env)
         from dynamicfusion_body_amd import _lib
-        _lib.set_option("plan_radix", 1 if "DFH_PLAN_RADIX" in env else None)        # (switches of the library; the others are Python's)
+        # every switch lives in the library's option table (dfh_set_option): the C side's and the Python layer's (py_*)
+        _lib.set_option("plan_radix", 1 if "DFH_PLAN_RADIX" in env else None)
         _lib.set_option("gn_gather_full", 1 if "GN_GATHER_FULL" in env else None)    # every block's list walked (default: column >= row, sums stored twice)
-        for k in env:
-            if k.startswith("DFH_"):
-                monkeypatch.setenv(k, "1")
+        _lib.set_option("py_no_side_stream", 1 if "DFH_NO_SIDE_STREAM" in env else None)
+        _lib.set_option("py_gn_no_fused_iter", 1 if "DFH_GN_NO_FUSED_ITER" in env else None)
+        _lib.set_option("py_gn_iter_per_call", 1 if "DFH_GN_ITER_PER_CALL" in env else None)
         sf = SlabFrame(K, scale, center, R, tdist / scale, node_pos, node_w, knn=4, pcg_iters=10, band=2.0, distributed=False)
         for d, lw in zip(first, lws):
             sf.integrate(d, lw)
@@ -273,8 +272,6 @@ def test_frame_loop_variants_give_the_same_bits(monkeypatch):
     for a, b in zip(got1[1:], ref1[1:]):
         assert torch.equal(a, b)
     assert not torch.equal(ref1[1], ref[1])
-    for k in ("DFH_NO_SIDE_STREAM", "DFH_PLAN_RADIX", "DFH_GN_NO_FUSED_ITER", "DFH_GN_ITER_PER_CALL"):
-        monkeypatch.delenv(k, raising=False)
 
 
 def test_association_inside_the_build_is_bit_identical(monkeypatch):
@@ -293,10 +290,8 @@ def test_association_inside_the_build_is_bit_identical(monkeypatch):
     dq1 = G.apply_twists(ident, rng.normal(scale=[3e-3] * 3 + [0.2] * 3, size=(N, 6)))
     out = {}
     for mode in ("fused", "separate"):
-        if mode == "separate":
-            monkeypatch.setenv("DFH_GN_NO_FUSED_ASSOC", "1")
-        else:
-            monkeypatch.delenv("DFH_GN_NO_FUSED_ASSOC", raising=False)
+        from dynamicfusion_body_amd import _lib
+        _lib.set_option("py_gn_no_fused_assoc", 1 if mode == "separate" else None)
         fs = FrameSolver(K, scale, center, R / 2, knn=k, pcg_iters=10, distributed=False)
         fs.set_graph(node_pos, ident, node_w)
         fs.set_canonical(T, Wt, band=2.0)
@@ -314,7 +309,6 @@ def test_association_inside_the_build_is_bit_identical(monkeypatch):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert out["fused"][1] == out["separate"][1] and torch.equal(out["fused"][2], out["separate"][2])
-    monkeypatch.delenv("DFH_GN_NO_FUSED_ASSOC", raising=False)
 
 
 def test_soak_300_frames():

@@ -369,7 +369,7 @@ def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, mon
     g, verts, norms, corr, nbr, vidx, npos, ndq, nw, lw, rw = load(golden)
     rng = np.random.default_rng(3)
     valid = (rng.random(len(verts)) < 0.7).astype(np.uint8)
-    monkeypatch.delenv("DFH_GN_ATOMIC", raising=False)
+    _lib.set_option("py_gn_atomic", None)
     sv = make_solver(npos, ndq, nw, nbr, vidx, verts, norms, corr, nbr.shape[1], pcg_iters=5, valid=valid)
     sv.build(lw, rw)
     s1 = sv.system.clone()
@@ -383,12 +383,12 @@ def test_planned_build_is_deterministic_and_matches_the_atomic_build(golden, mon
         _lib.set_option(switch, None)
     sv.build(lw, 0.0)                                   # without the regulariser rows
     s0 = sv.system.clone()
-    monkeypatch.setenv("DFH_GN_ATOMIC", "1")
+    _lib.set_option("py_gn_atomic", 1)
     sv.build(lw, rw)
     sa = sv.system.clone()
     sv.build(lw, 0.0)
     sa0 = sv.system.clone()
-    monkeypatch.delenv("DFH_GN_ATOMIC", raising=False)
+    _lib.set_option("py_gn_atomic", None)
     for p_, a_ in ((s1, sa), (s0, sa0)):
         assert float((p_ - a_).abs().max()) <= 1e-12 * float(a_.abs().max())
         assert p_[-1] == a_[-1] and p_[-1] == float(valid.sum())          # valid-sample count
@@ -408,10 +408,7 @@ def test_device_plan_builder_equals_the_torch_plan(monkeypatch):
         node_nbr, _ = solve.sample_knn(npos, npos, nw, k)
         plans = {}
         for mode in ("device", "torch"):
-            if mode == "torch":
-                monkeypatch.setenv("DFH_PLAN_TORCH", "1")
-            else:
-                monkeypatch.delenv("DFH_PLAN_TORCH", raising=False)
+            _lib.set_option("py_plan_torch", 1 if mode == "torch" else None)
             sv = solve.WarpSolver(knn=k, pcg_iters=5, distributed=False)
             sv.set_graph(npos, ndq, nw, node_nbr=node_nbr)
             sv.set_samples(pts, nrm)
@@ -428,15 +425,12 @@ def test_device_plan_builder_equals_the_torch_plan(monkeypatch):
         # a second sample set against the kept pattern: covered or not, both builders must agree on the verdict and the result
         pts2 = rng.uniform(0, 60, size=(S // 2 + 3, 3))
         for sv in (a, b):
-            if sv is b:
-                monkeypatch.setenv("DFH_PLAN_TORCH", "1")
-            else:
-                monkeypatch.delenv("DFH_PLAN_TORCH", raising=False)
+            _lib.set_option("py_plan_torch", 1 if sv is b else None)
             sv.set_samples(pts2, rng.normal(size=pts2.shape) * 0 + 1.0)
             sv.set_correspondences(pts2 + 0.1)
             sv.build(np.array([1.0, 0, 0, 0, 0, 0, 0, 0]), 0.5)
         assert a.B == b.B and torch.equal(a.col, b.col) and torch.equal(a.blk_ent, b.blk_ent) and torch.equal(a.vals, b.vals)
-    monkeypatch.delenv("DFH_PLAN_TORCH", raising=False)
+    _lib.set_option("py_plan_torch", None)
 
 
 def test_block_pattern_kept_across_sample_sets(golden):

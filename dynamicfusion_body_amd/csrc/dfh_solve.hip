@@ -2108,7 +2108,8 @@ __device__ unsigned long long g_pcg_trace[64][16][12];
 // Returns NaN totals when the wait was given up.
 template <class R, class H>
 __device__ __forceinline__ void grid_sum2(double *slots, const PcgAbort &ab, BarrierLds2 *lds, double v0, double v1 /* wave-uniform */,
-                                          double *s0, double *s1, bool fetch, R &&request, H &&here, unsigned long long *tr = nullptr) {
+                                          double *s0, double *s1, bool fetch, R &&request, H &&here, int blk, int nblk,
+                                          unsigned long long *tr = nullptr) {
     // fetch: the wave also wants its neighbours' published values: request() issues the loads, here() says whether the
     // last request found them all (wave-uniform).  Every wave keeps asking while the reduction is in flight, so the
     // values and the totals are usually both there one load latency after the slowest workgroup's stores land.
@@ -2122,14 +2123,14 @@ __device__ __forceinline__ void grid_sum2(double *slots, const PcgAbort &ab, Bar
     if (wave == 0 && lane < 2) {
         double v = 0.0;
         for (int w = 0; w < waves; ++w) v += lds->wave_part[lane][w];
-        st_agent(slots + 2 * blockIdx.x + lane, nz_bits(v));
+        st_agent(slots + 2 * blk + lane, nz_bits(v));
     }
     bool have = !fetch;
     GS_STAMP(6);
     unsigned spins = 0;
     if (kPollDelay > 0) __builtin_amdgcn_s_sleep(kPollDelay);   // nothing can have arrived yet
     if (wave == 0) {
-        const int nb = (int)gridDim.x;                  // lane l adds workgroups l, l + 64, ...
+        const int nb = nblk;                            // lane l adds workgroups l, l + 64, ...
         double t0 = 0.0, t1 = 0.0;
         for (;;) {
             bool all = true;
@@ -2183,7 +2184,15 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
                                                         const double *__restrict__ rhs, const PcgParams prm, int iters,
                                                         double *__restrict__ x, double *ring /* 4 x {u, v, t} x 6N */, double *part,
                                                         unsigned *abort_flag, unsigned spin_limit, unsigned long long *abort_count,
-                                                        unsigned *abort_host, double *__restrict__ update_dq, double update_step) {
+                                                        unsigned *abort_host, double *__restrict__ update_dq, double update_step,
+                                                        int die_stride) {
+    // die_stride > 1 (experiment, option pcg_one_xcd): the grid is die_stride times too large and only the workgroups whose index
+    // is a multiple of it work -- with round-robin dispatch over the eight XCDs (stride 8) they all sit on ONE die; the others leave
+    if (die_stride > 1 && (blockIdx.x % die_stride) != 0) return;
+    const int blk = die_stride > 1 ? (int)blockIdx.x / die_stride : (int)blockIdx.x;
+    const int nblk = die_stride > 1 ? (int)gridDim.x / die_stride : (int)gridDim.x;
+    if (die_stride > 1 && threadIdx.x == 0)                                     // which dies really took part (bit = XCC_ID): flag[3]
+        atomicOr(abort_flag + 3, 1u << (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15));
     // update_dq != NULL: the row's wave also applies its twist, update_dq[a] <- exp(update_step * x_a) (x) update_dq[a]
     // abort_count is read by dfh_pcg_status() at the caller's next synchronisation point
     __shared__ BarrierLds2 lds;
@@ -2193,7 +2202,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
     const size_t N6 = 6 * (size_t)N;
     const int lane = threadIdx.x & 63;
     const int waves = blockDim.x >> 6;
-    const int a = blockIdx.x * waves + (threadIdx.x >> 6);
+    const int a = blk * waves + (threadIdx.x >> 6);
     const bool row = a < N;
     const int slot = lane / 6, i = lane - 6 * slot;            // lanes 60..63 idle in the SpMV
     const int beg = row ? row_ptr[a] : 0, end = row ? row_ptr[a + 1] : 0;
@@ -2374,7 +2383,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
         const double *cur = region(it);
         const bool last = it == iters - 1;
         PCG_STAMP(0);
-        grid_sum2(part + (size_t)it * 2 * gridDim.x, ab, &lds, g, d, &gamma, &delta, !last, [&]() { request(cur, true); }, all_here
+        grid_sum2(part + (size_t)it * 2 * nblk, ab, &lds, g, d, &gamma, &delta, !last, [&]() { request(cur, true); }, all_here, blk, nblk
 #ifdef DFH_PCG_TRACE
                   , tw >= 0 && it < 16 ? &g_pcg_trace[tw][it][0] : nullptr
 #endif
@@ -2436,7 +2445,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(const int *__restrict__ r
     if (threadIdx.x == 0)
         s_ticket = __hip_atomic_fetch_add(abort_flag + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // release: after the x stores
     __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
+    if (s_ticket != (unsigned)nblk - 1u) return;
     bool bad = ab.raised();
     for (int r = (int)threadIdx.x; r < 6 * N; r += (int)blockDim.x) {
         const double v = ld_agent(x + r);
@@ -3266,6 +3275,14 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
     int dev = 0, wpb = 8, nblk = 1;
     bool persistent = false;
     { const int rc = pcg_shape(n_nodes, &dev, &wpb, &nblk, &persistent); if (rc != DFH_OK) return rc; }
+    // experiment (option pcg_one_xcd = the stride, 8 on MI355X): every working workgroup on one die, 16-wave workgroups so that
+    // up to 1 024 rows fit its 32 CUs two per CU.  Measured (profiles/r4_pcg_one_xcd.txt) -- not the default.
+    int die_stride = 1;
+    if (persistent && opt().pcg_one_xcd > 1 && n_nodes <= 1024) {
+        die_stride = (int)opt().pcg_one_xcd;
+        wpb = 16;
+        nblk = (n_nodes + wpb - 1) / wpb;
+    }
     unsigned long long *abort_count = nullptr;
     if (persistent) {
         if (dev >= 0 && dev < 64 && g_abort_count[dev]) {
@@ -3294,11 +3311,11 @@ static int pcg_solve_impl(const int *row_ptr, const int *col, double *vals, cons
         unsigned *flag = reinterpret_cast<unsigned *>(scal + 3 * ((size_t)iters + 1));    // spare scalar: abort flag
         double *part = scal + 3 * ((size_t)iters + 2);                                    // (2 per iteration + 1) reductions x nblk slots
         if (wpb <= 8)
-            hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, ring, part,
-                               flag, spin_limit, abort_count, abort_host, update_dq, update_step);
+            hipLaunchKernelGGL(pcg_cg1_kernel<512>, dim3(nblk * die_stride), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, ring, part,
+                               flag, spin_limit, abort_count, abort_host, update_dq, update_step, die_stride);
         else
-            hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, ring, part,
-                               flag, spin_limit, abort_count, abort_host, update_dq, update_step);
+            hipLaunchKernelGGL(pcg_cg1_kernel<1024>, dim3(nblk * die_stride), dim3(64 * wpb), 0, s, row_ptr, col, vals, rhs, p, iters, x_out, ring, part,
+                               flag, spin_limit, abort_count, abort_host, update_dq, update_step, die_stride);
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;
     }

@@ -50,7 +50,8 @@ for iters in (1, 2, 5, 10, 20, 40):
     sv.check_status()
     us = e0.elapsed_time(e1) * 1e3 / reps
     res.append((iters, us))
-    print("iters %3d: %.1f us per solve (memset + kernel), |x| %.6e" % (iters, us, float(sv.dx.norm())))
+    dies = int(sv.pcg_ws.view(torch.int32)[2 * (66 * sv.N + 3 * (iters + 1)) + 3])      # (option pcg_one_xcd: bit = XCC_ID of a die that took part)
+    print("iters %3d: %.1f us per solve (memset + kernel), |x| %.6e%s" % (iters, us, float(sv.dx.norm()), "  dies 0x%x" % dies if dies else ""))
 (i0, t0), (i1, t1) = res[2], res[-1]
 print("slope %.2f us per iteration, intercept %.1f us" % ((t1 - t0) / (i1 - i0), t0 - i0 * (t1 - t0) / (i1 - i0)))
 if hasattr(sv.lib, "dfh_debug_pcg_trace") or os.environ.get("DFH_LIB_PATH"):

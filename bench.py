@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-frame", action="store_true", help="skip the end-to-end per-frame leg")
     ap.add_argument("--no-frame-512", action="store_true", help="skip the config-5-size frame leg (512^3, 8 views, 2 048 nodes; 1 GPU only)")
     ap.add_argument("--gn-nodes", type=int, default=512)
+    ap.add_argument("--global-iters", type=int, default=None, help="frame legs: rigid-mode steps in front of the node iterations (default: SlabFrame's)")
     ap.add_argument("--gn-mode", default="auto", choices=("auto", "sharded", "replicated"), help="N > 1: how the warp solve runs")
     ap.add_argument("--gn-solves", type=int, default=5, help="timed solves of 10 GN iterations each")
     return ap.parse_args()
@@ -311,7 +312,7 @@ def frame_leg(args, torch, dist, scene, rank, world, barrier, nframes=8, with_k2
                 mesh_stream.wait_event(sf.updated)
                 pending.append(mesh.marching_cubes_begin(sf.T, 0.0))
         info["samples"] = sf.step(depths[f], lw_cam, gn_iters=iters, stage_ms=stages if timed else None,
-                                  on_updated=None if (timed or mesh_stream is None) else start_mesh)
+                                  on_updated=None if (timed or mesh_stream is None) else start_mesh, global_iters=args.global_iters)
         if world == 1:
             t1 = _t.perf_counter()
             if timed:

@@ -88,6 +88,11 @@ _SIGNATURES = {
                                       _vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _dbl, _vp, _int, _int, _int, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl,
                                       _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _dbl, _int, _vp, _int, _vp]),
+    "dfh_gn_frame_solve_views": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _c_double_p, _dbl,
+                                      _vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _dbl, _vp, _int, _int, _int, _c_double_p, _c_double_p, _dbl, _c_double_p, _dbl, _dbl,
+                                      _int, _dbl, _dbl, _vp, _vp, ctypes.c_size_t, _dbl, _int, _vp, _int,
+                                      _int, _dbl, _vp, _vp, ctypes.c_size_t, _vp]),
     "dfh_gn_pack_upper": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "dfh_gn_unpack_upper": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "dfh_gn_sort_workspace_bytes": (ctypes.c_size_t, [_int]),
@@ -106,6 +111,10 @@ _SIGNATURES = {
     "dfh_pcg_status_peek": (_int, [_vp, ctypes.POINTER(ctypes.c_long)]),
     "dfh_apply_twist": (_int, [_vp, _vp, _int, _dbl, _vp]),
     "dfh_relax_twists": (_int, [_vp, _int, _dbl, _vp]),
+    "dfh_gn_global_sampled_bytes": (ctypes.c_size_t, [_int, _int]),
+    "dfh_gn_global_sampled_views": (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp, _int, _c_double_p, _dbl, _vp, _int, _int, _int, _c_double_p,
+                                           _c_double_p, _dbl, _c_double_p, _dbl, _dbl, _int, _dbl, _int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dfh_gn_global_apply": (_int, [_vp, _dbl, _int, _vp, _vp, _vp]),
     "dfh_gn_global_step_bytes": (ctypes.c_size_t, []),
     "dfh_gn_global_step": (_int, [_vp, _int, _vp, _int, _dbl, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "dfh_surface_workspace_bytes": (ctypes.c_size_t, [_c_int_p]),

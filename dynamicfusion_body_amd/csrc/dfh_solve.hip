@@ -20,6 +20,7 @@
 // so the contraction stays on the VALU (BASELINE north_star: "MFMA only if ...").
 #include "dfh_dq.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -2562,6 +2563,141 @@ __global__ __launch_bounds__(256) void gn_global_step_kernel(const double *__res
     for (int a = threadIdx.x; a < N; a += 256) apply_twist_one(node_dq + 8 * (size_t)a, sxi[0], sxi[1], sxi[2], sxi[3], sxi[4], sxi[5]);
 }
 
+// The rigid mode from a SUBSAMPLE of the data rows, without building the block system (round 4): for a twist shared by all
+// nodes a sample's Jacobian is the sum of its k node blocks, J_g = sum_a J_a (6 entries), so A_g = sum_s J_g^T J_g and
+// g_g = sum_s J_g^T r need neither runs nor a gather.  Every `stride`-th 128-sample tile (the samples are sorted by node tuple:
+// a uniform thinning of the surface) is associated and differentiated exactly as in gn_build_data_kernel (same Huber weights);
+// the regulariser is left out (a common left twist rotates every regulariser residual rigidly: it only damps this mode).  Per
+// tile 21 + 6 sums (+ objective, count) in a fixed order; gn_global_reduce_kernel adds the tiles' partials in index order,
+// gn_global_apply_kernel damps, solves by Cholesky and applies the twist to every node (sharded samples: an all-reduce of the
+// 29 sums goes between the two).  A rigid-mode step costs ~35 us instead of a full build +
+// gather + dfh_gn_global_step (0.4 ms at config 5).  Restated in oracle/gn_np.global_step_sampled.
+constexpr int kGlobalVals = 29;                     // 21 upper entries of A_g | 6 of g_g | objective | valid count
+constexpr int kGlobalGrid = 1024;                   // workgroups of the rows kernel = partial sets (fixed: the summation order must not follow the device)
+template <int K>
+__global__ __launch_bounds__(kTile) void gn_global_rows_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
+                                                              const int *__restrict__ nbr, const double *__restrict__ wts,
+                                                              const double *__restrict__ node_dq, const BuildParams p, int stride, long n_sub,
+                                                              double *__restrict__ tile_part, const AssocArgs aa) {
+    __shared__ double sPart[kTileWaves][kGlobalVals];
+    const int tid = threadIdx.x;
+    double acc[kGlobalVals];
+#pragma unroll
+    for (int e = 0; e < kGlobalVals; ++e) acc[e] = 0.0;
+    // a workgroup walks the tiles blockIdx.x, + gridDim.x, ... of the thinned list and keeps its sums in registers: at most
+    // kGlobalGrid partial sets for the reduce kernel (one set per TILE made that kernel's serial adds the whole step: 1.3 ms)
+    for (long sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
+    const long s = sub * stride * kTile + tid;
+    if (s < p.S) {
+        int idx[kKMaxS];
+        double w[kKMaxS];
+#pragma unroll
+        for (int j = 0; j < kKMaxS; ++j) {
+            idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
+            w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
+        }
+        double bh[8];
+        const double nb = blend_static(node_dq, idx, w, K, bh);
+        const double pfx = round_f32(spos[3 * (size_t)s]), pfy = round_f32(spos[3 * (size_t)s + 1]), pfz = round_f32(spos[3 * (size_t)s + 2]);
+        const D3 x1 = dqb_warp_exact(bh, pfx, pfy, pfz);
+        const D3 xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
+        double c[3];
+        const bool ok = aa.views ? associate_views<float>(aa.ap, aa.views, aa.n_views, xp, c) : associate_point<float>(aa.ap, aa.depth, xp, c);
+        if (ok) {
+            double Jrow[6 * K];
+            double r = data_row_from(node_dq, idx, w, K, p.lw.q, bh, nb, pfx, pfy, pfz, xp, snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1],
+                                     snrm[3 * (size_t)s + 2], c[0], c[1], c[2], Jrow);
+            double obj = 0.5 * r * r, sc = 1.0;
+            if (p.huber > 0.0 && fabs(r) > p.huber) {
+                obj = p.huber * (fabs(r) - 0.5 * p.huber);
+                sc = sqrt(p.huber / fabs(r));
+            }
+            r *= sc;
+            double jg[6];
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) {
+                double v = 0.0;
+#pragma unroll
+                for (int a = 0; a < K; ++a) v += Jrow[6 * a + c6];
+                jg[c6] = v * sc;
+            }
+            int e = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) { acc[e] += jg[i] * jg[j]; ++e; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[21 + i] += jg[i] * r;
+            acc[27] += obj;
+            acc[28] += 1.0;
+        }
+    }
+    }
+#pragma unroll
+    for (int e = 0; e < kGlobalVals; ++e) {
+        double v = acc[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((tid & 63) == 0) sPart[tid >> 6][e] = v;
+    }
+    __syncthreads();
+    if (tid < kGlobalVals) {
+        double v = sPart[0][tid];
+#pragma unroll
+        for (int w_ = 1; w_ < kTileWaves; ++w_) v += sPart[w_][tid];
+        tile_part[(size_t)blockIdx.x * kGlobalVals + tid] = v;
+    }
+}
+
+// the tiles' partials added in index order (eight chunks of consecutive tiles, then the chunks): 29 sums
+__global__ __launch_bounds__(256) void gn_global_reduce_kernel(const double *__restrict__ tile_part, int n_tiles, double *__restrict__ sums) {
+    __shared__ double part[8][32];
+    const int e = threadIdx.x & 31, chunk = threadIdx.x >> 5;
+    const int per = (n_tiles + 7) / 8;
+    double v = 0.0;
+    if (e < kGlobalVals)
+        for (int t = chunk * per; t < min(n_tiles, (chunk + 1) * per); ++t) v += tile_part[(size_t)t * kGlobalVals + e];
+    part[chunk][e] = v;
+    __syncthreads();
+    if (threadIdx.x < kGlobalVals) {
+        double a = part[0][threadIdx.x];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) a += part[c][threadIdx.x];
+        sums[threadIdx.x] = a;
+    }
+}
+
+// (A_g + lm diag A_g) xi = -g_g from the 29 sums (after an all-reduce over ranks, where the samples are sharded), xi to every node
+__global__ __launch_bounds__(256) void gn_global_apply_kernel(const double *__restrict__ sums, double lm_rel, int N, double *__restrict__ node_dq,
+                                                               double *__restrict__ xi_out /* 6 | objective, count */) {
+    __shared__ double sv[kGlobalVals], sxi[6];
+    if (threadIdx.x < kGlobalVals) sv[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double D[36];
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) { D[6 * i + j] = sv[q]; D[6 * j + i] = sv[q]; ++q; }
+#pragma unroll
+        for (int d = 0; d < 6; ++d) D[7 * d] = D[7 * d] + lm_rel * D[7 * d];
+        double row[6];
+        inv6_row(D, (int)threadIdx.x, row);
+        double x = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x -= row[j] * sv[21 + j];
+        sxi[threadIdx.x] = (fabs(x) < 1e6 && sv[28] >= 6.0) ? x : 0.0;             // (NaN, a singular system, hardly any data: no step)
+    }
+    __syncthreads();
+    if (xi_out) {
+        if (threadIdx.x < 6) xi_out[threadIdx.x] = sxi[threadIdx.x];
+        if (threadIdx.x == 6) xi_out[6] = sv[27];
+        if (threadIdx.x == 7) xi_out[7] = sv[28];
+    }
+    for (int a = threadIdx.x; a < N; a += 256) apply_twist_one(node_dq + 8 * (size_t)a, sxi[0], sxi[1], sxi[2], sxi[3], sxi[4], sxi[5]);
+}
+
 __global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ node_dq, const double *__restrict__ xi, int N,
                                                            double step) {
     const int a = blockIdx.x * 256 + threadIdx.x;
@@ -3458,6 +3594,51 @@ int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, c
     return DFH_OK;
 }
 
+// A frame's whole solve behind one call (round 4): n_global rigid-mode steps (build + dfh_gn_global_step each), then n_iters
+// node iterations (dfh_gn_iteration_views).  The same launches in the same order as the separate calls: the same bits; what it
+// saves is the host's way through the binding, twice per rigid-mode step.
+int dfh_gn_frame_solve_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                     double *corr_out, unsigned char *valid_out, int n_samples, int knn, double *node_dq,
+                     const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                     const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                     double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                     const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                     const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                     const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
+                     double scale, const double center[3], double half, double max_dist,
+                     int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
+                     double step, int n_iters, const int *blk_upper, int n_upper,
+                     int n_global, double global_lm, double *global_xi_out, void *global_scratch, size_t global_scratch_bytes, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(views && n_views >= 1 && n_views <= DFH_GN_MAX_VIEWS, "dfh_gn_frame_solve_views: needs 1..%d packed views", DFH_GN_MAX_VIEWS);
+    DFH_REQUIRE(n_global >= 0 && n_global <= 100, "dfh_gn_frame_solve_views: %d rigid-mode steps", n_global);
+    if (n_global > 0) {
+        DFH_REQUIRE(blk_ptr && K && Kinv && center && lw_dq && corr_out && valid_out && node_dq, "dfh_gn_frame_solve_views: null pointer");
+        DFH_REQUIRE(H >= 2 && W >= 2 && scale != 0.0, "dfh_gn_frame_solve_views: bad depth map / scale");
+        AssocArgs aa;
+        int rc = fill_assoc_params(aa.ap, lw_dq, H, W, K, Kinv, kIdentity34, scale, center, half, max_dist, knn);
+        if (rc != DFH_OK) return rc;
+        aa.depth = nullptr;
+        aa.views = static_cast<const AssocView *>(views);
+        aa.n_views = n_views;
+        aa.cull = n_views >= 4 && !on(opt().gn_no_view_cull) ? 1 : 0;
+        for (int g = 0; g < n_global; ++g) {
+            rc = gn_build_impl(sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
+                               n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr,
+                               blk_ent, node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, stream, &aa,
+                               nullptr, 0, nullptr, blk_upper, n_upper);
+            if (rc != DFH_OK) return rc;
+            rc = dfh_gn_global_step(vals, n_blocks, rhs, n_nodes, global_lm, node_dq, global_xi_out, global_scratch, global_scratch_bytes, stream);
+            if (rc != DFH_OK) return rc;
+        }
+    }
+    return dfh_gn_iteration_views(sample_pos, sample_nrm, nbr, weights, corr_out, valid_out, n_samples, knn, node_dq, node_pos, node_w, node_nbr,
+                                  n_nodes, lw_dq, rw, row_ptr, col, n_blocks, vals, rhs, cost_count, run_id, n_rows, partial, blk_ptr, blk_ent,
+                                  node_ptr, node_ent, partial_reg, rblk_ptr, rblk_ent, rnode_ptr, rnode_ent, huber_delta, views, n_views, H, W,
+                                  K, Kinv, scale, center, half, max_dist, pcg_iters, lm_abs, lm_rel, x_out, pcg_workspace, pcg_workspace_bytes,
+                                  step, n_iters, blk_upper, n_upper, stream);
+}
+
 // J^T J is symmetric: block (b, a) is the transpose of block (a, b).  Between ranks only the blocks with col >= row travel
 // (about half of `vals`), followed by J^T r and {cost, count}; `src[b]` = index among the travelling blocks of the one that
 // holds block b's data (its own, or its mirror's for col < row).  One launch each way, a thread per double.
@@ -3522,6 +3703,62 @@ int dfh_gn_global_step(const double *vals, int n_blocks, const double *rhs, int 
     DFH_REQUIRE(scratch_bytes >= dfh_gn_global_step_bytes(), "dfh_gn_global_step: scratch too small (need %zu bytes, zeroed once)", dfh_gn_global_step_bytes());
     hipLaunchKernelGGL(gn_global_step_kernel, dim3(kGlobalWgs), dim3(256), 0, (hipStream_t)stream, vals, n_blocks, rhs, n_nodes, lm_rel, node_dq,
                        xi_out, static_cast<double *>(scratch));
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+size_t dfh_gn_global_sampled_bytes(int n_samples, int stride) {
+    if (n_samples < 0 || stride < 1) return 0;
+    const long n_tiles = (n_samples + dfh::kTile - 1) / dfh::kTile;
+    (void)n_tiles;
+    return sizeof(double) * ((size_t)dfh::kGlobalVals * dfh::kGlobalGrid + 32);                                // workgroup partials | the 29 sums
+}
+
+int dfh_gn_global_apply(const double *sums29, double lm_rel, int n_nodes, double *node_dq, double *xi_out, void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(sums29 && node_dq && n_nodes >= 1 && lm_rel >= 0.0, "dfh_gn_global_apply: bad arguments");
+    hipLaunchKernelGGL(gn_global_apply_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums29, lm_rel, n_nodes, node_dq, xi_out);
+    DFH_HIP_CHECK(hipGetLastError());
+    return DFH_OK;
+}
+
+int dfh_gn_global_sampled_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights, int n_samples, int knn,
+                                double *node_dq, int n_nodes, const double lw_dq[8], double huber_delta, const void *views, int n_views, int H, int W,
+                                const double K[9], const double Kinv[9], double scale, const double center[3], double half, double max_dist,
+                                int stride, double lm_rel, int n_steps, double *xi_out, double *sums_out, void *scratch, size_t scratch_bytes,
+                                void *stream) {
+    using namespace dfh;
+    DFH_REQUIRE(n_steps >= 0 && n_steps <= 100 && stride >= 1, "dfh_gn_global_sampled_views: %d steps, stride %d", n_steps, stride);
+    if (n_steps == 0) return DFH_OK;
+    DFH_REQUIRE(n_samples >= 0 && node_dq && lw_dq && views && K && Kinv && center && scratch, "dfh_gn_global_sampled_views: null pointer");
+    DFH_REQUIRE(n_samples == 0 || (sample_pos && sample_nrm && nbr && weights), "dfh_gn_global_sampled_views: null sample array");
+    DFH_REQUIRE(knn == 4, "dfh_gn_global_sampled_views: knn = 4 only (the frame loop's)");
+    DFH_REQUIRE(n_views >= 1 && n_views <= DFH_GN_MAX_VIEWS && n_nodes >= 1 && lm_rel >= 0.0 && huber_delta >= 0.0, "dfh_gn_global_sampled_views: bad arguments");
+    DFH_REQUIRE(scratch_bytes >= dfh_gn_global_sampled_bytes(n_samples, stride), "dfh_gn_global_sampled_views: scratch too small");
+    DFH_REQUIRE(!sums_out || n_steps == 1, "dfh_gn_global_sampled_views: sums_out (the caller reduces over ranks and applies) takes one step per call");
+    AssocArgs aa;
+    const int rc = fill_assoc_params(aa.ap, lw_dq, H, W, K, Kinv, kIdentity34, scale, center, half, max_dist, knn);
+    if (rc != DFH_OK) return rc;
+    aa.depth = nullptr;
+    aa.views = static_cast<const AssocView *>(views);
+    aa.n_views = n_views;
+    aa.cull = 0;
+    BuildParams bp;
+    for (int i = 0; i < 8; ++i) bp.lw.q[i] = lw_dq[i];
+    bp.S = n_samples; bp.k = knn; bp.N = n_nodes; bp.huber = huber_delta;
+    const long n_tiles = (n_samples + kTile - 1) / kTile;
+    const long n_sub = (n_tiles + stride - 1) / stride;
+    const int n_wg = (int)std::min<long>(n_sub, kGlobalGrid);
+    double *tile_part = static_cast<double *>(scratch);
+    double *sums = sums_out ? sums_out : tile_part + (size_t)kGlobalVals * kGlobalGrid;
+    hipStream_t st = (hipStream_t)stream;
+    for (int g = 0; g < n_steps; ++g) {
+        if (n_wg > 0)
+            hipLaunchKernelGGL(gn_global_rows_kernel<4>, dim3((unsigned)n_wg), dim3(kTile), 0, st, sample_pos, sample_nrm, nbr, weights,
+                               (const double *)node_dq, bp, stride, n_sub, tile_part, aa);
+        hipLaunchKernelGGL(gn_global_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)tile_part, n_wg, sums);
+        if (!sums_out) hipLaunchKernelGGL(gn_global_apply_kernel, dim3(1), dim3(256), 0, st, (const double *)sums, lm_rel, n_nodes, node_dq, xi_out);
+    }
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;
 }

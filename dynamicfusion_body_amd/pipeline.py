@@ -93,16 +93,22 @@ class FrameSolver:
         self.solver.set_samples(pos, nrm, knn_bricks=knn_bricks)
         return pos.shape[0]
 
-    def gn_iteration(self, depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.0, n_iters=1):
+    def gn_iteration(self, depth, lw_cam, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.0, n_iters=1, n_global=0, global_lm=0.1):
         """associate -> build (+ all-reduce) -> PCG -> twist update, n_iters times; asynchronous.  depth / lw_cam may be lists
-        (several live views: every sample associates with the view in which it lies closest to the observed surface)."""
+        (several live views: every sample associates with the view in which it lies closest to the observed surface).
+        n_global: that many rigid-mode steps first (global_iteration), in the same library call on one GPU."""
         self.solver.iterate_associated(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, rw, max_dist, huber,
-                                       lm_abs, lm_rel, n_iters=n_iters)
+                                       lm_abs, lm_rel, n_iters=n_iters, n_global=n_global, global_lm=global_lm)
 
-    def global_iteration(self, depth, lw_cam, rw=5.0, max_dist=2.0, huber=0.0, lm_rel=0.1, n_iters=1):
-        """associate -> build (+ all-reduce) -> the rigid mode alone (WarpSolver.global_step: one twist for all nodes), n_iters
-        times; asynchronous.  Cheap (a build and one small launch each) and worth several node iterations where the live frame
-        has moved as a whole: ten truncated PCG iterations hardly touch that mode."""
+    def global_iteration(self, depth, lw_cam, rw=5.0, max_dist=2.0, huber=0.0, lm_rel=0.1, n_iters=1, built=False, stride=1):
+        """The rigid mode alone -- one twist shared by all nodes -- n_iters times; asynchronous.  Worth several node iterations where
+        the live frame has moved as a whole: ten truncated PCG iterations hardly touch that mode.  Default: straight from the
+        samples (WarpSolver.global_sampled: data rows only, two short launches a step); built=True: from the built normal
+        equations, regulariser included (associate -> build (+ all-reduce) -> WarpSolver.global_step)."""
+        if not built:
+            self.solver.global_sampled(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, max_dist, huber, lm_rel,
+                                       n_steps=n_iters, stride=stride)
+            return
         for _ in range(int(n_iters)):
             self.solver.build_associated(depth, self.K, self.Kinv, lw_cam, self.scale, self.center, self.half, self.lw, rw, max_dist, huber)
             self.solver.global_step(lm_rel)
@@ -124,6 +130,7 @@ class SlabFrame:
 
     RELAX = 0.8          # default of step(relax=...): see there
     GLOBAL_ITERS = 2     # default of step(global_iters=...): rigid-mode steps in front of the node iterations
+    GLOBAL_STRIDE = 4    # ... each fitted to every 4th 128-sample tile (step(global_stride=...))
 
     def __init__(self, K, scale, center, res, tdist_vox, node_pos, node_w, knn=4, pcg_iters=10, band=4.0, volume_dtype=torch.float32,
                  distributed=True, solve_mode="auto"):
@@ -251,7 +258,7 @@ class SlabFrame:
         return n_new
 
     def step(self, depth, lw_cam, gn_iters=10, rw=5.0, lm_abs=10.0, lm_rel=1e-2, max_dist=2.0, huber=0.5, stage_ms=None,
-             update_graph=False, on_updated=None, data_views=None, relax=None, global_iters=None, global_lm=0.1):
+             update_graph=False, on_updated=None, data_views=None, relax=None, global_iters=None, global_lm=0.1, global_stride=None):
         """Defaults (regulariser weight, LM damping, association gate and Huber threshold in voxels, the per-frame decay of the warp
         field `relax` = 0.8) are the ones under which the loop follows a +-0.6 voxel oscillation of the bench scene with a BOUNDED
         warp field: max node translation 0.85 voxel at frame 400, 1.01 at frame 1 200, sample count constant (tools/soak.py;
@@ -307,11 +314,14 @@ class SlabFrame:
         mark("live_tsdf")
         live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
         mark("allgather")
-        # the rigid mode first (FrameSolver.global_iteration), then the node iterations
+        # the rigid mode first (two steps: one twist shared by all nodes, fitted to the data rows -- FrameSolver.global_iteration),
+        # then the node iterations (one host call: nothing between their launches depends on the host)
         ng = self.GLOBAL_ITERS if global_iters is None else int(global_iters)
         if ng > 0:
-            self.fs.global_iteration(solve_depth, solve_lw, rw=rw, max_dist=max_dist, huber=huber, lm_rel=global_lm, n_iters=ng)
-        # (one host call for the frame's iterations: nothing between them depends on the host)
+            # (every `global_stride`-th tile of THIS rank's samples: with the samples sharded over ranks a stride > 1 thins another
+            # subsample than one GPU does -- the same estimator on other data; stride 1 is partition-independent)
+            self.fs.global_iteration(solve_depth, solve_lw, max_dist=max_dist, huber=huber, lm_rel=global_lm, n_iters=ng,
+                                     stride=self.GLOBAL_STRIDE if global_stride is None else int(global_stride))
         self.fs.gn_iteration(solve_depth, solve_lw, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist, huber=huber, n_iters=gn_iters)
         mark("solve")
         sv = self.fs.solver

@@ -702,7 +702,7 @@ class WarpSolver:
         self._allreduce_system()
 
     def iterate_associated(self, depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist=0.0, huber=0.0, lm_abs=0.0, lm_rel=0.0,
-                           n_iters=1):
+                           n_iters=1, n_global=0, global_lm=0.1):
         """n_iters GN iterations: build_associated + solve_update each.  On one GPU (no all-reduce between the halves) they
         are ONE call, dfh_gn_iteration_views (the views' table holds one or several depth maps): the iterations are queued
         back to back without returning to Python, and in each the clearing of the solve's workspace rides in the data-row
@@ -717,6 +717,9 @@ class WarpSolver:
                     not _lib.opt_on("py_gn_no_fused_assoc") and not _lib.opt_on("py_gn_no_fused_iter") and
                     not (self.distributed and (_dist.world()[1] > 1 or self.force_collective)))
         if not one_call:
+            for _ in range(int(n_global)):                # the rigid mode first (global_step): one twist for all nodes
+                self.build_associated(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist, huber)
+                self.global_step(global_lm)
             for _ in range(int(n_iters)):
                 self.build_associated(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist, huber)
                 self.solve_update(lm_abs, lm_rel)
@@ -733,6 +736,9 @@ class WarpSolver:
                   float(huber))
         tail = (self.pcg_iters, float(lm_abs), float(lm_rel), self.dx.data_ptr(), self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, 1.0)
         if not many and _lib.opt_on("py_gn_iter_per_call"):
+            for _ in range(int(n_global)):
+                self.build_associated(depth, K, Kinv, lw_cam, scale, center, half, lw_dq, rw, max_dist, huber)
+                self.global_step(global_lm)
             H, W = depth.shape
             for _ in range(int(n_iters)):
                 _lib.check(self.lib.dfh_gn_iteration(
@@ -741,6 +747,17 @@ class WarpSolver:
                     "dfh_gn_iteration")
             return
         tab, nv, H, W = self._views_table(depth if many else [depth], lw_cam if many else [lw_cam])
+        if int(n_global) > 0:
+            if getattr(self, "_global_ws", None) is None:
+                self._global_ws = torch.zeros((self.lib.dfh_gn_global_step_bytes() + 7) // 8, dtype=torch.float64, device="cuda")
+                self.global_xi = torch.zeros(8, dtype=torch.float64, device="cuda")
+            _lib.check(self.lib.dfh_gn_frame_solve_views(
+                *common, tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
+                _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), *tail, int(n_iters),
+                self.blk_upper.data_ptr() if self.blk_upper is not None else 0, self.n_upper, int(n_global), float(global_lm),
+                self.global_xi.data_ptr(), self._global_ws.data_ptr(), self._global_ws.numel() * 8, current_stream_ptr()),
+                "dfh_gn_frame_solve_views")
+            return
         _lib.check(self.lib.dfh_gn_iteration_views(
             *common, tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
             _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), *tail, int(n_iters),
@@ -776,12 +793,41 @@ class WarpSolver:
                                           self.pcg_ws.data_ptr(), self.pcg_ws.numel() * 8, current_stream_ptr()),
                    "dfh_pcg_solve")
 
+    def global_sampled(self, depth, K, Kinv, lw_cam, scale, center, half, lw_dq, max_dist=0.0, huber=0.0, lm_rel=0.1, n_steps=1, stride=1):
+        """n_steps rigid-mode steps straight from the samples (dfh_gn_global_sampled_views): ONE twist shared by all nodes, fitted
+        to the data rows of every `stride`-th tile (no built system, no regulariser), applied to every node.  depth / lw_cam:
+        one view or lists.  Samples sharded over ranks: the 29 sums are all-reduced, every rank applies the same twist.
+        Asynchronous; self.global_xi holds the last step's twist | objective | valid count."""
+        depth, lw_cam, many = self._one_or_many(depth, lw_cam)
+        tab, nv, H, W = self._views_table(depth if many else [depth], lw_cam if many else [lw_cam])
+        if getattr(self, "global_xi", None) is None or self.global_xi.numel() < 8:
+            self.global_xi = torch.zeros(8, dtype=torch.float64, device="cuda")
+        nbytes = self.lib.dfh_gn_global_sampled_bytes(self.S, int(stride))
+        if getattr(self, "_gs_ws", None) is None or self._gs_ws.numel() * 8 < nbytes:
+            self._gs_ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device="cuda")
+        sharded = self.distributed and (_dist.world()[1] > 1 or self.force_collective)
+        args = (self.spos.data_ptr(), self.snrm.data_ptr(), self.snbr.data_ptr(), self.swts.data_ptr(), self.S, self.knn, self.node_dq.data_ptr(),
+                self.N, _lib.darr(lw_dq, 8), float(huber), tab.data_ptr(), nv, H, W, _lib.darr(K, 9), _lib.darr(Kinv, 9), float(scale),
+                _lib.darr(np.asarray(center, dtype=np.float64), 3), float(half), float(max_dist), int(stride), float(lm_rel))
+        if not sharded:
+            _lib.check(self.lib.dfh_gn_global_sampled_views(*args, int(n_steps), self.global_xi.data_ptr(), 0, self._gs_ws.data_ptr(),
+                                                            self._gs_ws.numel() * 8, current_stream_ptr()), "dfh_gn_global_sampled_views")
+            return
+        if getattr(self, "_gs_sums", None) is None:
+            self._gs_sums = torch.zeros(32, dtype=torch.float64, device="cuda")
+        for _ in range(int(n_steps)):
+            _lib.check(self.lib.dfh_gn_global_sampled_views(*args, 1, 0, self._gs_sums.data_ptr(), self._gs_ws.data_ptr(),
+                                                            self._gs_ws.numel() * 8, current_stream_ptr()), "dfh_gn_global_sampled_views")
+            _dist.allreduce_system(self._gs_sums, force=self.force_collective)
+            _lib.check(self.lib.dfh_gn_global_apply(self._gs_sums.data_ptr(), float(lm_rel), self.N, self.node_dq.data_ptr(),
+                                                    self.global_xi.data_ptr(), current_stream_ptr()), "dfh_gn_global_apply")
+
     def global_step(self, lm_rel=0.1):
         """The rigid mode of the last build, solved on its own and applied to every node (dfh_gn_global_step): one twist shared
         by all nodes.  Asynchronous; the twist is left in self.global_xi (6 doubles on the device)."""
         if getattr(self, "_global_ws", None) is None:
             self._global_ws = torch.zeros((self.lib.dfh_gn_global_step_bytes() + 7) // 8, dtype=torch.float64, device="cuda")
-            self.global_xi = torch.zeros(6, dtype=torch.float64, device="cuda")
+            self.global_xi = torch.zeros(8, dtype=torch.float64, device="cuda")
         _lib.check(self.lib.dfh_gn_global_step(self.vals.data_ptr(), self.B, self.rhs.data_ptr(), self.N, float(lm_rel), self.node_dq.data_ptr(),
                                                self.global_xi.data_ptr(), self._global_ws.data_ptr(), self._global_ws.numel() * 8,
                                                current_stream_ptr()), "dfh_gn_global_step")

@@ -436,6 +436,21 @@ int dfh_gn_iteration_views(const double *sample_pos, const double *sample_nrm, c
                      double scale, const double center[3], double half, double max_dist,
                      int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
                      double step, int n_iters, const int *blk_upper, int n_upper, void *stream);
+/* A frame's whole solve behind one call: n_global rigid-mode steps (a build + dfh_gn_global_step(global_lm) each; global_scratch as
+ * there, global_xi_out may be NULL), then the n_iters node iterations of dfh_gn_iteration_views -- the same launches in the same
+ * order as the separate calls, hence the same bits.  pipeline.SlabFrame.step's solve on one GPU. */
+int dfh_gn_frame_solve_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights,
+                     double *corr_out, unsigned char *valid_out, int n_samples, int knn, double *node_dq,
+                     const double *node_pos, const double *node_w, const int *node_nbr, int n_nodes,
+                     const double lw_dq[8], double rw, const int *row_ptr, const int *col, int n_blocks, double *vals,
+                     double *rhs, double *cost_count, const int *run_id, int n_rows, double *partial, const int *blk_ptr,
+                     const int *blk_ent, const int *node_ptr, const int *node_ent, double *partial_reg,
+                     const int *rblk_ptr, const int *rblk_ent, const int *rnode_ptr, const int *rnode_ent, double huber_delta,
+                     const void *views, int n_views, int H, int W, const double K[9], const double Kinv[9],
+                     double scale, const double center[3], double half, double max_dist,
+                     int pcg_iters, double lm_abs, double lm_rel, double *x_out, void *pcg_workspace, size_t pcg_workspace_bytes,
+                     double step, int n_iters, const int *blk_upper, int n_upper,
+                     int n_global, double global_lm, double *global_xi_out, void *global_scratch, size_t global_scratch_bytes, void *stream);
 
 /* Multi-GPU solve: what travels in the per-iteration all-reduce.  `system` = {J^T J blocks (n_blocks x 36) | J^T r (6 n_nodes) |
  * cost, count} as the builds write it; J^T J is symmetric, so only the blocks with col >= row are packed (then J^T r and
@@ -485,6 +500,22 @@ int dfh_relax_twists(double *node_dq, int n_nodes, double factor, void *stream);
  * reference fits a global rigid motion first too (Fusion.solve, precompute_lw: core/fusion.py:356-365).  scratch: device
  * memory of dfh_gn_global_step_bytes() bytes, ZEROED by the caller once (the kernel leaves it ready for the next call); sums
  * are added in a fixed order: the same bits every run.  Restated in oracle/gn_np.global_step. */
+/* The same rigid-mode step from a SUBSAMPLE of the data rows, without a built system (what the frame loop takes): every
+ * `stride`-th 128-sample tile of the (sorted) samples is associated against the views' table and differentiated as in the builds
+ * (same Huber weights); a sample's Jacobian for the shared twist is the sum of its knn node blocks; the regulariser is left out (a
+ * common left twist only rotates its residuals).  n_steps steps, each three short launches (rows, the 29 sums -- 21 upper entries
+ * of A_g, 6 of g_g, objective, valid count -- and solve + apply); xi_out (8 doubles, may be NULL): the last step's twist | its
+ * objective | its valid-sample count.  scratch: dfh_gn_global_sampled_bytes(n_samples, stride) bytes.  Sums in a fixed order: the
+ * same bits every run.  knn = 4.  sums_out != NULL (n_steps = 1): only the 29 sums of THIS rank's samples are produced (32 doubles)
+ * -- the caller all-reduces them over ranks and calls dfh_gn_global_apply: every rank then applies the same twist.
+ * Restated in oracle/gn_np.global_step_sampled. */
+size_t dfh_gn_global_sampled_bytes(int n_samples, int stride);
+int dfh_gn_global_sampled_views(const double *sample_pos, const double *sample_nrm, const int *nbr, const double *weights, int n_samples, int knn,
+                                double *node_dq, int n_nodes, const double lw_dq[8], double huber_delta, const void *views, int n_views, int H, int W,
+                                const double K[9], const double Kinv[9], double scale, const double center[3], double half, double max_dist,
+                                int stride, double lm_rel, int n_steps, double *xi_out, double *sums_out, void *scratch, size_t scratch_bytes,
+                                void *stream);
+int dfh_gn_global_apply(const double *sums29, double lm_rel, int n_nodes, double *node_dq, double *xi_out, void *stream);
 size_t dfh_gn_global_step_bytes(void);
 int dfh_gn_global_step(const double *vals, int n_blocks, const double *rhs, int n_nodes, double lm_rel, double *node_dq, double *xi_out,
                        void *scratch, size_t scratch_bytes, void *stream);

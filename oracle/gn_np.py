@@ -368,6 +368,24 @@ def global_step(dqs, blocks, Jtr, lm_rel):
     return apply_twists(dqs, np.tile(xi, (len(dqs), 1))), xi
 
 
+def global_step_sampled(dqs, pos, nrm, nbr, node_pos, node_w, lw, associate, huber, lm_rel, stride=1, tile=128):
+    """The rigid-mode step straight from the samples (dfh_gn_global_sampled_views): the data rows of every `stride`-th `tile`-sample
+    tile, a sample's Jacobian for the shared twist = the sum of its k node blocks, Huber weights as in the builds, no regulariser;
+    (A_g + lm_rel diag A_g) xi = -g_g, xi applied to every node.  Returns (new dqs, xi, valid count)."""
+    warped = O.warp(pos, dqs[nbr], node_pos[nbr], node_w[nbr], m_lw=lw)
+    corr, valid = associate(warped)
+    sel = np.flatnonzero(valid & ((np.arange(len(pos)) // tile) % stride == 0))
+    r, J = data_residual_jacobian(dqs, pos[sel], nrm[sel], corr[sel], nbr[sel], node_pos, node_w, lw)
+    if huber > 0.0:
+        sc, _ = huber_scale(r, huber)
+        r, J = r * sc, J * sc[:, None, None]
+    Jg = J.sum(axis=1)
+    A = Jg.T @ Jg
+    A = A + lm_rel * np.diag(np.diag(A))
+    xi = -np.linalg.solve(A, Jg.T @ r) if len(sel) >= 6 else np.zeros(6)
+    return apply_twists(dqs, np.tile(xi, (len(dqs), 1))), xi, len(sel)
+
+
 def huber_scale(r, delta):
     """(sqrt of the IRLS weight per row, Huber objective sum rho(r)) -- dfh_gn_build_planned's huber_delta."""
     a = np.abs(r)
@@ -377,15 +395,20 @@ def huber_scale(r, delta):
 
 
 def gn_loop_truncated(dqs, pos, nrm, nbr, node_nbr, node_pos, node_w, lw, associate, iters, rw, lm_abs, lm_rel, huber, pcg_iters,
-                      exact=False, global_iters=0, global_lm=0.1):
+                      exact=False, global_iters=0, global_lm=0.1, global_sampled=True):
     """The shipped GN loop (pipeline.FrameSolver.gn_iteration x iters) on the CPU: per iteration associate ->
     Huber-weighted normal equations -> `pcg_iters` iterations of pcg_cg1 (exact=True: sparse direct solve) -> twist
-    update.  associate(warped_points) -> (corr, valid).  global_iters: that many rigid-mode steps first (associate -> the same
-    normal equations -> global_step), as pipeline.SlabFrame.step takes them.  Returns (costs at every build of the node
+    update.  associate(warped_points) -> (corr, valid).  global_iters: that many rigid-mode steps first, as
+    pipeline.SlabFrame.step takes them (global_sampled: from the data rows, global_step_sampled; else from the built normal
+    equations, global_step).  Returns (costs at every build of the node
     iterations, valid counts, final dqs)."""
     N = len(dqs)
     dqs = np.asarray(dqs, dtype=np.float64).copy()
     costs, counts = [], []
+    if global_iters and global_sampled:
+        for _ in range(global_iters):
+            dqs, _, _ = global_step_sampled(dqs, pos, nrm, nbr, node_pos, node_w, lw, associate, huber, global_lm)
+        global_iters = 0
     for it_ in range(global_iters + iters):
         warped = O.warp(pos, dqs[nbr], node_pos[nbr], node_w[nbr], m_lw=lw)
         corr, valid = associate(warped)

@@ -452,3 +452,44 @@ def test_solve_recovers_a_known_translation():
     if os.path.exists(gold):
         g = json.load(open(gold))
         assert abs(g["gpu_10_iterations"]["normal_share"] - m_gpu["normal_share"]) <= 1e-3
+
+
+def test_rigid_mode_step_variants_and_oracle():
+    """dfh_gn_global_sampled_views (the frame loop's rigid-mode step: one twist for all nodes from the data rows) against its numpy
+    restatement (oracle/gn_np.global_step_sampled: all tiles, and every 3rd tile), and against the step from the BUILT normal
+    equations (dfh_gn_global_step) with the regulariser switched off -- the same system summed another way."""
+    R, N = 96, 128
+    K, Kinv, (H, W), scale, center, tdist, T, Wt = canonical(R, "C2")
+    fs = FrameSolver(K, scale, center, R / 2, knn=4, pcg_iters=10, distributed=False)
+    node_pos, node_w = scene.fibonacci_nodes(N, R)
+    ident = np.tile(IDENT, (N, 1))
+    fs.set_graph(node_pos, ident, node_w)
+    S = fs.set_canonical(T, Wt, band=2.0)
+    assert S > 5000
+    lws = [scene.view_extrinsic(a) for a in (0.0, 40.0, -40.0)]
+    lives = [scene.render_depth(K, lw, H, W, dtype=np.float32, invalid_frac=0.0, sphere_offset=np.array([0.5, -0.3, 0.2]) * scale) for lw in lws]
+    depths = [torch.from_numpy(d).cuda() for d in lives]
+    sv = fs.solver
+    rng = np.random.default_rng(4)
+    dq0 = G.apply_twists(ident, rng.normal(scale=[1e-3] * 3 + [0.1] * 3, size=(N, 6)))
+    pos, nrm, nbr, node_nbr = host_arrays(sv)
+
+    def assoc(w):
+        c, v, _ = G.associate_depth_views(w, K, Kinv, lws, lives, scale, center, R / 2, 2.0)
+        return c, v
+    for stride in (1, 3):
+        sv.node_dq.copy_(torch.from_numpy(dq0).cuda())
+        fs.global_iteration(depths, lws, max_dist=2.0, huber=0.5, lm_rel=0.1, n_iters=1, stride=stride)
+        xi = sv.global_xi.cpu().numpy()
+        dq_o, xi_o, n_o = G.global_step_sampled(dq0, pos, nrm, nbr, node_pos, node_w, IDENT, assoc, 0.5, 0.1, stride=stride)
+        assert int(xi[7]) == n_o and n_o > 1000
+        assert np.abs(xi[:6] - xi_o).max() <= 1e-9 * max(1.0, np.abs(xi_o).max()), (stride, xi[:6], xi_o)
+        assert np.abs(sv.node_dq.cpu().numpy() - dq_o).max() <= 1e-9
+        if stride == 1:
+            xi_all = xi[:6].copy()
+    assert np.linalg.norm(xi_all[3:]) > 0.05                                      # it does move: the live sphere is 0.6 voxel away
+    # the built system without the regulariser holds the same sums
+    sv.node_dq.copy_(torch.from_numpy(dq0).cuda())
+    fs.global_iteration(depths, lws, rw=0.0, max_dist=2.0, huber=0.5, lm_rel=0.1, n_iters=1, built=True)
+    xi_b = sv.global_xi.cpu().numpy()[:6]
+    assert np.abs(xi_b - xi_all).max() <= 1e-9 * max(1.0, np.abs(xi_all).max()), (xi_b, xi_all)

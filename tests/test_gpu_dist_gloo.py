@@ -142,7 +142,7 @@ def _frame_worker(rank, ws, port, out, sphere_r=None):
             if mode == "sharded":
                 n_mine = n_s
             for d in frames:
-                sf.step(d, lw_cam, gn_iters=3, lm_abs=1.0)
+                sf.step(d, lw_cam, gn_iters=3, lm_abs=1.0, global_stride=1)
             res[mode] = sf
         a, b = res["sharded"].a, res["sharded"].b
         assert (a, b) == D.slab_range(R, rank, ws) and (res["whole"].a, res["whole"].b) == (0, R)
@@ -241,7 +241,7 @@ def _frame_worker_full(rank, ws, port, out):
             sf.refresh_samples()
             counts = []
             for fr in frames:
-                counts.append(sf.step(fr, lws, gn_iters=10))
+                counts.append(sf.step(fr, lws, gn_iters=10, global_stride=1))    # (stride 1: the rigid-mode step over ALL samples is partition-independent)
             res[mode] = (sf, counts)
         (sh, n_sh), (rp, n_rp), (wh, n_wh) = res["sharded"], res["replicated"], res["whole"]
         a, b = sh.a, sh.b

@@ -49,7 +49,7 @@ constexpr int kGnTile = DFH_GN_TILE;
 #define DFH_OPTION_LIST(X)                                                                                                \
     X(k1_strided) X(k1_late_loads) X(k1_planes_per_block) X(k1_force_scalar) X(k1_bricks_min) X(k1_no_bricks)            \
     X(k1_bricks_nocull) X(k1_no_multi) X(k1_cull) X(k1_nzi) X(k1_prefetch) X(k1_nt)                  \
-    X(k2_exact) X(k2_no_strided) X(k3_no_cache) X(k3_exact) X(k3_no_lds) X(k3_wg_per_cu) X(k3_tpb) X(k3_skip) X(plan_radix) X(rigid_atomic) X(gn_reg_own_launch) X(gn_reg_own_gather) \
+    X(k2_exact) X(k2_no_strided) X(k2_nt) X(k3_no_cache) X(k3_exact) X(k3_no_lds) X(k3_wg_per_cu) X(k3_tpb) X(k3_skip) X(plan_radix) X(rigid_atomic) X(gn_reg_own_launch) X(gn_reg_own_gather) \
     X(dbg_gather_part) X(pcg_wpb) X(pcg_multilaunch) X(pcg_spin_limit) X(pcg_one_xcd) X(gn_iter_own_clear) X(gn_gather_full) X(gn_no_view_cull)                                                            \
     X(py_plan_torch) X(py_allreduce_full) X(py_gn_atomic) X(py_gn_no_fused_assoc) X(py_gn_no_fused_iter) X(py_gn_iter_per_call) X(py_no_side_stream) X(py_no_host_scalars)
 struct Options {

@@ -112,7 +112,9 @@ __device__ __forceinline__ double sample_fast(const LiveT *__restrict__ vol, int
 
 // STRIDED: a lane's 4 voxels are z, z+64, z+128, z+192 of its wave's 256-voxel run, so that in every
 // one of the 32 corner gathers (and the T/w accesses) consecutive lanes touch consecutive voxels.
-template <typename LiveT, bool STRIDED>
+// NT: non-temporal T / w (the slab's pair of volumes exceeds the 256 MiB Infinity Cache: nothing of it is re-read before it is
+// evicted, and every 128-byte line is touched by one instruction of one wave -- K1's finding, profiles/r3_rmw_stream_512.txt).
+template <typename LiveT, bool STRIDED, bool NT = false>
 __global__ __launch_bounds__(256) void fuse_volume_rigid_fast_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w,
                                                                       const LiveT *__restrict__ live, const RigidParams p,
                                                                       const RigidFastParams f) {
@@ -170,7 +172,10 @@ __global__ __launch_bounds__(256) void fuse_volume_rigid_fast_kernel(float *__re
     P t, w;
     if (STRIDED) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { t.v[j] = tsdf[off + j * ZS]; w.v[j] = tsdf_w[off + j * ZS]; }
+        for (int j = 0; j < VEC; ++j) {
+            if (NT) { t.v[j] = __builtin_nontemporal_load(tsdf + off + j * ZS); w.v[j] = __builtin_nontemporal_load(tsdf_w + off + j * ZS); }
+            else { t.v[j] = tsdf[off + j * ZS]; w.v[j] = tsdf_w[off + j * ZS]; }
+        }
     } else {
         t = *reinterpret_cast<const P *>(tsdf + off);
         w = *reinterpret_cast<const P *>(tsdf_w + off);
@@ -190,7 +195,10 @@ __global__ __launch_bounds__(256) void fuse_volume_rigid_fast_kernel(float *__re
     if (STRIDED) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            if (upd[j]) { tsdf[off + j * ZS] = t.v[j]; tsdf_w[off + j * ZS] = w.v[j]; }
+            if (upd[j]) {
+                if (NT) { __builtin_nontemporal_store(t.v[j], tsdf + off + j * ZS); __builtin_nontemporal_store(w.v[j], tsdf_w + off + j * ZS); }
+                else { tsdf[off + j * ZS] = t.v[j]; tsdf_w[off + j * ZS] = w.v[j]; }
+            }
         }
     } else {
         *reinterpret_cast<P *>(tsdf + off) = t;
@@ -1281,7 +1289,11 @@ __global__ __launch_bounds__(256) void dqb_bound_kernel(const double *__restrict
     mine[13] = sqrtf((me[0] - 1.0f) * (me[0] - 1.0f) + vv);
     const int n = __builtin_popcount((unsigned)(__ballot(have) >> (16 * (grp & 3))) & 0xffffu);       // ids are packed to the front
     const bool overflow = (__shfl((int)id, (int)(threadIdx.x & 48), 64) & 0xffff) == 0xfffe;   // the group's lane 0
-    __syncthreads();
+    // (a group reads only what its own 16 lanes wrote, all in one wave: the wave's LDS operations execute in order -- no workgroup
+    // barrier in this kernel, its waves run independently: 200 -> 150 us at 512^3)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     float num = 0.0f, n2min = __builtin_huge_valf();
     const int npairs = n * (n + 1) / 2;
     for (int q = sub; q < npairs; q += 16) {
@@ -1328,31 +1340,24 @@ __global__ __launch_bounds__(256) void dqb_bound_kernel(const double *__restrict
         k.mb[brick] = (unsigned char)m;
         reinterpret_cast<unsigned char *>(k.S)[brick] = safe ? 1 : 0;
     }
-    // the warp kernel's bricks of this block, in brick order (z fastest: neighbours along z stay neighbours), onto sub-list
-    // blockIdx % kSkipLists behind ONE atomic
-    __shared__ unsigned char s_unsafe[16];
-    __shared__ unsigned s_base;
-    if (sub == 0) s_unsafe[grp] = real && !safe ? 1 : 0;
-    __syncthreads();
+    // the warp kernel's bricks of this WAVE (four of them, in brick order: z fastest, neighbours along z stay neighbours) onto
+    // sub-list hash(block) behind one atomic
     // (not blockIdx % kSkipLists: with 64 columns per x plane that is "the columns at y = l", a plane, and the sphere's planes
     // hold anything from none to most of the shell -- 135 us instead of 100)
     const unsigned l = (blockIdx.x ^ (blockIdx.x >> 6) ^ (blockIdx.x >> 12) ^ (blockIdx.x >> 18)) % kSkipLists;
-    if (threadIdx.x == 0) {
-        unsigned tot = 0;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) tot += s_unsafe[g];
-        s_base = tot ? atomicAdd(k.sub_count + 16 * l, tot) : 0u;
-    }
-    __syncthreads();
-    if (sub == 0 && real && !safe) {
-        unsigned before = 0;
-        for (int g = 0; g < grp; ++g) before += s_unsafe[g];
-        k.sub_list[(size_t)l * k.sub_cap + s_base + before] = (unsigned)brick;
-    }
+    const unsigned long long unsafe = __ballot(sub == 0 && real && !safe);      // bits 0, 16, 32, 48
+    if (unsafe == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == __builtin_ctzll(unsafe)) base = atomicAdd(k.sub_count + 16 * l, (unsigned)__builtin_popcountll(unsafe));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(unsafe));
+    if (sub == 0 && real && !safe)
+        k.sub_list[(size_t)l * k.sub_cap + base + (unsigned)__builtin_popcountll(unsafe & ((1ull << lane) - 1ull))] = (unsigned)brick;
 }
 
 // the bricks with Sb = 1: T, w, wi in 16-byte packs, s = tdist; a pack nothing changes in (T already at tdist, w saturated: most
 // of the free space) is not written back
+template <bool NT>
 __global__ __launch_bounds__(256) void dqb_stream_kernel(float *__restrict__ tsdf, float *__restrict__ tsdf_w, const float *__restrict__ wi_cache,
                                                           const DqbParams p, const DqbSkip k, const DqbRedoList redo_list, unsigned npacks, int sat_ok) {
     const unsigned pack = blockIdx.x * 256u + threadIdx.x;
@@ -1362,15 +1367,25 @@ __global__ __launch_bounds__(256) void dqb_stream_kernel(float *__restrict__ tsd
     const unsigned xl = row / (unsigned)p.Y, y = row - xl * (unsigned)p.Y;
     if (!reinterpret_cast<const unsigned char *>(k.S)[((size_t)(xl >> 2) * p.nby + (y >> 2)) * p.nbz + (cz >> 2)]) return;
     const size_t off = (size_t)pack * 4;
-    const float4 t0 = *reinterpret_cast<const float4 *>(tsdf + off);
-    const float4 w0 = *reinterpret_cast<const float4 *>(tsdf_w + off);
+    // (NT: volumes beyond the Infinity Cache -- whole 1-KiB rows per wave instruction, nothing re-read: K1's non-temporal policy)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    float4 t0, w0;
+    if (NT) {
+        const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(tsdf + off)), b = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(tsdf_w + off));
+        t0 = make_float4(a.x, a.y, a.z, a.w); w0 = make_float4(b.x, b.y, b.z, b.w);
+    } else {
+        t0 = *reinterpret_cast<const float4 *>(tsdf + off);
+        w0 = *reinterpret_cast<const float4 *>(tsdf_w + off);
+    }
     // T already at tdist and w at wmax (the free space after a few frames): the update changes nothing whatever wi >= 0 is,
     // PROVIDED tdist is a power of two (the frame loop's 4 voxels; sat_ok): then tdist wi and tdist wt are exact, their sum is
     // tdist (wi + wt) exactly (two float32 values of similar size add exactly in fp64), times the reciprocal, good to an ulp of
     // the double, rounds to the float32 tdist; and wt = wmax gives min(wi + wmax, wmax) = wmax.  No wi load, no store.
     const float td = (float)p.tdist, wm = (float)p.wmax;
     if (sat_ok && t0.x == td && t0.y == td && t0.z == td && t0.w == td && w0.x == wm && w0.y == wm && w0.z == wm && w0.w == wm) return;
-    const float4 wi = *reinterpret_cast<const float4 *>(wi_cache + off);
+    float4 wi;
+    if (NT) { const v4f c = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(wi_cache + off)); wi = make_float4(c.x, c.y, c.z, c.w); }
+    else wi = *reinterpret_cast<const float4 *>(wi_cache + off);
     float4 t = t0, w = w0;
     float *tv = &t.x, *wv = &w.x;
     const float *wiv = &wi.x;
@@ -1382,8 +1397,14 @@ __global__ __launch_bounds__(256) void dqb_stream_kernel(float *__restrict__ tsd
             redo_list.offs[atomicAdd(redo_list.count, 1u)] = (unsigned)(off + j);
         }
     }
-    if (t.x != t0.x || t.y != t0.y || t.z != t0.z || t.w != t0.w) *reinterpret_cast<float4 *>(tsdf + off) = t;
-    if (w.x != w0.x || w.y != w0.y || w.z != w0.z || w.w != w0.w) *reinterpret_cast<float4 *>(tsdf_w + off) = w;
+    if (t.x != t0.x || t.y != t0.y || t.z != t0.z || t.w != t0.w) {
+        if (NT) { v4f a; a.x = t.x; a.y = t.y; a.z = t.z; a.w = t.w; __builtin_nontemporal_store(a, reinterpret_cast<v4f *>(tsdf + off)); }
+        else *reinterpret_cast<float4 *>(tsdf + off) = t;
+    }
+    if (w.x != w0.x || w.y != w0.y || w.z != w0.z || w.w != w0.w) {
+        if (NT) { v4f a; a.x = w.x; a.y = w.y; a.z = w.z; a.w = w.w; __builtin_nontemporal_store(a, reinterpret_cast<v4f *>(tsdf_w + off)); }
+        else *reinterpret_cast<float4 *>(tsdf_w + off) = w;
+    }
 }
 
 // Regions of the skip inside a level-2 workspace: behind the fast path's 28 B per voxel and the redo list's 4 B + header, in the
@@ -1495,8 +1516,12 @@ static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const dou
                                    p.LY, p.LZ, p.tdist, sk, cx_lo);
             hipLaunchKernelGGL(dqb_reach_kernel, dim3((unsigned)((sk.SCX * sk.SCY + 3) / 4)), dim3(256), 0, s, p, sk);
             hipLaunchKernelGGL(dqb_bound_kernel, dim3((unsigned)((nbr + 15) / 16)), dim3(256), 0, s, node_dq, p, sk, opt().k3_skip == 2 ? 1 : 0);
-            hipLaunchKernelGGL(dqb_stream_kernel, dim3((unsigned)((nv / 4 + 255) / 256)), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, wi_cache, p, sk,
-                               redo_list, (unsigned)(nv / 4), sat_ok);
+            if (nv * 8 > ((size_t)256 << 20))
+                hipLaunchKernelGGL(dqb_stream_kernel<true>, dim3((unsigned)((nv / 4 + 255) / 256)), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, wi_cache,
+                                   p, sk, redo_list, (unsigned)(nv / 4), sat_ok);
+            else
+                hipLaunchKernelGGL(dqb_stream_kernel<false>, dim3((unsigned)((nv / 4 + 255) / 256)), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, wi_cache,
+                                   p, sk, redo_list, (unsigned)(nv / 4), sat_ok);
         }
 #define DFH_K3L(TPB, STRIDE)                                                                                                                          \
         do {                                                                                                                                          \
@@ -1645,10 +1670,11 @@ extern "C" int dfh_fuse_volume_rigid(void *tsdf, void *tsdf_w, int vol_dtype, co
         for (int b = 0; b < 31; ++b) if (p.zpacks == (1 << b)) p.zp_shift = b;
         dim3 grid((unsigned)(((long)p.Y * p.zpacks + 255) / 256), (unsigned)p.nx), block(256);
         const bool strided = p.zpacks % 64 == 0 && !on(opt().k2_no_strided);
-#define DFH_K2(LT, ST) hipLaunchKernelGGL((fuse_volume_rigid_fast_kernel<LT, ST>), grid, block, 0, s, (float *)tsdf, \
-                                          (float *)tsdf_w, (const LT *)live, p, f)
-        if (live_dtype == DFH_F32) { if (strided) DFH_K2(float, true); else DFH_K2(float, false); }
-        else { if (strided) DFH_K2(double, true); else DFH_K2(double, false); }
+#define DFH_K2(LT, ST, NT_) hipLaunchKernelGGL((fuse_volume_rigid_fast_kernel<LT, ST, NT_>), grid, block, 0, s, (float *)tsdf, \
+                                               (float *)tsdf_w, (const LT *)live, p, f)
+        const bool nt = strided && (opt().k2_nt > 0 || (opt().k2_nt < 0 && (size_t)p.nx * p.Y * p.Z * 8 > ((size_t)256 << 20)));
+        if (live_dtype == DFH_F32) { if (strided) { if (nt) DFH_K2(float, true, true); else DFH_K2(float, true, false); } else DFH_K2(float, false, false); }
+        else { if (strided) { if (nt) DFH_K2(double, true, true); else DFH_K2(double, true, false); } else DFH_K2(double, false, false); }
 #undef DFH_K2
         DFH_HIP_CHECK(hipGetLastError());
         return DFH_OK;

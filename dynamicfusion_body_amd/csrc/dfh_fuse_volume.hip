@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(256) void dqb_bound_kernel(const double *__restrict
         const double need = d + 1.0;                                           // the corners: floor / ceil of the position
         m = need <= 4.0 ? 1 : (need <= 8.0 ? 2 : 255);
     }
-    const bool safe = m <= rs;                                                 // (uniform over the 16 lanes)
+    const bool safe = m <= rs && all_bounds != 2;                              // (uniform over the 16 lanes; all_bounds = 2: experiment, every brick to the warp kernel)
     if (sub == 0 && real) {
         k.db[brick] = want ? D : -1.0f;                                        // -1: not computed (the live volume ruled the skip out)
         k.mb[brick] = (unsigned char)m;
@@ -1515,7 +1515,7 @@ static int launch_dqb_fast(void *tsdf, void *tsdf_w, const void *live, const dou
                 hipLaunchKernelGGL((dqb_live_mask_kernel<LiveT>), dim3((unsigned)((cx_hi - cx_lo) * sk.CY)), dim3(1024), 0, s, (const LiveT *)live, p.LX,
                                    p.LY, p.LZ, p.tdist, sk, cx_lo);
             hipLaunchKernelGGL(dqb_reach_kernel, dim3((unsigned)((sk.SCX * sk.SCY + 3) / 4)), dim3(256), 0, s, p, sk);
-            hipLaunchKernelGGL(dqb_bound_kernel, dim3((unsigned)((nbr + 15) / 16)), dim3(256), 0, s, node_dq, p, sk, opt().k3_skip == 2 ? 1 : 0);
+            hipLaunchKernelGGL(dqb_bound_kernel, dim3((unsigned)((nbr + 15) / 16)), dim3(256), 0, s, node_dq, p, sk, opt().k3_skip == 2 ? 1 : (opt().k3_skip == 3 ? 2 : 0));
             if (nv * 8 > ((size_t)256 << 20))
                 hipLaunchKernelGGL(dqb_stream_kernel<true>, dim3((unsigned)((nv / 4 + 255) / 256)), dim3(256), 0, s, (float *)tsdf, (float *)tsdf_w, wi_cache,
                                    p, sk, redo_list, (unsigned)(nv / 4), sat_ok);

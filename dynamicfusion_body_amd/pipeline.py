@@ -137,7 +137,9 @@ class SlabFrame:
         """solve_mode (several ranks): "sharded" = every rank builds the normal equations of its own slab's samples, one
         all-reduce per GN iteration (BASELINE north star); "replicated" = the slabs' samples are all-gathered once per frame
         and every rank solves the whole system, no per-iteration collective (bit-identical warp fields on all ranks, and the
-        single-GPU loop's bits); "auto" = dist.solve_mode's latency model, decided at the first sample refresh."""
+        single-GPU loop's bits WHEN both run the same PCG path -- _lib dfh_pcg_path: ranks that share one GPU, a rehearsal, take
+        the two-launch kernels, one rank per GPU the persistent kernel like a single-GPU run; tests/test_gpu_dist_gloo.py pins it at
+        256^3 / 512 nodes); "auto" = dist.solve_mode's latency model, decided at the first sample refresh."""
         from . import dist as D
         self.D = D
         self.distributed = bool(distributed)

@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from dynamicfusion_body_amd import _lib, kernels
 from dynamicfusion_body_amd.dq import twist_exp_dq
 for R in (256, 512):

@@ -59,7 +59,7 @@ print("node DQs: |r - 1| max %.3g median %.3g; 2|d| max %.3g median %.3g" % (flo
 
 
 def k3(T, Wt, skip, all_bounds=False):
-    _lib.set_option("k3_skip", (2 if all_bounds else None) if skip else 0)
+    _lib.set_option("k3_skip", 3 if skip == "list" else ((2 if all_bounds else 1) if skip else 0))
     kernels.fuse_volume_dqb(T, Wt, live, sv.node_pos, dq, sv.node_w, 4, sf.ident_lw, tvox, res=(R, R, R), x_range=(0, R), workspace=sf.ws_dqb,
                             rebuild_candidates=False)
     _lib.set_option("k3_skip", None)
@@ -97,7 +97,7 @@ for reach in (1, 2, 3):
           float(er.view(R // 4, R // 4, R // 16, 4).all(dim=3).float().mean())))
 
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for skip in (True, False, True, False):
+for skip in (True, False, "list", True, False, "list"):
     T, Wt = T0.clone(), W0.clone()
     k3(T, Wt, skip)
     torch.cuda.synchronize()
@@ -106,7 +106,7 @@ for skip in (True, False, True, False):
         k3(T, Wt, skip)
     e1.record()
     torch.cuda.synchronize()
-    print("K3 steady state, skip %-3s: %.1f us per call" % ("on" if skip else "off", e0.elapsed_time(e1) / a.reps * 1e3))
+    print("K3 steady state, skip %-4s: %.1f us per call" % (skip if skip == "list" else ("on" if skip else "off"), e0.elapsed_time(e1) / a.reps * 1e3))
 
 if a.check_bound:
     worst = 0.0

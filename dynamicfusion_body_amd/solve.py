@@ -290,7 +290,9 @@ class WarpSolver:
         self.spos, self.snrm = pos.contiguous(), nrm.contiguous()
         self.snbr, self.swts = nbr.contiguous(), weights.contiguous()
         self.S = pos.shape[0]
-        self.corr = torch.zeros((self.S, 3), dtype=torch.float64, device="cuda")
+        # (corr: every association path writes all S rows -- 0 where invalid -- and the builds read it for valid samples only: no
+        # fill needed, 63 MB per frame at config 5; valid IS cleared: a build before any association must see no rows)
+        self.corr = torch.empty((self.S, 3), dtype=torch.float64, device="cuda")
         self.valid = torch.zeros(self.S, dtype=torch.uint8, device="cuda")
         self._pattern = None
 

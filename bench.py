@@ -145,7 +145,7 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 one_solve()
-                torch.cuda.synchronize()
+                quiesce_collectives(torch, dist, world)
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     one_solve()
             torch.cuda.current_stream().wait_stream(side)
@@ -210,6 +210,18 @@ def gn_leg(args, torch, dist, scene, rank, world, barrier):
 def kernels_mod():
     from dynamicfusion_body_amd import kernels
     return kernels
+
+
+def quiesce_collectives(torch, dist, world):
+    """Before a stream capture in a process with a live RCCL group: drain the device and give the process group's watchdog thread
+    (it polls every 100 ms) time to retire the collectives already issued, so that it has no event left to query while this
+    thread captures.  thread_local capture mode is meant to allow such queries; one child of
+    tests/test_gpu_dist_gloo.py::test_one_rank_rccl_sharded_iteration_captures_into_a_graph aborted (SIGABRT) in about twenty
+    runs before this, none since."""
+    torch.cuda.synchronize()
+    if dist is not None and world >= 1 and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        import time
+        time.sleep(0.3)
 
 
 def pcg_path_name(n_nodes):
@@ -547,6 +559,7 @@ def main():
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             g = torch.cuda.CUDAGraph()
+            quiesce_collectives(torch, dist, world)
             with torch.cuda.stream(side):
                 # thread_local: RCCL's watchdog thread may query events while this thread captures; in the default global
                 # mode that would invalidate the capture

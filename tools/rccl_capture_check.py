@@ -82,6 +82,7 @@ def main():
             with torch.cuda.stream(side):
                 one_solve()
                 torch.cuda.synchronize()
+                time.sleep(0.3)      # the group's watchdog (100 ms poll) retires the eager collectives: nothing left to query during the capture
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     one_solve()
             torch.cuda.current_stream().wait_stream(side)

@@ -92,11 +92,16 @@ __device__ __forceinline__ void ld4(const float *a, float (&o)[4]) {
 // loads the pack at voxel v0 (a multiple of 4, inside the volume); neighbours only if a voxel lies in the band
 __device__ __forceinline__ void band_pack_load(const float *__restrict__ T, const float *__restrict__ W, const ExtractParams &p, long v0, BandPack &k) {
     ld4(T + v0, k.t);
-    ld4(W + v0, k.w);
     k.in_band = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if ((double)k.w[j] > 0.0 && fabs((double)k.t[j]) < p.band) k.in_band |= 1u << j;
+        if (fabs((double)k.t[j]) < p.band) k.in_band |= 1u << j;
+    if (!k.in_band) return;
+    // the weights only of packs with a voxel inside the band (a twentieth of them): the sweep reads 4 B per voxel, not 8
+    ld4(W + v0, k.w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!((double)k.w[j] > 0.0)) k.in_band &= ~(1u << j);
     if (!k.in_band) return;
     long row;                    // index of the z row
     if (p.nvox < (1L << 31)) {   // (32-bit divisions where the volume allows them)

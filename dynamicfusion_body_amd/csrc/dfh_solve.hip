@@ -2568,78 +2568,93 @@ __global__ __launch_bounds__(256) void gn_global_step_kernel(const double *__res
 // g_g = sum_s J_g^T r need neither runs nor a gather.  Every `stride`-th 128-sample tile (the samples are sorted by node tuple:
 // a uniform thinning of the surface) is associated and differentiated exactly as in gn_build_data_kernel (same Huber weights);
 // the regulariser is left out (a common left twist rotates every regulariser residual rigidly: it only damps this mode).  Per
-// tile 21 + 6 sums (+ objective, count) in a fixed order; gn_global_reduce_kernel adds the tiles' partials in index order,
-// gn_global_apply_kernel damps, solves by Cholesky and applies the twist to every node (sharded samples: an all-reduce of the
-// 29 sums goes between the two).  A rigid-mode step costs ~35 us instead of a full build +
-// gather + dfh_gn_global_step (0.4 ms at config 5).  Restated in oracle/gn_np.global_step_sampled.
+// tile 21 + 6 sums (+ objective, count) in a fixed order; gn_global_finish_kernel adds the workgroups' partials in index order,
+// damps, solves and applies the twist to every node (sharded samples: it stops at the 29 sums, an all-reduce goes in between and
+// gn_global_apply_kernel does the rest).  Restated in oracle/gn_np.global_step_sampled.
 constexpr int kGlobalVals = 29;                     // 21 upper entries of A_g | 6 of g_g | objective | valid count
-constexpr int kGlobalGrid = 1024;                   // workgroups of the rows kernel = partial sets (fixed: the summation order must not follow the device)
+constexpr int kGlobalGrid = 1536;                   // workgroups of the rows kernel = partial sets (fixed: the summation order must not follow the device)
+// The sums on the matrix cores, like the data rows' Gram matrices: a wave writes {J_g (6) | r | 0} of its 64 samples to LDS and
+// accumulates X^T X with v_mfma_f64_16x16x4 (16 steps of four samples per tile; A_g and g_g are its entries (i <= j < 6) and
+// (i, 6)); the accumulator is four doubles per lane where 27 running sums per thread made the kernel a 256-VGPR one: one wave
+// per SIMD, a tile's whole chain of dependent loads exposed -- 65 us for config 3's 762 tiles, 131 us for config 5's 5.2 k.
 template <int K>
-__global__ __launch_bounds__(kTile) void gn_global_rows_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(3, 8))) void gn_global_rows_kernel(const double *__restrict__ spos, const double *__restrict__ snrm,
                                                               const int *__restrict__ nbr, const double *__restrict__ wts,
                                                               const double *__restrict__ node_dq, const BuildParams p, int stride, long n_sub,
                                                               double *__restrict__ tile_part, const AssocArgs aa) {
     __shared__ double sPart[kTileWaves][kGlobalVals];
-    const int tid = threadIdx.x;
-    double acc[kGlobalVals];
-#pragma unroll
-    for (int e = 0; e < kGlobalVals; ++e) acc[e] = 0.0;
-    // a workgroup walks the tiles blockIdx.x, + gridDim.x, ... of the thinned list and keeps its sums in registers: at most
-    // kGlobalGrid partial sets for the reduce kernel (one set per TILE made that kernel's serial adds the whole step: 1.3 ms)
+    __shared__ double sX[kTile * 8];
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    double obj_acc = 0.0, cnt_acc = 0.0;
+    // a workgroup walks the tiles blockIdx.x, + gridDim.x, ... of the thinned list and keeps its sums: at most kGlobalGrid
+    // partial sets for the finish kernel (one set per TILE made that kernel's serial adds the whole step: 1.3 ms)
     for (long sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
-    const long s = sub * stride * kTile + tid;
-    if (s < p.S) {
-        int idx[kKMaxS];
-        double w[kKMaxS];
+        const long s = sub * stride * kTile + tid;
+        double jg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, rr = 0.0;
+        if (s < p.S) {
+            int idx[kKMaxS];
+            double w[kKMaxS];
 #pragma unroll
-        for (int j = 0; j < kKMaxS; ++j) {
-            idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
-            w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
-        }
-        double bh[8];
-        const double nb = blend_static(node_dq, idx, w, K, bh);
-        const double pfx = round_f32(spos[3 * (size_t)s]), pfy = round_f32(spos[3 * (size_t)s + 1]), pfz = round_f32(spos[3 * (size_t)s + 2]);
-        const D3 x1 = dqb_warp_exact(bh, pfx, pfy, pfz);
-        const D3 xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
-        double c[3];
-        const bool ok = aa.views ? associate_views<float>(aa.ap, aa.views, aa.n_views, xp, c) : associate_point<float>(aa.ap, aa.depth, xp, c);
-        if (ok) {
-            double Jrow[6 * K];
-            double r = data_row_from(node_dq, idx, w, K, p.lw.q, bh, nb, pfx, pfy, pfz, xp, snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1],
-                                     snrm[3 * (size_t)s + 2], c[0], c[1], c[2], Jrow);
-            double obj = 0.5 * r * r, sc = 1.0;
-            if (p.huber > 0.0 && fabs(r) > p.huber) {
-                obj = p.huber * (fabs(r) - 0.5 * p.huber);
-                sc = sqrt(p.huber / fabs(r));
+            for (int j = 0; j < kKMaxS; ++j) {
+                idx[j] = j < K ? nbr[(size_t)s * K + j] : 0;
+                w[j] = j < K ? wts[(size_t)s * K + j] : 0.0;
             }
-            r *= sc;
-            double jg[6];
+            double bh[8];
+            const double nb = blend_static(node_dq, idx, w, K, bh);
+            const double pfx = round_f32(spos[3 * (size_t)s]), pfy = round_f32(spos[3 * (size_t)s + 1]), pfz = round_f32(spos[3 * (size_t)s + 2]);
+            const D3 x1 = dqb_warp_exact(bh, pfx, pfy, pfz);
+            const D3 xp = dqb_warp_exact(p.lw.q, round_f32(x1.x), round_f32(x1.y), round_f32(x1.z));
+            double c[3];
+            const bool ok = aa.views ? associate_views<float>(aa.ap, aa.views, aa.n_views, xp, c) : associate_point<float>(aa.ap, aa.depth, xp, c);
+            if (ok) {
+                double Jrow[6 * K];
+                double r = data_row_from(node_dq, idx, w, K, p.lw.q, bh, nb, pfx, pfy, pfz, xp, snrm[3 * (size_t)s], snrm[3 * (size_t)s + 1],
+                                         snrm[3 * (size_t)s + 2], c[0], c[1], c[2], Jrow);
+                double obj = 0.5 * r * r, sc = 1.0;
+                if (p.huber > 0.0 && fabs(r) > p.huber) {
+                    obj = p.huber * (fabs(r) - 0.5 * p.huber);
+                    sc = sqrt(p.huber / fabs(r));
+                }
+                rr = r * sc;
 #pragma unroll
-            for (int c6 = 0; c6 < 6; ++c6) {
-                double v = 0.0;
+                for (int c6 = 0; c6 < 6; ++c6) {
+                    double v = 0.0;
 #pragma unroll
-                for (int a = 0; a < K; ++a) v += Jrow[6 * a + c6];
-                jg[c6] = v * sc;
+                    for (int a = 0; a < K; ++a) v += Jrow[6 * a + c6];
+                    jg[c6] = v * sc;
+                }
+                obj_acc += obj;
+                cnt_acc += 1.0;
             }
-            int e = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = i; j < 6; ++j) { acc[e] += jg[i] * jg[j]; ++e; }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acc[21 + i] += jg[i] * r;
-            acc[27] += obj;
-            acc[28] += 1.0;
         }
-    }
+        double *row = sX + 8 * tid;
+#pragma unroll
+        for (int c6 = 0; c6 < 6; ++c6) row[c6] = jg[c6];
+        row[6] = rr; row[7] = 0.0;
+        // (a wave reads only the rows its own lanes wrote; its LDS operations execute in order: no workgroup barrier)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#pragma unroll 4
+        for (int st = 0; st < 16; ++st) {                                     // A[i = li][k = lk] = B[k = lk][j = li] = X[64 wv + 4 st + lk][li]
+            const double x = li < 8 ? sX[8 * (64 * wv + 4 * st + lk) + li] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
-    for (int e = 0; e < kGlobalVals; ++e) {
-        double v = acc[e];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if ((tid & 63) == 0) sPart[tid >> 6][e] = v;
+    for (int r4 = 0; r4 < 4; ++r4) {                                          // C/D: column = lane & 15, row = (lane >> 4) + 4 r
+        const int pa = lk + 4 * r4, pb = li;
+        if (pa < 6 && pb >= pa && pb < 6) sPart[wv][pa * 6 - (pa * (pa - 1)) / 2 + (pb - pa)] = acc[r4];
+        else if (pa < 6 && pb == 6) sPart[wv][21 + pa] = acc[r4];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { obj_acc += __shfl_xor(obj_acc, o, 64); cnt_acc += __shfl_xor(cnt_acc, o, 64); }
+    if (lane == 0) { sPart[wv][27] = obj_acc; sPart[wv][28] = cnt_acc; }
     __syncthreads();
     if (tid < kGlobalVals) {
         double v = sPart[0][tid];
@@ -2649,30 +2664,9 @@ __global__ __launch_bounds__(kTile) void gn_global_rows_kernel(const double *__r
     }
 }
 
-// the tiles' partials added in index order (eight chunks of consecutive tiles, then the chunks): 29 sums
-__global__ __launch_bounds__(256) void gn_global_reduce_kernel(const double *__restrict__ tile_part, int n_tiles, double *__restrict__ sums) {
-    __shared__ double part[8][32];
-    const int e = threadIdx.x & 31, chunk = threadIdx.x >> 5;
-    const int per = (n_tiles + 7) / 8;
-    double v = 0.0;
-    if (e < kGlobalVals)
-        for (int t = chunk * per; t < min(n_tiles, (chunk + 1) * per); ++t) v += tile_part[(size_t)t * kGlobalVals + e];
-    part[chunk][e] = v;
-    __syncthreads();
-    if (threadIdx.x < kGlobalVals) {
-        double a = part[0][threadIdx.x];
-#pragma unroll
-        for (int c = 1; c < 8; ++c) a += part[c][threadIdx.x];
-        sums[threadIdx.x] = a;
-    }
-}
-
-// (A_g + lm diag A_g) xi = -g_g from the 29 sums (after an all-reduce over ranks, where the samples are sharded), xi to every node
-__global__ __launch_bounds__(256) void gn_global_apply_kernel(const double *__restrict__ sums, double lm_rel, int N, double *__restrict__ node_dq,
-                                                               double *__restrict__ xi_out /* 6 | objective, count */) {
-    __shared__ double sv[kGlobalVals], sxi[6];
-    if (threadIdx.x < kGlobalVals) sv[threadIdx.x] = sums[threadIdx.x];
-    __syncthreads();
+// the damped 6 x 6 solve and the twist for every node, from the 29 sums in LDS (sv); sxi: scratch
+__device__ __forceinline__ void global_solve_apply(const double *sv, double *sxi, double lm_rel, int N, double *__restrict__ node_dq,
+                                                   double *__restrict__ xi_out) {
     if (threadIdx.x < 6) {
         double D[36];
         int q = 0;
@@ -2695,7 +2689,48 @@ __global__ __launch_bounds__(256) void gn_global_apply_kernel(const double *__re
         if (threadIdx.x == 6) xi_out[6] = sv[27];
         if (threadIdx.x == 7) xi_out[7] = sv[28];
     }
-    for (int a = threadIdx.x; a < N; a += 256) apply_twist_one(node_dq + 8 * (size_t)a, sxi[0], sxi[1], sxi[2], sxi[3], sxi[4], sxi[5]);
+    for (int a = threadIdx.x; a < N; a += blockDim.x) apply_twist_one(node_dq + 8 * (size_t)a, sxi[0], sxi[1], sxi[2], sxi[3], sxi[4], sxi[5]);
+}
+
+// the workgroups' partials added in index order (32 chunks of consecutive sets, sixteen loads in flight per thread, then the
+// chunks): 29 sums; APPLY: the solve and the twists in the same launch (one rank: nothing to all-reduce in between).  The old
+// pair -- 8 chunks of 128 dependent load-and-add steps, then a launch for the solve -- took 29 + 8 us.
+template <bool APPLY>
+__global__ __launch_bounds__(1024) void gn_global_finish_kernel(const double *__restrict__ tile_part, int n_sets, double *__restrict__ sums,
+                                                                 double lm_rel, int N, double *__restrict__ node_dq, double *__restrict__ xi_out) {
+    __shared__ double part[32][32];
+    __shared__ double sv[32], sxi[6];
+    const int e = threadIdx.x & 31, chunk = threadIdx.x >> 5;
+    const int per = (n_sets + 31) / 32;
+    const int t0 = chunk * per, t1 = min(n_sets, t0 + per);
+    double v = 0.0;
+    for (int t = t0; t < t1; t += 16) {
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = (t + j < t1 && e < kGlobalVals) ? tile_part[(size_t)(t + j) * kGlobalVals + e] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += x[j];
+    }
+    part[chunk][e] = v;
+    __syncthreads();
+    if (threadIdx.x < kGlobalVals) {
+        double a = part[0][threadIdx.x];
+#pragma unroll
+        for (int c = 1; c < 32; ++c) a += part[c][threadIdx.x];
+        sv[threadIdx.x] = a;
+        sums[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (APPLY) global_solve_apply(sv, sxi, lm_rel, N, node_dq, xi_out);
+}
+
+// (A_g + lm diag A_g) xi = -g_g from the 29 sums (after an all-reduce over ranks, where the samples are sharded), xi to every node
+__global__ __launch_bounds__(256) void gn_global_apply_kernel(const double *__restrict__ sums, double lm_rel, int N, double *__restrict__ node_dq,
+                                                               double *__restrict__ xi_out /* 6 | objective, count */) {
+    __shared__ double sv[kGlobalVals], sxi[6];
+    if (threadIdx.x < kGlobalVals) sv[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+    global_solve_apply(sv, sxi, lm_rel, N, node_dq, xi_out);
 }
 
 __global__ __launch_bounds__(256) void apply_twist_kernel(double *__restrict__ node_dq, const double *__restrict__ xi, int N,
@@ -3756,8 +3791,8 @@ int dfh_gn_global_sampled_views(const double *sample_pos, const double *sample_n
         if (n_wg > 0)
             hipLaunchKernelGGL(gn_global_rows_kernel<4>, dim3((unsigned)n_wg), dim3(kTile), 0, st, sample_pos, sample_nrm, nbr, weights,
                                (const double *)node_dq, bp, stride, n_sub, tile_part, aa);
-        hipLaunchKernelGGL(gn_global_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)tile_part, n_wg, sums);
-        if (!sums_out) hipLaunchKernelGGL(gn_global_apply_kernel, dim3(1), dim3(256), 0, st, (const double *)sums, lm_rel, n_nodes, node_dq, xi_out);
+        if (sums_out) hipLaunchKernelGGL(gn_global_finish_kernel<false>, dim3(1), dim3(1024), 0, st, (const double *)tile_part, n_wg, sums, lm_rel, n_nodes, node_dq, xi_out);
+        else hipLaunchKernelGGL(gn_global_finish_kernel<true>, dim3(1), dim3(1024), 0, st, (const double *)tile_part, n_wg, sums, lm_rel, n_nodes, node_dq, xi_out);
     }
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;

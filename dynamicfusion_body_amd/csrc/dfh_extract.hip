@@ -221,101 +221,86 @@ __global__ __launch_bounds__(256) void surface_emit_vec_kernel(const float *__re
     }
 }
 
-// exclusive scan of the block counts in place (single workgroup), total -> *total_out.  16 K counts per round: every
-// thread takes 16 of them 1024 apart (coalesced, all loads in flight at once), waves scan by shuffles, wave 0 scans the
-// 256 wave totals, three barriers per round.
-// CHUNKED (volumes beyond 16 K blocks, i.e. beyond 256^3: round 4): one workgroup per 16 K counts scans ITS chunk from zero and
-// leaves the chunk's total in chunk_tot[blockIdx.x]; surface_scan_top_kernel scans those totals and surface_scan_add_kernel adds
-// every chunk's base to its counts -- three short launches instead of one workgroup walking eight rounds (512^3: 235 -> ~35 us).
-constexpr int kScanE = 16;
-template <bool CHUNKED>
-__global__ __launch_bounds__(1024) void surface_scan_kernel(int *__restrict__ block_count, int nblocks, long *__restrict__ total_out,
-                                                             long *__restrict__ chunk_tot) {
-    __shared__ long wtot[kScanE * 16];          // [chunk e][wave w] inclusive totals, chunk-major = scan order
-    __shared__ long woff[kScanE * 16 + 1];      // exclusive offsets of the same, [256] = the round's total
+// Exclusive scan of the block counts in place, total -> *total_out and the sentinel block_count[nblocks].
+// Two launches: a workgroup scans ITS 4 096 counts from zero (a thread takes four consecutive ones with one 16-byte load, the
+// waves scan the threads' sums with six 32-bit shuffles, sixteen wave totals go through LDS) and leaves the chunk's total; then
+// every 256 counts add the sum of the chunk totals before theirs.  (Rounds 2-4 scanned 16 K counts per workgroup with sixteen
+// 64-bit shuffle scans per thread: 192 ds_bpermute per wave, 3 072 through ONE CU's LDS pipe -- 29 us at 256^3 where this takes
+// 5 + 4; a single workgroup walking a 512^3 volume's list took 235 us.  Tried with it and dropped: one wave per block, four
+// blocks per workgroup in the count and emit passes (a quarter of the workgroups, no barrier) -- count 37 -> 50 us, emit 54 -> 75 us
+// at 256^3: the packs inside the band are what these passes take, and a wave then walks four of them in turn.)
+constexpr int kScanChunk = 4096;
+template <bool SINGLE>
+__global__ __launch_bounds__(1024) void surface_scan_chunk_kernel(int *__restrict__ block_count, int nblocks, long *__restrict__ chunk_tot,
+                                                                   long *__restrict__ total_out) {
+    __shared__ int wtot[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    long carry = 0;
-    const long first = CHUNKED ? (long)blockIdx.x * 1024 * kScanE : 0;
-    const long last = CHUNKED ? min((long)nblocks, first + 1024 * kScanE) : (long)nblocks;
-    for (long base = first; base < last; base += 1024 * kScanE) {
-        int v[kScanE];
-        long inc[kScanE];
+    const long base = (long)blockIdx.x * kScanChunk + 4 * (long)t;
+    int v[4] = {0, 0, 0, 0};
+    if (base + 3 < nblocks && ((uintptr_t)block_count & 15) == 0) {
+        const int4 q = *reinterpret_cast<const int4 *>(block_count + base);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
 #pragma unroll
-        for (int e = 0; e < kScanE; ++e) {
-            const long idx = base + (long)e * 1024 + t;
-            v[e] = idx < nblocks ? block_count[idx] : 0;
-        }
+        for (int j = 0; j < 4; ++j) v[j] = base + j < nblocks ? block_count[base + j] : 0;
+    }
+    const int sum = (v[0] + v[1]) + (v[2] + v[3]);      // (a chunk holds at most 4 096 x 1 024 samples: int is enough)
+    int x = sum;
 #pragma unroll
-        for (int e = 0; e < kScanE; ++e) {
-            long x = v[e];
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wtot[wv] = x;
+    __syncthreads();
+    int off = 0, all = 0;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const long y = __shfl_up(x, o, 64);
-                if (lane >= o) x += y;
-            }
-            inc[e] = x;
-            if (lane == 63) wtot[e * 16 + wv] = x;
-        }
-        __syncthreads();
-        if (wv == 0) {                            // 256 partials, 4 consecutive ones per lane
-            long p0 = wtot[4 * lane], p1 = wtot[4 * lane + 1], p2 = wtot[4 * lane + 2], p3 = wtot[4 * lane + 3];
-            long x = p0 + p1 + p2 + p3;
+    for (int w_ = 0; w_ < 16; ++w_) {
+        const int q = wtot[w_];
+        off += w_ < wv ? q : 0;
+        all += q;
+    }
+    const int ex = off + x - sum;
+    const int o4[4] = {ex, ex + v[0], ex + v[0] + v[1], ex + v[0] + v[1] + v[2]};
+    if (base + 3 < nblocks && ((uintptr_t)block_count & 15) == 0) {
+        *reinterpret_cast<int4 *>(block_count + base) = make_int4(o4[0], o4[1], o4[2], o4[3]);
+    } else {
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const long y = __shfl_up(x, o, 64);
-                if (lane >= o) x += y;
-            }
-            const long ex = x - (p0 + p1 + p2 + p3);
-            woff[4 * lane] = ex;
-            woff[4 * lane + 1] = ex + p0;
-            woff[4 * lane + 2] = ex + p0 + p1;
-            woff[4 * lane + 3] = ex + p0 + p1 + p2;
-            if (lane == 63) woff[kScanE * 16] = x;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < kScanE; ++e) {
-            const long idx = base + (long)e * 1024 + t;
-            if (idx < nblocks) block_count[idx] = (int)(carry + woff[e * 16 + wv] + inc[e] - v[e]);   // capacity is checked by the host against the total
-        }
-        carry += woff[kScanE * 16];
-        __syncthreads();                          // wtot / woff are rewritten in the next round
+        for (int j = 0; j < 4; ++j)
+            if (base + j < nblocks) block_count[base + j] = o4[j];
     }
     if (t == 0) {
-        if (CHUNKED) {
-            chunk_tot[blockIdx.x] = carry;
+        if (SINGLE) {
+            *total_out = (long)all;
+            block_count[nblocks] = all;               // sentinel: block b emits offset[b+1] - offset[b] samples
         } else {
-            *total_out = carry;
-            block_count[nblocks] = (int)carry;    // sentinel: block b emits offset[b+1] - offset[b] samples
+            chunk_tot[blockIdx.x] = (long)all;
         }
     }
 }
 
-// exclusive scan of the chunk totals in place (<= a few thousand: one wave), the volume's total, the sentinel
-__global__ __launch_bounds__(64) void surface_scan_top_kernel(long *__restrict__ chunk_tot, int nchunks, int *__restrict__ block_count, int nblocks,
-                                                               long *__restrict__ total_out) {
-    const int lane = threadIdx.x;
-    long carry = 0;
-    for (int base = 0; base < nchunks; base += 64) {
-        const long v = base + lane < nchunks ? chunk_tot[base + lane] : 0;
-        long x = v;
+// 256 counts per workgroup, all of one chunk: + the totals of the chunks before it (added up in index order by the workgroup
+// itself: a few hundred values at most); the last workgroup also leaves the volume's total and the sentinel
+__global__ __launch_bounds__(256) void surface_scan_add_kernel(int *__restrict__ block_count, int nblocks, const long *__restrict__ chunk_tot,
+                                                                long *__restrict__ total_out) {
+    __shared__ long part[4];
+    const int c = (int)(((long)blockIdx.x * 256) / kScanChunk);
+    const bool last = blockIdx.x == gridDim.x - 1;
+    const int upto = last ? c + 1 : c;                // (the last workgroup lies in the last chunk: + its own total = the volume's)
+    long v = 0;
+    for (int j = threadIdx.x; j < upto; j += 256) v += chunk_tot[j];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const long y = __shfl_up(x, o, 64);
-            if (lane >= o) x += y;
-        }
-        if (base + lane < nchunks) chunk_tot[base + lane] = carry + x - v;
-        carry += __shfl(x, 63, 64);
-    }
-    if (lane == 0) {
-        *total_out = carry;
-        block_count[nblocks] = (int)carry;
-    }
-}
-
-__global__ __launch_bounds__(256) void surface_scan_add_kernel(int *__restrict__ block_count, int nblocks, const long *__restrict__ chunk_base) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const long sum = (part[0] + part[1]) + (part[2] + part[3]);
+    const long base = last ? sum - chunk_tot[c] : sum;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < nblocks) block_count[i] += (int)chunk_base[i / (1024 * kScanE)];
+    if (i < nblocks && base != 0) block_count[i] += (int)base;
+    if (last && threadIdx.x == 0) {
+        *total_out = sum;
+        block_count[nblocks] = (int)sum;
+    }
 }
 
 template <typename VolT>
@@ -372,7 +357,7 @@ size_t dfh_surface_workspace_bytes(const int res[3]) {
     if (!res || res[0] <= 0 || res[1] <= 0 || res[2] <= 0) return 0;
     const long nvox = (long)res[0] * res[1] * res[2];
     const size_t nb = (size_t)((nvox + dfh::kExVox - 1) / dfh::kExVox);
-    const size_t nchunks = (nb + 1024 * dfh::kScanE - 1) / (1024 * dfh::kScanE);
+    const size_t nchunks = (nb + dfh::kScanChunk - 1) / dfh::kScanChunk;
     return ((sizeof(int) * (nb + 1) + 15) & ~(size_t)15) + sizeof(long) * (nchunks + 2);          // counts + sentinel | chunk totals of the scan
 }
 
@@ -395,14 +380,13 @@ int dfh_surface_count(const void *tsdf, const void *tsdf_w, int vol_dtype, const
     } else {
         hipLaunchKernelGGL(surface_count_kernel<double>, dim3((unsigned)nb), dim3(256), 0, s, (const double *)tsdf, (const double *)tsdf_w, p, bc);
     }
-    if (nb <= 1024 * kScanE) {
-        hipLaunchKernelGGL(surface_scan_kernel<false>, dim3(1), dim3(1024), 0, s, bc, (int)nb, total_out, (long *)nullptr);
+    if (nb <= kScanChunk) {
+        hipLaunchKernelGGL(surface_scan_chunk_kernel<true>, dim3(1), dim3(1024), 0, s, bc, (int)nb, (long *)nullptr, total_out);
     } else {
-        const int nchunks = (int)((nb + 1024 * kScanE - 1) / (1024 * kScanE));
+        const int nchunks = (int)((nb + kScanChunk - 1) / kScanChunk);
         long *chunk_tot = reinterpret_cast<long *>(static_cast<char *>(workspace) + ((sizeof(int) * ((size_t)nb + 1) + 15) & ~(size_t)15));
-        hipLaunchKernelGGL(surface_scan_kernel<true>, dim3((unsigned)nchunks), dim3(1024), 0, s, bc, (int)nb, total_out, chunk_tot);
-        hipLaunchKernelGGL(surface_scan_top_kernel, dim3(1), dim3(64), 0, s, chunk_tot, nchunks, bc, (int)nb, total_out);
-        hipLaunchKernelGGL(surface_scan_add_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, bc, (int)nb, (const long *)chunk_tot);
+        hipLaunchKernelGGL(surface_scan_chunk_kernel<false>, dim3((unsigned)nchunks), dim3(1024), 0, s, bc, (int)nb, chunk_tot, total_out);
+        hipLaunchKernelGGL(surface_scan_add_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, bc, (int)nb, (const long *)chunk_tot, total_out);
     }
     DFH_HIP_CHECK(hipGetLastError());
     return DFH_OK;

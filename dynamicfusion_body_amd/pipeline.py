@@ -299,9 +299,11 @@ class SlabFrame:
             kernels.integrate_depth_views(self.live, self.live_w, depth_list, self.K, self.Kinv, lw_list, self.scale, self.center,
                                           self.tdist_world, tsdf_res=R, res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_views,
                                           fresh=self.tvox)          # (the fill of the live volume is part of the sweep)
-        # The solver's per-frame plan depends on the samples only and the live volume on the depth maps only: the live-volume
-        # sweep (bandwidth-bound) runs on a side stream beside the plan's launches (bound by latency and atomics, with two
-        # read-backs in between); the streams join before the first GN iteration.  With stage timing the order is sequential.
+        # The solve reads the depth maps (projective association), not the live volume; the live volume depends on the depth maps
+        # only and is first read by the TSDF update.  So the live-volume sweep (bandwidth-bound) runs on a side stream beside the
+        # plan's launches AND the whole solve (bound by latency, ten waves per CU), and the streams join in front of the TSDF
+        # update (round 4; rounds 2-3 joined before the first GN iteration).  With stage timing the order is sequential.
+        joined = True
         if stage_ms is None and not _lib.opt_on("py_no_side_stream"):
             if self._side is None:
                 self._side = torch.cuda.Stream()
@@ -310,12 +312,10 @@ class SlabFrame:
             with torch.cuda.stream(self._side):
                 sweep_live()
             self.fs.solver.prepare()
-            main.wait_stream(self._side)
+            joined = False
         else:
             sweep_live()
         mark("live_tsdf")
-        live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
-        mark("allgather")
         # the rigid mode first (two steps: one twist shared by all nodes, fitted to the data rows -- FrameSolver.global_iteration),
         # then the node iterations (one host call: nothing between their launches depends on the host)
         ng = self.GLOBAL_ITERS if global_iters is None else int(global_iters)
@@ -326,6 +326,10 @@ class SlabFrame:
                                      stride=self.GLOBAL_STRIDE if global_stride is None else int(global_stride))
         self.fs.gn_iteration(solve_depth, solve_lw, rw=rw, lm_abs=lm_abs, lm_rel=lm_rel, max_dist=max_dist, huber=huber, n_iters=gn_iters)
         mark("solve")
+        if not joined:
+            torch.cuda.current_stream().wait_stream(self._side)
+        live_full = self.D.allgather_planes(self.live, R) if self.ws > 1 else self.live
+        mark("allgather")
         sv = self.fs.solver
         kernels.fuse_volume_dqb(self.T, self.Wt, live_full, sv.node_pos, sv.node_dq, sv.node_w, self.knn, self.ident_lw, self.tvox,
                                 res=(R, R, R), x_range=(self.a, self.b), workspace=self.ws_dqb, rebuild_candidates=self._first)

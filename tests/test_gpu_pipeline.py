@@ -134,19 +134,26 @@ def test_device_extraction_matches_torch_definition(dtype):
         extract_surface_samples(Td, Wd[:2], 1.5)
 
 
-def test_device_extraction_more_than_one_scan_round():
-    """> 16 384 blocks of 1 024 voxels: the in-workgroup scan of the block counts takes a second (partial) round."""
+@pytest.mark.parametrize("shape", [(258, 256, 260), (128, 128, 256), (129, 128, 256), (131, 130, 252)])
+def test_device_extraction_more_than_one_scan_chunk(shape):
+    """The scan of the block counts (1 024 voxels per block) works in chunks of 4 096 counts, one workgroup each, and a second
+    launch adds the chunk bases (csrc/dfh_extract.hip): 16 770 blocks = five chunks, the last one partly filled; exactly 4 096 blocks
+    (the single-workgroup case, full); 4 128 (a second chunk of 32 blocks); 4 191 blocks whose last one is cut by the volume's end."""
     from dynamicfusion_body_amd.pipeline import extract_surface_samples_torch
-    shape = (258, 256, 260)
     ax = [torch.arange(s, device="cuda", dtype=torch.float64) for s in shape]
-    d = torch.sqrt((ax[0][:, None, None] - 130.3) ** 2 + (ax[1][None, :, None] - 127.6) ** 2 + (ax[2][None, None, :] - 131.1) ** 2)
-    Td = (d - 90.0).to(torch.float32).contiguous()
+    c = [0.505 * s for s in shape]
+    d = torch.sqrt((ax[0][:, None, None] - c[0]) ** 2 + (ax[1][None, :, None] - c[1]) ** 2 + (ax[2][None, None, :] - c[2]) ** 2)
+    Td = (d - 0.35 * min(shape)).to(torch.float32).contiguous()
     Wd = ((ax[0][:, None, None] + ax[1][None, :, None] * 3 + ax[2][None, None, :] * 7) % 5 != 0).to(torch.float32).contiguous()
     pos, nrm = extract_surface_samples(Td, Wd, 1.5)
     pt, nt = extract_surface_samples_torch(Td, Wd, 1.5)
-    assert pos.shape == pt.shape and pos.shape[0] > 100000
+    assert pos.shape == pt.shape and pos.shape[0] > 20000
     assert float((pos - pt).abs().max()) <= 1e-12 and float((nrm - nt).abs().max()) <= 1e-12
-    assert float(pos[-1, 0]) > 200.0                                     # samples behind the first 16 384 blocks are there
+    assert float(pos[-1, 0]) > 0.75 * shape[0]                           # samples behind the first chunk(s) are there
+    cap = pos.shape[0] // 3                                               # (the even subsample reads the total behind the last chunk)
+    sel = (torch.arange(cap, device="cuda", dtype=torch.int64) * pos.shape[0] + cap - 1) // cap
+    p2, _ = extract_surface_samples(Td, Wd, 1.5, max_samples=cap)
+    assert torch.equal(p2, pos[sel])
 
 
 def test_composed_frame_loop_tracks_without_drift():

@@ -122,6 +122,36 @@ def test_rigid_slabs_and_errors():
         kernels.fuse_volume_rigid(Tf, Wf[:3], live, lw, tdist)
 
 
+@pytest.mark.parametrize("res", [(64, 64, 256), (40, 36, 252), (33, 30, 64)])
+def test_rigid_non_temporal_and_strided_paths_give_the_same_bits(res):
+    """K2's float32 kernel has four shapes: a lane's four voxels 64 apart along z (z rows of whole 256-voxel runs) or next to each
+    other, T / w through the caches or non-temporal (option k2_nt; the library's own choice: slabs whose pair of volumes exceeds the
+    Infinity Cache).  One expression, one set of bits -- whole grid and slabs."""
+    from dynamicfusion_body_amd import _lib
+    rng = np.random.default_rng(17)
+    tdist = 4.0
+    c = np.array(res) / 2.0
+    live = dev(sphere_volume(res, c + np.array([0.4, -0.3, 0.6]), 0.3 * min(res), tdist), torch.float32)
+    T0 = sphere_volume(res, c, 0.31 * min(res), tdist); W0 = rng.integers(0, 4, size=res).astype(np.float64)
+    lw = small_dq(rng, 0.02, 0.4)
+    ref = None
+    for nt, no_strided in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        _lib.set_option("k2_nt", nt)
+        _lib.set_option("k2_no_strided", no_strided)
+        T, W = dev(T0, torch.float32), dev(W0, torch.float32)
+        kernels.fuse_volume_rigid(T, W, live, lw, tdist)
+        Ts, Ws = dev(T0, torch.float32), dev(W0, torch.float32)
+        a = res[0] // 3
+        for x0, x1 in ((0, a), (a, res[0])):
+            kernels.fuse_volume_rigid(Ts[x0:x1], Ws[x0:x1], live, lw, tdist, res=res, x_range=(x0, x1))
+        assert torch.equal(Ts, T) and torch.equal(Ws, W)
+        if ref is None:
+            ref = (T, W)
+            assert int((W != dev(W0, torch.float32)).sum()) > 0.5 * W.numel()          # (the call does update most voxels)
+        else:
+            assert torch.equal(T, ref[0]) and torch.equal(W, ref[1]), (nt, no_strided)
+
+
 # ------------------------------------------------------------------------------ K3
 def make_fusion(g, vol_dtype):
     fu = Fusion(g["T0"], float(g["tdist"]), knn=int(g["knn"]), volume_dtype=vol_dtype)
